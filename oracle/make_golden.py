@@ -1,0 +1,145 @@
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz by running the REFERENCE's own module code.
+
+Runs only in the build container (needs /root/reference; third-party deps come from
+oracle/shims). Each fixture holds seeded inputs + the reference's outputs; the tests compare
+`oracle/forge_oracle.py` (CPU) and the HIP path (GPU box) against them. No reference source is
+copied: the fixtures are data.
+
+    python oracle/make_golden.py            # (re)writes tests/golden/*.npz and prints oracle-vs-reference errors
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import forge_oracle as fo          # noqa: E402
+import ref_import                  # noqa: E402
+from forge_amd import synthetic as syn   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def npz(name, **arrays):
+    arrays = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **arrays)
+    print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def err(tag, ref, mine):
+    print("  oracle vs reference %-18s max|diff| = %.3e (|ref|max %.3g)" % (tag, (ref - mine).abs().max().item(), ref.abs().max().item()))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    m = ref_import.import_reference()
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+
+    # ---------------- rotate (models/rotate.py:92-156) ----------------
+    cfg = ref_import.kubric_config()
+    rot = m["models.rotate"].Rotate_world(cfg)
+    jit = (torch.rand(10, 2, generator=g) - 0.5) * 0.3
+    poses, extr, _ = syn.orbit_cameras(10, 1.5, 15.0, jit)
+    vox = torch.rand(1, 3, 4, 16, 16, 16, generator=g)
+    P = poses[None, [0, 1, 3]].contiguous()
+    with torch.no_grad():
+        out = rot(voxels=vox, camPoses_cv2=P, grid_size=16)
+    err("rotate16", out, fo.rotate_world(vox, P, 1.0))
+    npz("rotate_d16", voxels=vox, poses=P, out=out, vol_size=1.0, half_extent=rot.grid_coord_max_16)
+    vox = torch.rand(1, 2, 1, 32, 32, 32, generator=g)
+    P = torch.eye(4)[None, None].repeat(1, 2, 1, 1)
+    with torch.no_grad():
+        out = rot(voxels=vox, camPoses_cv2=P, grid_size=32)
+    err("rotate32-identity", out, fo.rotate_world(vox, P, 1.0))
+    npz("rotate_identity_d32", voxels=vox, poses=P, out=out, vol_size=1.0, half_extent=rot.grid_coord_max)
+
+    # ---------------- renderer (models/volume_render.py:40-88) ----------------
+    cfg_r = ref_import.kubric_config(img_size=64, n_pts_per_ray=48)
+    vr = m["models.volume_render"].VolRender(cfg_r).eval()
+    sd = syn.seeded_state_dict({"render." + k: v for k, v in vr.state_dict().items()}, 3)
+    vr.load_state_dict({k[len("render."):]: v for k, v in sd.items()})
+    feat, dens = syn.blob_volumes(4, 16, 16, seed=5)
+    E = extr[[0, 2, 6, 9]].clone()
+    E[3, 0, 3] += 0.35           # off-centre camera: some rays miss the volume entirely
+    K = syn.intrinsics(64)[None].repeat(4, 1, 1)
+    K[2, 0, 2] += 3.0            # non-central principal point / anisotropic focal
+    K[2, 1, 1] *= 1.1
+    cam = {"R": E[:, :3, :3].clone(), "T": E[:, :3, 3].clone(), "K": K.clone()}
+    with torch.no_grad():
+        imgs, sil, depth, oproj = vr(cam, feat, dens, render_depth=True, return_origin_proj=True)
+        mine = fo.vol_render(feat, dens, E[:, :3, :3], E[:, :3, 3], K, sd, 64, 48, 0.5, 2.0, 1.0, 5, True, True)
+    for t, a, b in zip(("img", "sil", "depth", "origin_proj"), (imgs, sil, depth, oproj), mine):
+        err("render." + t, a, b)
+    # raw ray-marcher output, called exactly as volume_render.py:53-63 does
+    from pytorch3d.structures import Volumes
+    from pytorch3d.utils.camera_conversions import cameras_from_opencv_projection
+    Kh = fo.halve_intrinsics(K)
+    cams = cameras_from_opencv_projection(R=E[:, :3, :3], tvec=E[:, :3, 3], camera_matrix=Kh,
+                                          image_size=torch.tensor([32, 32])[None].repeat(4, 1))
+    with torch.no_grad():
+        raw = vr.renderer(cameras=cams, volumes=Volumes(densities=dens, features=feat, voxel_size=1.0 / 16),
+                          render_depth=True)[0]
+    err("render.raw", raw, fo.render_rays(feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, 32, 32, 48, 0.5, 2.0, 1.0, True))
+    npz("render_d16", feat=feat, dens=dens, R=E[:, :3, :3], T=E[:, :3, 3], K=K, img_size=64, n_pts=48,
+        min_depth=0.5, max_depth=2.0, vol_size=1.0, weight_seed=3, raw=raw, imgs=imgs, sil=sil, depth=depth,
+        origin_proj=oproj, **{"w." + k: v for k, v in sd.items()})
+
+    # ---------------- ConvGRU fusion (models/fusion.py:71-95 via models/encoder.py:59-63) ----------------
+    gru = m["models.fusion"].ConvGRU_3D(cfg, n_layers=1, input_size=8, hidden_size=8).eval()
+    pre = "encoder_3d.fusion_feature."
+    sdg = syn.seeded_state_dict({pre + k: v for k, v in gru.state_dict().items()}, 7)
+    gru.load_state_dict({k[len(pre):]: v for k, v in sdg.items()})
+    x = torch.randn(2, 3, 8, 6, 6, 6, generator=g)
+    with torch.no_grad():
+        out = gru(x, [gru.fusion_conv(x.mean(dim=1))])
+    err("fuse", out, fo.fuse(x, sdg))
+    npz("gru_toy", x=x, out=out, **{"w." + k: v for k, v in sdg.items()})
+
+    # ---------------- full model: encoder stage, heads, forward (seeded weights, not stored) -------------
+    model = m["models.model_single_pose_estimator"].FORGE_poseEstimator3D(cfg).eval()
+    sdm = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(sdm)
+    keys = np.array(sorted(model.state_dict().keys()))
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    npz("state_dict_keys_pose3d", keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
+    z = torch.randn(1, 128, 4, 4, 4, generator=g)
+    with torch.no_grad():
+        d = model.encoder_3d.get_density3D(z)
+        r = model.encoder_3d.get_render_features(z)
+    err("density_head", d, fo.density_head(z, sdm))
+    err("features_head", r, fo.render_features_head(z, sdm))
+    npz("heads_toy", z=z, density=d, features=r, weight_seed=0)
+
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=0)
+    ds = syn.SyntheticDataset(1.5)
+    with torch.no_grad():
+        f3 = model.encoder_3d.get_feat3D(sample["images"][0, :1])
+        imgs, masks = model({k: v.clone() for k, v in sample.items()}, ds, "cpu")
+        oi, om = fo.forward_pose3d_gt(sample, sdm, cfg)
+    err("get_feat3D", f3, fo.get_feat3D(sample["images"][0, :1], sdm))
+    err("forward.imgs", imgs, oi)
+    err("forward.masks", masks, om)
+    print("  forward PSNR(oracle, reference) = %.2f dB" % fo.psnr(oi, imgs))
+    npz("forward_pose3d", sample_seed=0, weight_seed=0, feat3d_sub=f3[:, ::8, ::4, ::4, ::4],
+        imgs_sub=imgs[:, :, ::4, ::4], masks_sub=masks[:, :, ::4, ::4],
+        imgs_mean=imgs.mean(dim=(1, 2, 3)), masks_mean=masks.mean(dim=(1, 2, 3)))
+
+    # joint model (models/model.py) key list for the state-dict surface test
+    if m.get("models.model") is not None:
+        jm = m["models.model"].FORGE(ref_import.kubric_config(use_gt_pose=False, parameter="joint"))
+        keys = np.array(sorted(jm.state_dict().keys()))
+        shapes = {k: tuple(v.shape) for k, v in jm.state_dict().items()}
+        npz("state_dict_keys_joint", keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
+
+
+if __name__ == "__main__":
+    main()

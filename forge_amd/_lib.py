@@ -1,0 +1,58 @@
+"""ctypes binding of libforge_hip.so (include/forge_hip.h). No fallbacks: if the library is
+missing or a call fails, a RuntimeError is raised — the product never routes through a CPU path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libforge_hip.so")
+_lib = None
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_F = ctypes.c_float
+_LL = ctypes.c_longlong
+
+# name -> argtypes; must list every symbol declared in include/forge_hip.h (tests check this)
+SIGNATURES = {
+    "forge_version": [],
+    "forge_last_error": [],
+    "forge_rotate_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
+    "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
+    "forge_ncdhw_to_ndhwc": [_P, _P, _I, _I, _LL, _P],
+    "forge_ndhwc_to_ncdhw": [_P, _P, _I, _I, _LL, _P],
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "forge_amd: %s not found. Build it with `python -m forge_amd.build` (needs hipcc, "
+                "targets gfx950). There is no CPU/PyTorch fallback for the HIP kernels." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_char_p if name == "forge_last_error" else _I
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().forge_last_error().decode("utf-8", "replace")
+        raise RuntimeError("forge_amd: %s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,19 @@
+// api.cpp — version + thread-local error string of the C-ABI (include/forge_hip.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/forge_hip.h"
+
+namespace forge {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace forge
+
+extern "C" int forge_version(void) { return 100; /* 0.1.0 */ }
+extern "C" const char* forge_last_error(void) { return forge::g_err; }

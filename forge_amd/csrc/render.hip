@@ -1,0 +1,377 @@
+// render.hip — a6: fused ray sampler + trilinear volume sampler + emission-absorption ray-marcher.
+//
+// Replaces models/volume_render.py:53-63 of the reference, i.e. PyTorch3D's
+// cameras_from_opencv_projection -> NDCGridRaysampler -> VolumeSampler (2x grid_sample,
+// align_corners=True, zeros) -> EmissionAbsorptionRaymarcher (+ README.md:26-33 depth patch),
+// which materialise ray points (12.6 MB/view) and sampled tensors (71 MB/view) in HBM.
+// Here nothing is materialised: each ray is marched in registers.
+//
+// Work decomposition (gfx950, wave = 64): C/4 lanes per ray, each lane owning 4 feature channels
+// (one 16-byte channels-last load per tap) and all lanes of a ray sharing the density taps. A wave
+// covers a 4x4 pixel quad (C=16), a 256-thread workgroup an 8x8 pixel tile, so the lanes of a
+// wave walk neighbouring rays in lock-step and their taps hit the same L1 lines. The march is
+// sequential per ray (transmittance carried in a register, same multiplication order as
+// torch.cumprod), but tap addresses do not depend on loaded data, so the compiler keeps the next
+// sample's 16 loads in flight under the current sample's FMAs.
+//
+// Exact early-outs only (densities are unclamped): (i) samples whose 8 taps are
+// all outside the grid contribute d = 0 exactly -> the march is restricted to the conservative
+// ray/AABB sample interval; (ii) T == 0 exactly -> every later weight is exactly 0.
+//
+// Roofline: compulsory HBM traffic is tiny (one read of the 17-channel volume per scene + the
+// output planes); the kernel is bound by L1/TA gather rate — see DESIGN.md.
+#include "common.h"
+
+namespace forge {
+
+struct RayCam {
+    float ox, oy, oz;      // camera centre  c = -R^T t
+    float dx, dy, dz;      // un-normalised world direction R^T ((w+.5-cx)/fx, (h+.5-cy)/fy, 1)
+};
+
+__device__ __forceinline__ RayCam make_ray(const float* __restrict__ cam, int w, int h) {
+    // cam: R[9] row-major, T[3], fx, fy, cx, cy
+    const float dxc = ((float)w + 0.5f - cam[14]) / cam[12];
+    const float dyc = ((float)h + 0.5f - cam[15]) / cam[13];
+    RayCam r;
+    r.dx = cam[0] * dxc + cam[3] * dyc + cam[6];
+    r.dy = cam[1] * dxc + cam[4] * dyc + cam[7];
+    r.dz = cam[2] * dxc + cam[5] * dyc + cam[8];
+    r.ox = -(cam[0] * cam[9] + cam[3] * cam[10] + cam[6] * cam[11]);
+    r.oy = -(cam[1] * cam[9] + cam[4] * cam[10] + cam[7] * cam[11]);
+    r.oz = -(cam[2] * cam[9] + cam[5] * cam[10] + cam[8] * cam[11]);
+    return r;
+}
+
+// torch.linspace(zmin, zmax, S)[s]: ATen fills the first half as start + step*i and the second
+// half as end - step*(S-1-i).
+__device__ __forceinline__ float sample_depth(int s, int S, float zmin, float zmax, float step) {
+    return (s < S / 2) ? (zmin + step * (float)s) : (zmax - step * (float)(S - 1 - s));
+}
+
+// Conservative sample-index interval [s0, s1] in which a ray can have any in-range tap.
+// pix_a(z) = alpha_a + beta_a z must lie in (-1, N_a) on all three axes.
+__device__ __forceinline__ void ray_interval(const RayCam& r, float hx, float hy, float hz, int W, int H, int D,
+                                             int S, float zmin, float step, int& s0, int& s1) {
+    float lo = -INFINITY, hi = INFINITY;
+    const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz}, hh[3] = {hx, hy, hz};
+    const int N[3] = {W, H, D};
+    bool empty = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float sc = 0.5f * (float)(N[a] - 1);
+        const float alpha = (o[a] / hh[a] + 1.f) * sc, beta = (d[a] / hh[a]) * sc;
+        const float pmin = -1.001f, pmax = (float)N[a] + 0.001f;
+        if (fabsf(beta) < 1e-20f) {
+            empty |= !(alpha > pmin && alpha < pmax);
+        } else {
+            const float t1 = (pmin - alpha) / beta, t2 = (pmax - alpha) / beta;
+            lo = fmaxf(lo, fminf(t1, t2));
+            hi = fminf(hi, fmaxf(t1, t2));
+        }
+    }
+    if (empty || !(lo <= hi)) { s0 = 0; s1 = -1; return; }
+    const float fs0 = floorf((lo - zmin) / step) - 1.f, fs1 = ceilf((hi - zmin) / step) + 1.f;
+    s0 = (int)fmaxf(fs0, 0.f);
+    s1 = (int)fminf(fs1, (float)(S - 1));
+    if (fs1 < 0.f || fs0 > (float)(S - 1)) { s0 = 0; s1 = -1; }
+}
+
+struct Taps {
+    long long i000;                 // voxel index of the clamped (z0,y0,x0) tap
+    int ox, oy, oz;                 // voxel-index offsets to the +x/+y/+z taps (0 when clamped)
+    float w[8];                     // trilinear weights, 0 for out-of-range taps
+    bool any;
+};
+
+// align_corners=True un-normalisation ((l + 1) / 2) * (N - 1) in ATen's operation order.
+__device__ __forceinline__ void taps_ac_true(float px, float py, float pz, int W, int H, int D, Taps& t) {
+    px = fminf(fmaxf(px, -2.f), (float)W + 1.f);
+    py = fminf(fmaxf(py, -2.f), (float)H + 1.f);
+    pz = fminf(fmaxf(pz, -2.f), (float)D + 1.f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)(x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)(y0 + 1) < (unsigned)H;
+    const bool vz0 = (unsigned)z0 < (unsigned)D, vz1 = (unsigned)(z0 + 1) < (unsigned)D;
+    t.any = (vx0 | vx1) & (vy0 | vy1) & (vz0 | vz1);
+    const float wxa = vx0 ? (fx + 1.f) - px : 0.f, wxb = vx1 ? px - fx : 0.f;
+    const float wya = vy0 ? (fy + 1.f) - py : 0.f, wyb = vy1 ? py - fy : 0.f;
+    const float wza = vz0 ? (fz + 1.f) - pz : 0.f, wzb = vz1 ? pz - fz : 0.f;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    const int za = min(max(z0, 0), D - 1), zb = min(max(z0 + 1, 0), D - 1);
+    t.i000 = ((long long)za * H + ya) * W + xa;
+    t.ox = xb - xa; t.oy = (yb - ya) * W; t.oz = (zb - za) * H * W;
+    t.w[0] = wxa * wya * wza; t.w[1] = wxb * wya * wza; t.w[2] = wxa * wyb * wza; t.w[3] = wxb * wyb * wza;
+    t.w[4] = wxa * wya * wzb; t.w[5] = wxb * wya * wzb; t.w[6] = wxa * wyb * wzb; t.w[7] = wxb * wyb * wzb;
+}
+
+__device__ __forceinline__ long long tap_off(const Taps& t, int k) {
+    return t.i000 + ((k & 1) ? t.ox : 0) + ((k & 2) ? t.oy : 0) + ((k & 4) ? t.oz : 0);
+}
+
+// ray r_local of a workgroup -> pixel inside the 8 x (RPB/8) tile, 4x4 quads per 16 consecutive rays
+__device__ __forceinline__ void tile_pixel(int r, int& lx, int& ly) {
+    lx = (r & 3) | (((r >> 4) & 1) << 2);
+    ly = ((r >> 2) & 3) | ((r >> 5) << 2);
+}
+
+template <int C4>
+__global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
+                                                         const float* __restrict__ cams, const int* __restrict__ view2vol,
+                                                         float* __restrict__ out_feat, float* __restrict__ out_opac,
+                                                         float* __restrict__ out_depth, int D, int H, int W, int Hr, int Wr,
+                                                         int S, float zmin, float zmax, float hx, float hy, float hz) {
+    constexpr int RPB = 256 / C4, TH = RPB / 8;
+    const int v = blockIdx.z;
+    const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
+    int lx, ly;
+    tile_pixel(r, lx, ly);
+    const int w = blockIdx.x * 8 + lx, h = blockIdx.y * TH + ly;
+    if (w >= Wr || h >= Hr) return;
+    const float* cam = cams + v * 16;
+    const long long nvox = (long long)D * H * W;
+    const float4* F = feat + (long long)view2vol[v] * nvox * C4 + cg;
+    const float* Dn = dens + (long long)view2vol[v] * nvox;
+
+    const RayCam ray = make_ray(cam, w, h);
+    const float step = (zmax - zmin) / (float)(S - 1);
+    int s0, s1;
+    ray_interval(ray, hx, hy, hz, W, H, D, S, zmin, step, s0, s1);
+    const float scx = (float)(W - 1), scy = (float)(H - 1), scz = (float)(D - 1);
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float T = 1.f, depth = 0.f;
+#pragma unroll 2
+    for (int s = s0; s <= s1; ++s) {
+        const float z = sample_depth(s, S, zmin, zmax, step);
+        const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
+        const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
+        const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
+        Taps t;
+        taps_ac_true(px, py, pz, W, H, D, t);
+        if (!t.any) continue;                     // d = 0 exactly: weight 0, T unchanged
+        float d = 0.f;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long o = tap_off(t, k);
+            d = fmaf(t.w[k], Dn[o], d);
+            f = f4_fma(t.w[k], F[o * C4], f);
+        }
+        const float wgt = d * T;
+        acc = f4_fma(wgt, f, acc);
+        depth = fmaf(wgt, z, depth);
+        T *= (1.f - d);
+        if (T == 0.f) break;                      // all later weights are exactly 0
+    }
+    const long long plane = (long long)Hr * Wr, pix = (long long)h * Wr + w;
+    float* of = out_feat + ((long long)v * (C4 * 4) + cg * 4) * plane + pix;
+    of[0] = acc.x; of[plane] = acc.y; of[2 * plane] = acc.z; of[3 * plane] = acc.w;
+    if (cg == 0) {
+        out_opac[(long long)v * plane + pix] = 1.f - T;
+        if (out_depth) out_depth[(long long)v * plane + pix] = depth;
+    }
+}
+
+// Backward. Pass 1 re-marches the densities and parks (d_s, T_s) of every sample in LDS
+// ([s][ray] so a wave's lanes hit consecutive banks); pass 2 walks the ray backwards with
+//     dL/dd_s = T_s (a_s - Q_s),  Q_{s-1} = a_s d_s + (1 - d_s) Q_s,  Q_{S-1} = -g_opacity,
+//     a_s = sum_c g_c f_sc + g_depth z_s          (no division by (1 - d_s): densities may be 1)
+// and scatter-adds through the same 8 taps with hardware fp32 atomics.
+template <int C4>
+__global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
+                                                         const float* __restrict__ cams, const int* __restrict__ view2vol,
+                                                         const float* __restrict__ g_feat, const float* __restrict__ g_opac,
+                                                         const float* __restrict__ g_depth, float* __restrict__ dfeat,
+                                                         float* __restrict__ ddens, int D, int H, int W, int Hr, int Wr,
+                                                         int S, float zmin, float zmax, float hx, float hy, float hz) {
+    constexpr int RPB = 256 / C4, TH = RPB / 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][S][RPB]
+    float* lds_d = lds;
+    float* lds_T = lds + (size_t)S * RPB;
+    const int v = blockIdx.z;
+    const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
+    int lx, ly;
+    tile_pixel(r, lx, ly);
+    const int w = blockIdx.x * 8 + lx, h = blockIdx.y * TH + ly;
+    const bool inside = (w < Wr) && (h < Hr);
+    const float* cam = cams + v * 16;
+    const long long nvox = (long long)D * H * W;
+    const long long vbase = (long long)view2vol[v] * nvox;
+    const float4* F = feat + vbase * C4 + cg;
+    const float* Dn = dens + vbase;
+
+    const RayCam ray = make_ray(cam, min(w, Wr - 1), min(h, Hr - 1));
+    const float step = (zmax - zmin) / (float)(S - 1);
+    int s0 = 0, s1 = -1;
+    if (inside) ray_interval(ray, hx, hy, hz, W, H, D, S, zmin, step, s0, s1);
+    const float scx = (float)(W - 1), scy = (float)(H - 1), scz = (float)(D - 1);
+
+    // pass 1: densities + transmittance (every lane of the ray computes the same values; lane cg==0 stores)
+    float T = 1.f;
+    int s_last = s0 - 1;          // last sample marched in the forward pass
+    for (int s = s0; s <= s1; ++s) {
+        const float z = sample_depth(s, S, zmin, zmax, step);
+        const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
+        const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
+        const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
+        Taps t;
+        taps_ac_true(px, py, pz, W, H, D, t);
+        float d = 0.f;
+        if (t.any) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d = fmaf(t.w[k], Dn[tap_off(t, k)], d);
+        }
+        if (cg == 0) { lds_d[s * RPB + r] = d; lds_T[s * RPB + r] = T; }
+        T *= (1.f - d);
+        s_last = s;
+        if (T == 0.f) break;
+    }
+    __syncthreads();
+
+    const long long plane = (long long)Hr * Wr, pix = (long long)min(h, Hr - 1) * Wr + min(w, Wr - 1);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float gop = 0.f, gdep = 0.f;
+    if (inside) {
+        const float* gf = g_feat + ((long long)v * (C4 * 4) + cg * 4) * plane + pix;
+        g = make_float4(gf[0], gf[plane], gf[2 * plane], gf[3 * plane]);
+        gop = g_opac[(long long)v * plane + pix];
+        if (g_depth) gdep = g_depth[(long long)v * plane + pix];
+    }
+    // Samples after an exact T == 0 break have weight 0 and T_s = 0: dL/dd_s = 0, and Q only matters
+    // multiplied by T_s = 0 further down... except through (1-d) factors of *earlier* samples, for
+    // which the forward value of later samples is irrelevant once T hit 0 exactly only if the zero
+    // came from the last marched sample (d = 1): Q_{s_last} would need later terms. They are all
+    // multiplied by T_j = 0 in the true gradient, so starting the recurrence at s_last with
+    // Q = -g_op * prod_{i > s_last}(1 - d_i) is required; that product is not known without marching
+    // on. Keep it exact: when the forward pass broke early, finish marching densities here.
+    float Q = -gop;
+    if (inside && s_last < s1) {
+        // rare path (T == 0 exactly): fold the tail's (1 - d) factors and a_j d_j terms into Q
+        for (int s = s1; s > s_last; --s) {
+            const float z = sample_depth(s, S, zmin, zmax, step);
+            const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
+            const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
+            const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
+            Taps t;
+            taps_ac_true(px, py, pz, W, H, D, t);
+            float d = 0.f;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t.any) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const long long o = tap_off(t, k);
+                    d = fmaf(t.w[k], Dn[o], d);
+                    f = f4_fma(t.w[k], F[o * C4], f);
+                }
+            }
+            float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
+#pragma unroll
+            for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
+            a = fmaf(gdep, z, a);
+            Q = fmaf(a, d, (1.f - d) * Q);
+        }
+    }
+    // pass 2: reverse march over the samples the forward pass visited.
+    // NOTE: all C4 lanes of a ray have identical (s0, s_last), so the xor-shuffles below are
+    // executed by all lanes of each ray group together.
+    for (int s = s_last; s >= s0; --s) {
+        const float z = sample_depth(s, S, zmin, zmax, step);
+        const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
+        const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
+        const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
+        Taps t;
+        taps_ac_true(px, py, pz, W, H, D, t);
+        const float d = lds_d[s * RPB + r], Ts = lds_T[s * RPB + r];
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t.any) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f = f4_fma(t.w[k], F[tap_off(t, k) * C4], f);
+        }
+        float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
+#pragma unroll
+        for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
+        a = fmaf(gdep, z, a);
+        const float dLdd = Ts * (a - Q);
+        Q = fmaf(a, d, (1.f - d) * Q);
+        if (t.any) {
+            const float wgt = d * Ts;
+            const float4 gw = make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (t.w[k] != 0.f) {
+                    const long long o = tap_off(t, k);
+                    float* df = dfeat + ((vbase + o) * C4 + cg) * 4;
+                    atomic_add_f32(df + 0, t.w[k] * gw.x);
+                    atomic_add_f32(df + 1, t.w[k] * gw.y);
+                    atomic_add_f32(df + 2, t.w[k] * gw.z);
+                    atomic_add_f32(df + 3, t.w[k] * gw.w);
+                    if (cg == 0) atomic_add_f32(ddens + vbase + o, t.w[k] * dLdd);
+                }
+            }
+        }
+    }
+}
+
+static int check_render_args(const char* fn, const void* feat, const void* dens, const void* cam, const void* v2v,
+                             int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S, float hx, float hy, float hz) {
+    FORGE_REQUIRE(feat && dens && cam && v2v, FORGE_EINVAL, "%s: null pointer argument", fn);
+    FORGE_REQUIRE(V > 0 && nvol > 0 && D > 1 && H > 1 && W > 1 && Hr > 0 && Wr > 0 && S > 1, FORGE_EINVAL,
+                  "%s: bad dims V=%d nvol=%d D=%d H=%d W=%d Hr=%d Wr=%d S=%d", fn, V, nvol, D, H, W, Hr, Wr, S);
+    FORGE_REQUIRE(C == 4 || C == 8 || C == 16 || C == 32, FORGE_ESHAPE, "%s: C=%d unsupported (4, 8, 16 or 32)", fn, C);
+    FORGE_REQUIRE(hx > 0.f && hy > 0.f && hz > 0.f, FORGE_EINVAL, "%s: half extents must be > 0", fn);
+    FORGE_REQUIRE(V <= 65535, FORGE_ESHAPE, "%s: V=%d exceeds gridDim.z", fn, V);
+    return 0;
+}
+
+}  // namespace forge
+
+using namespace forge;
+
+#define FORGE_DISPATCH_C4(C, ...)                      \
+    switch ((C) / 4) {                                 \
+        case 1: { constexpr int C4 = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int C4 = 2; __VA_ARGS__; } break; \
+        case 4: { constexpr int C4 = 4; __VA_ARGS__; } break; \
+        case 8: { constexpr int C4 = 8; __VA_ARGS__; } break; \
+    }
+
+extern "C" int forge_render_fwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
+                                float* out_feat, float* out_opac, float* out_depth,
+                                int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
+                                float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
+    if (int rc = check_render_args("forge_render_fwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
+    FORGE_REQUIRE(out_feat && out_opac, FORGE_EINVAL, "forge_render_fwd: null output pointer");
+    FORGE_DISPATCH_C4(C, {
+        constexpr int TH = (256 / C4) / 8;
+        dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
+        hipLaunchKernelGGL(render_fwd_kernel<C4>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                           view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+    });
+    FORGE_LAUNCH_CHECK("forge_render_fwd");
+    return 0;
+}
+
+extern "C" int forge_render_bwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
+                                const float* g_feat, const float* g_opac, const float* g_depth,
+                                float* dfeat, float* ddens, float* dcam,
+                                int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
+                                float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
+    if (int rc = check_render_args("forge_render_bwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
+    FORGE_REQUIRE(g_feat && g_opac && dfeat && ddens, FORGE_EINVAL, "forge_render_bwd: null gradient pointer");
+    FORGE_REQUIRE(dcam == nullptr, FORGE_EINVAL, "forge_render_bwd: camera gradients (dcam) are not implemented yet");
+    const size_t lds_bytes = (size_t)2 * S * (256 / (C / 4)) * sizeof(float);
+    FORGE_REQUIRE(lds_bytes <= 160 * 1024, FORGE_ESHAPE, "forge_render_bwd: S=%d needs %zu B of LDS (> 160 KiB)", S, lds_bytes);
+    FORGE_DISPATCH_C4(C, {
+        constexpr int TH = (256 / C4) / 8;
+        dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
+        if (lds_bytes > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)render_bwd_kernel<C4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL(render_bwd_kernel<C4>, grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                           view2vol, g_feat, g_opac, g_depth, dfeat, ddens, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+    });
+    FORGE_LAUNCH_CHECK("forge_render_bwd");
+    return 0;
+}

@@ -1,0 +1,230 @@
+// rotate.hip — a2: fused voxel-grid pose warp for gfx950 (MI355X).
+//
+// Replaces models/rotate.py:127-141 of the reference: there PyTorch materialises a homogeneous
+// grid [n, D*H*W, 4], multiplies it by T^T, divides, and calls F.grid_sample (trilinear, zeros,
+// align_corners=False), then concatenates view 0. Here one launch does all of it: the 3x4 affine
+// lives in SGPRs, every thread owns (output voxel, 4 channels), the 8 taps are 16-byte loads of
+// channels-last rows (C contiguous floats per voxel => a voxel's 128 channels are one 512-B
+// coalesced segment across 32 lanes), view 0 is copied by the same kernel.
+//
+// Roofline: HBM. Algorithmic bytes per warped view = 2 * C*D*H*W*4 (read once + write once);
+// tap re-reads (each source voxel is touched by ~8 outputs) are meant to be served by L1/L2:
+// workgroups are remapped so each XCD's L2 sees one contiguous z-slab of the output.
+#include "common.h"
+
+namespace forge {
+
+struct TriTaps {
+    int x0, y0, z0;          // floor of the pixel coordinate
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+};
+
+// align_corners=False un-normalisation + trilinear weights, in ATen's operation order
+// (grid_sampler_unnormalize: ((coord + 1) * size - 1) / 2 ; weights as (x0+1 - x), (x - x0)).
+__device__ __forceinline__ void taps_ac_false(float sx, float sy, float sz, int W, int H, int D, TriTaps& t) {
+    float px = ((sx + 1.f) * (float)W - 1.f) * 0.5f;
+    float py = ((sy + 1.f) * (float)H - 1.f) * 0.5f;
+    float pz = ((sz + 1.f) * (float)D - 1.f) * 0.5f;
+    // keep the int conversion defined for wild poses; anything beyond [-2, N+1] has no valid tap
+    px = fminf(fmaxf(px, -2.f), (float)W + 1.f);
+    py = fminf(fmaxf(py, -2.f), (float)H + 1.f);
+    pz = fminf(fmaxf(pz, -2.f), (float)D + 1.f);
+    const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+    t.x0 = (int)fx; t.y0 = (int)fy; t.z0 = (int)fz;
+    t.wx1 = px - fx; t.wx0 = (fx + 1.f) - px;
+    t.wy1 = py - fy; t.wy0 = (fy + 1.f) - py;
+    t.wz1 = pz - fz; t.wz0 = (fz + 1.f) - pz;
+}
+
+__global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restrict__ vox, const float* __restrict__ xf,
+                                                         const int* __restrict__ mode, float4* __restrict__ out,
+                                                         int C4, int D, int H, int W, long long per_vol /* D*H*W*C4 */,
+                                                         unsigned blocks_per_vol) {
+    // grid = n * blocks_per_vol; a workgroup never straddles two volumes
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / blocks_per_vol;
+    const long long e = (long long)(bid % blocks_per_vol) * 256 + threadIdx.x;   // element (voxel, c4) in volume
+    if (e >= per_vol) return;
+    const float4* src = vox + (long long)n * per_vol;
+    float4* dst = out + (long long)n * per_vol;
+    if (mode[n] == 0) {            // view 0: pass-through (models/rotate.py:141)
+        dst[e] = src[e];
+        return;
+    }
+    const int c4 = (int)(e % C4);
+    long long v = e / C4;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H);
+    const int z = (int)(v / H);
+    const float* A = xf + n * 12;  // uniform per workgroup -> scalar loads
+    const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
+    const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
+    const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+    const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
+    const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
+    const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
+    TriTaps t;
+    taps_ac_false(sx, sy, sz, W, H, D, t);
+
+    const bool vx0 = (unsigned)t.x0 < (unsigned)W, vx1 = (unsigned)(t.x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)t.y0 < (unsigned)H, vy1 = (unsigned)(t.y0 + 1) < (unsigned)H;
+    const bool vz0 = (unsigned)t.z0 < (unsigned)D, vz1 = (unsigned)(t.z0 + 1) < (unsigned)D;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!((vx0 | vx1) & (vy0 | vy1) & (vz0 | vz1))) {   // fully outside: zeros padding
+        dst[e] = acc;
+        return;
+    }
+    // clamped indices + zeroed weights: every load is in-bounds and unconditional (8 in flight)
+    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
+    const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
+    const int za = min(max(t.z0, 0), D - 1), zb = min(max(t.z0 + 1, 0), D - 1);
+    const float wxa = vx0 ? t.wx0 : 0.f, wxb = vx1 ? t.wx1 : 0.f;
+    const float wya = vy0 ? t.wy0 : 0.f, wyb = vy1 ? t.wy1 : 0.f;
+    const float wza = vz0 ? t.wz0 : 0.f, wzb = vz1 ? t.wz1 : 0.f;
+    const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
+    const float4* p = src + c4;
+    const float4 v000 = p[za * sD + ya * sH + xa * sW];
+    const float4 v001 = p[za * sD + ya * sH + xb * sW];
+    const float4 v010 = p[za * sD + yb * sH + xa * sW];
+    const float4 v011 = p[za * sD + yb * sH + xb * sW];
+    const float4 v100 = p[zb * sD + ya * sH + xa * sW];
+    const float4 v101 = p[zb * sD + ya * sH + xb * sW];
+    const float4 v110 = p[zb * sD + yb * sH + xa * sW];
+    const float4 v111 = p[zb * sD + yb * sH + xb * sW];
+    // ATen accumulation order: tnw, tne, tsw, tse, bnw, bne, bsw, bse (t = z0, n = y0, w = x0)
+    acc = f4_fma(wxa * wya * wza, v000, acc);
+    acc = f4_fma(wxb * wya * wza, v001, acc);
+    acc = f4_fma(wxa * wyb * wza, v010, acc);
+    acc = f4_fma(wxb * wyb * wza, v011, acc);
+    acc = f4_fma(wxa * wya * wzb, v100, acc);
+    acc = f4_fma(wxb * wya * wzb, v101, acc);
+    acc = f4_fma(wxa * wyb * wzb, v110, acc);
+    acc = f4_fma(wxb * wyb * wzb, v111, acc);
+    dst[e] = acc;
+}
+
+// Backward: scatter-add of the upstream gradient through the same 8 taps (hardware fp32 atomics,
+// resolved in L2), optional gradient w.r.t. the 3x4 affine (pose refinement).
+__global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
+                                                         const float* __restrict__ xf, const int* __restrict__ mode,
+                                                         float* __restrict__ dvox, float* __restrict__ dxf,
+                                                         int C4, int D, int H, int W, long long per_vol,
+                                                         unsigned blocks_per_vol) {
+    __shared__ float red[12][4];   // per-wave partials of d xf
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / blocks_per_vol;
+    const long long e = (long long)(bid % blocks_per_vol) * 256 + threadIdx.x;
+    const bool active = e < per_vol;
+    const int md = mode[n];
+    float dA[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) dA[i] = 0.f;
+    if (active && md == 0) {
+        const float4 g = dout[(long long)n * per_vol + e];
+        float* d = dvox + ((long long)n * per_vol + e) * 4;
+        // mode-0 volumes receive exactly one contribution per element: plain accumulate is enough,
+        // but dvox may alias nothing else, so a non-atomic RMW is safe.
+        d[0] += g.x; d[1] += g.y; d[2] += g.z; d[3] += g.w;
+    } else if (active) {
+        const int c4 = (int)(e % C4);
+        long long v = e / C4;
+        const int x = (int)(v % W); v /= W;
+        const int y = (int)(v % H);
+        const int z = (int)(v / H);
+        const float* A = xf + n * 12;
+        const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
+        const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
+        const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+        const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
+        const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
+        const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
+        TriTaps t;
+        taps_ac_false(sx, sy, sz, W, H, D, t);
+        const float4 g = dout[(long long)n * per_vol + e];
+        const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
+        float gsx = 0.f, gsy = 0.f, gsz = 0.f;   // d loss / d pixel coordinate
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const int xi = t.x0 + dx, yi = t.y0 + dy, zi = t.z0 + dz;
+            if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H && (unsigned)zi < (unsigned)D) {
+                const float wx = dx ? t.wx1 : t.wx0, wy = dy ? t.wy1 : t.wy0, wz = dz ? t.wz1 : t.wz0;
+                const float w = wx * wy * wz;
+                const long long off = (long long)n * per_vol + zi * sD + yi * sH + xi * sW + c4;
+                float* d = dvox + off * 4;
+                atomic_add_f32(d + 0, w * g.x);
+                atomic_add_f32(d + 1, w * g.y);
+                atomic_add_f32(d + 2, w * g.z);
+                atomic_add_f32(d + 3, w * g.w);
+                if (dxf) {
+                    const float4 s = vox[off];
+                    const float dot = s.x * g.x + s.y * g.y + s.z * g.z + s.w * g.w;
+                    gsx += (dx ? 1.f : -1.f) * wy * wz * dot;
+                    gsy += (dy ? 1.f : -1.f) * wx * wz * dot;
+                    gsz += (dz ? 1.f : -1.f) * wx * wy * dot;
+                }
+            }
+        }
+        if (dxf) {   // d pixel / d s = N/2 per axis (align_corners=False)
+            gsx *= 0.5f * (float)W; gsy *= 0.5f * (float)H; gsz *= 0.5f * (float)D;
+            dA[0] = gsx * gx; dA[1] = gsx * gy; dA[2] = gsx * gz; dA[3] = gsx;
+            dA[4] = gsy * gx; dA[5] = gsy * gy; dA[6] = gsy * gz; dA[7] = gsy;
+            dA[8] = gsz * gx; dA[9] = gsz * gy; dA[10] = gsz * gz; dA[11] = gsz;
+        }
+    }
+    if (dxf && md != 0) {   // md is workgroup-uniform: whole-block reduction then 12 atomics
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float s = dA[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+            if (lane == 0) red[i][wv] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const float s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+            atomic_add_f32(dxf + n * 12 + threadIdx.x, s);
+        }
+    }
+}
+
+static int check_rotate_args(const void* a, const void* b, const void* c, const void* d, int n, int C, int D, int H, int W) {
+    FORGE_REQUIRE(a && b && c && d, FORGE_EINVAL, "forge_rotate: null pointer argument");
+    FORGE_REQUIRE(n > 0 && C > 0 && D > 1 && H > 1 && W > 1, FORGE_EINVAL,
+                  "forge_rotate: need n>0, C>0 and D,H,W>1 (got n=%d C=%d D=%d H=%d W=%d)", n, C, D, H, W);
+    FORGE_REQUIRE(C % 4 == 0, FORGE_ESHAPE, "forge_rotate: C=%d must be a multiple of 4 (16-byte channel groups)", C);
+    return 0;
+}
+
+}  // namespace forge
+
+using namespace forge;
+
+extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
+                                int n, int C, int D, int H, int W, forge_stream_t stream) {
+    if (int rc = check_rotate_args(vox, xf, mode, out, n, C, D, H, W)) return rc;
+    const int C4 = C / 4;
+    const long long per_vol = (long long)D * H * W * C4;
+    const unsigned bpv = (unsigned)((per_vol + 255) / 256);
+    FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_fwd: grid too large");
+    hipLaunchKernelGGL(rotate_fwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, per_vol, bpv);
+    FORGE_LAUNCH_CHECK("forge_rotate_fwd");
+    return 0;
+}
+
+extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const int* mode,
+                                float* dvox, float* dxf, int n, int C, int D, int H, int W,
+                                forge_stream_t stream) {
+    if (int rc = check_rotate_args(dout, xf, mode, dvox, n, C, D, H, W)) return rc;
+    FORGE_REQUIRE(!dxf || vox, FORGE_EINVAL, "forge_rotate_bwd: dxf requested but vox is NULL");
+    const int C4 = C / 4;
+    const long long per_vol = (long long)D * H * W * C4;
+    const unsigned bpv = (unsigned)((per_vol + 255) / 256);
+    FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_bwd: grid too large");
+    hipLaunchKernelGGL(rotate_bwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, (const float4*)vox, xf, mode, dvox, dxf, C4, D, H, W, per_vol, bpv);
+    FORGE_LAUNCH_CHECK("forge_rotate_bwd");
+    return 0;
+}

@@ -1,0 +1,104 @@
+"""Pose parameterisations <-> SE(3), host-side torch math (tiny; not on the accelerated path).
+
+Same function names / conventions as the reference's utils/geo_utils.py (:6-137 conversions,
+:140-213 mat2quat): quaternions are (w,x,y,z); every *2mat takes [B, rot_dim+3] with the
+translation in the trailing 3 entries and returns [B,4,4]."""
+import torch
+import torch.nn.functional as F
+
+
+def _se3(rot, trans):
+    B = rot.shape[0]
+    top = torch.cat([rot, trans.reshape(B, 3, 1)], dim=2)
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=rot.dtype, device=rot.device).expand(B, 1, 4)
+    return torch.cat([top, bottom], dim=1)
+
+
+def euler2mat(angle):
+    """utils/geo_utils.py:6-47: R = Rz(angle[:,2]) @ Ry(angle[:,0]) @ Rx(angle[:,1]); t = angle[:,3:]"""
+    x, y, z = angle[:, 1], angle[:, 0], angle[:, 2]
+    zero, one = torch.zeros_like(z), torch.ones_like(z)
+    cz, sz, cy, sy, cx, sx = z.cos(), z.sin(), y.cos(), y.sin(), x.cos(), x.sin()
+    Rz = torch.stack([cz, -sz, zero, sz, cz, zero, zero, zero, one], dim=1).reshape(-1, 3, 3)
+    Ry = torch.stack([cy, zero, sy, zero, one, zero, -sy, zero, cy], dim=1).reshape(-1, 3, 3)
+    Rx = torch.stack([one, zero, zero, zero, cx, -sx, zero, sx, cx], dim=1).reshape(-1, 3, 3)
+    return _se3(Rz @ Ry @ Rx, angle[:, 3:])
+
+
+def symmetric_orthogonalization(x):
+    """utils/geo_utils.py:73-85: nearest rotation (SVD, det-corrected) of a 3x3 given as 9 numbers."""
+    m = x.reshape(-1, 3, 3)
+    u, _, v = torch.svd(m)
+    vt = v.transpose(1, 2)
+    det = torch.det(u @ vt).reshape(-1, 1, 1)
+    vt = torch.cat([vt[:, :2, :], vt[:, 2:, :] * det], dim=1)
+    return u @ vt
+
+
+def rot9d2mat(x):
+    return _se3(symmetric_orthogonalization(x[:, :9]), x[:, 9:])
+
+
+def rot6d2mat(x):
+    """Zhou et al. CVPR'19 (utils/geo_utils.py:89-107): Gram-Schmidt on two 3-vectors, columns b1 b2 b3."""
+    b1 = F.normalize(x[:, 0:3])
+    a2 = x[:, 3:6]
+    b2 = F.normalize(a2 - (b1 * a2).sum(dim=1, keepdim=True) * b1)
+    b3 = torch.cross(b1, b2, dim=1)
+    return _se3(torch.stack([b1, b2, b3], dim=-1), x[:, 6:])
+
+
+def quat2mat_transform(quat):
+    """utils/geo_utils.py:122-137"""
+    q = quat / quat.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = q.unbind(dim=1)
+    rows = [w * w + x * x - y * y - z * z, 2 * x * y - 2 * w * z, 2 * w * y + 2 * x * z,
+            2 * w * z + 2 * x * y, w * w - x * x + y * y - z * z, 2 * y * z - 2 * w * x,
+            2 * x * z - 2 * w * y, 2 * w * x + 2 * y * z, w * w - x * x - y * y + z * z]
+    return torch.stack(rows, dim=1).reshape(-1, 3, 3)
+
+
+def quat2mat(x):
+    return _se3(quat2mat_transform(x[:, :4]), x[:, 4:])
+
+
+def mat2quat_transform(R, eps=1e-6):
+    """utils/geo_utils.py:148-213 (the torchgeometry 4-branch algorithm), as a torch.where select.
+    R [B,3,3] -> (w,x,y,z)."""
+    r00, r11, r22 = R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]
+    s = lambda i, j: R[:, i, j]
+    t0 = 1 + r00 - r11 - r22
+    t1 = 1 - r00 + r11 - r22
+    t2 = 1 - r00 - r11 + r22
+    t3 = 1 + r00 + r11 + r22
+    q0 = torch.stack([s(2, 1) - s(1, 2), t0, s(1, 0) + s(0, 1), s(0, 2) + s(2, 0)], dim=-1)
+    q1 = torch.stack([s(0, 2) - s(2, 0), s(1, 0) + s(0, 1), t1, s(2, 1) + s(1, 2)], dim=-1)
+    q2 = torch.stack([s(1, 0) - s(0, 1), s(0, 2) + s(2, 0), s(2, 1) + s(1, 2), t2], dim=-1)
+    q3 = torch.stack([t3, s(2, 1) - s(1, 2), s(0, 2) - s(2, 0), s(1, 0) - s(0, 1)], dim=-1)
+    small_r22 = (r22 < eps)[:, None]
+    pick_a = (r00 > r11)[:, None]
+    pick_b = (r00 < -r11)[:, None]
+    q = torch.where(small_r22, torch.where(pick_a, q0, q1), torch.where(pick_b, q2, q3))
+    t = torch.where(small_r22, torch.where(pick_a, t0[:, None], t1[:, None]),
+                    torch.where(pick_b, t2[:, None], t3[:, None]))
+    return 0.5 * q / torch.sqrt(t)
+
+
+def mat2quat(x):
+    """[B,4,4] -> [B,7] (quaternion, translation) — utils/geo_utils.py:140-145"""
+    return torch.cat([mat2quat_transform(x[:, :3, :3]), x[:, :3, 3]], dim=1)
+
+
+def get_relative_pose(cam_1, cam_2):
+    """utils/geo_utils.py:232-265: T_c1->c2 = inv(P1) @ P2 for rigid poses. cam_1 [4,4] or [t,4,4], cam_2 [t,4,4]"""
+    if cam_1.dim() == 2:
+        cam_1 = cam_1[None].expand(cam_2.shape[0], 4, 4)
+    R1t = cam_1[:, :3, :3].transpose(1, 2)
+    R = R1t @ cam_2[:, :3, :3]
+    t = (R1t @ (cam_2[:, :3, 3] - cam_1[:, :3, 3])[..., None])[..., 0]
+    return _se3(R, t)
+
+
+def canonicalize_poses(canonical_pose, cam_poses_rel):
+    """utils/geo_utils.py:268-287"""
+    return canonical_pose[None] @ cam_poses_rel

@@ -1,0 +1,167 @@
+"""3-D pose estimator (cross-attention over feature volumes) — NOT on the accelerated hot path
+("pose heads stay stock PyTorch-ROCm"). It exists so that
+`FORGE_poseEstimator3D` / `FORGE` keep the reference's attribute surface (`encoder_traj`,
+`.toSE3`, `.pose_dim`, `return_features=`) and state_dict keys (`encoder_traj.*`, 26.65 M
+parameters). Architecture re-expressed from models/pose_estimator_3d.py:9-144 and the
+Block/Attention/Mlp/positional-embedding helpers of models/model_utils.py:59-256."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import geo_utils
+
+_ROT_DIMS = {"euler": 3, "quat": 4, "6D": 6, "9D": 9}
+
+
+def sincos_pos_embed_3d(embed_dim, grid_size, temporal_size):
+    """models/model_utils.py:59-88: interleaved sin/cos per axis, concatenated (t, w, h), cut to embed_dim.
+    Returns [temporal*grid*grid, embed_dim]."""
+    ch = int(math.ceil(embed_dim / 6) * 2)
+    ch += ch % 2
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+
+    def axis(n):
+        a = torch.arange(n).float()[:, None] * inv_freq[None]
+        return torch.stack((a.sin(), a.cos()), dim=-1).flatten(-2)      # [n, ch]
+
+    emb = torch.zeros(temporal_size, grid_size, grid_size, 3 * ch)
+    emb[..., :ch] = axis(temporal_size)[:, None, None]
+    emb[..., ch:2 * ch] = axis(grid_size)[None, :, None]
+    emb[..., 2 * ch:] = axis(grid_size)[None, None, :]
+    return emb.reshape(-1, 3 * ch)[:, :embed_dim]
+
+
+class Attention(nn.Module):
+    """models/model_utils.py:207-229 — unscaled dot-product attention, no parameters."""
+
+    def __init__(self, dim, num_heads=1):
+        super().__init__()
+        self.num_heads = num_heads
+
+    def get_attn(self, query, key):
+        return torch.matmul(query, key.transpose(-2, -1)).softmax(dim=-1)
+
+    def forward(self, query, key, value):
+        B, N, C = query.shape
+        split = lambda x: x.reshape(B, N, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        q, k, v = split(query), split(key), split(value)
+        attn = torch.matmul(q, k.transpose(-2, -1)).softmax(dim=-1)
+        return torch.matmul(attn, v).transpose(1, 2).reshape(B, N, C)
+
+
+class Mlp(nn.Module):
+    """models/model_utils.py:232-255"""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+        for fc in (self.fc1, self.fc2):
+            nn.init.xavier_uniform_(fc.weight)
+            nn.init.normal_(fc.bias, std=1e-6)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Block(nn.Module):
+    """models/model_utils.py:144-204 — 1x1-conv q/k/v encoders on [B,C,N] tensors, shared LayerNorm for
+    q and k, residual attention + MLP."""
+
+    def __init__(self, dim, num_heads=1, mlp_ratio=4.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm, return_attn=False):
+        super().__init__()
+        self.channels = dim
+        self.encode_query = nn.Conv1d(dim, dim, 1)
+        self.encode_key = nn.Conv1d(dim, dim, 1)
+        self.attn = Attention(dim, num_heads=num_heads)
+        self.encode_value = nn.Conv1d(dim, dim, 1)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+        self.norm = norm_layer(dim)
+
+    def _qk(self, query, key, query_embed, key_embed):
+        q = query if query_embed is None else query + query_embed.to(query)
+        k = key if key_embed is None else key + key_embed.to(key)
+        q = self.norm(q.permute(0, 2, 1)).permute(0, 2, 1)
+        k = self.norm(k.permute(0, 2, 1)).permute(0, 2, 1)
+        return self.encode_query(q).permute(0, 2, 1), self.encode_key(k).permute(0, 2, 1)
+
+    def get_attn(self, query, key, query_embed=None, key_embed=None):
+        q, k = self._qk(query, key, query_embed, key_embed)
+        return self.attn.get_attn(query=q, key=k)                       # [B,N,N]
+
+    def forward(self, query, key, query_embed=None, key_embed=None):
+        b = query.shape[0]
+        q, k = self._qk(query, key, query_embed, key_embed)
+        v = self.encode_value(key).permute(0, 2, 1)
+        x = query.permute(0, 2, 1)
+        x = x + self.attn(query=q, key=k, value=v)
+        x = x + self.mlp(self.norm2(x))
+        return x.permute(0, 2, 1).contiguous().view(b, self.channels, -1)
+
+
+class PoseTransformer(nn.Module):
+    """models/pose_estimator_3d.py:116-144"""
+
+    def __init__(self, inp_res=32, dim=64, mlp_ratio=1, coord_dim=64):
+        super().__init__()
+        self.coord_dim = coord_dim
+        self.cross_transformer = Block(dim=dim, mlp_ratio=mlp_ratio, return_attn=True)
+        self.self_transformer = Block(dim=dim, mlp_ratio=mlp_ratio, return_attn=False)
+        # plain attribute (not a buffer) as in the reference: absent from the state_dict
+        self.pos_embed_3d_coord = (sincos_pos_embed_3d(coord_dim, inp_res, inp_res) * 0.1).reshape(1, -1, coord_dim)
+
+    def forward(self, q, k, q_pe=None, k_pe=None):
+        pe = self.pos_embed_3d_coord.to(q)
+        attn = self.cross_transformer.get_attn(query=q, key=k)          # [B,N,N]
+        coord = torch.matmul(attn, pe).permute(0, 2, 1)                  # [B,C,N]
+        return self.self_transformer(query=coord, key=coord)
+
+
+class PoseEstimator3D(nn.Module):
+    """models/pose_estimator_3d.py:9-113"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.rot_representation = config.network.rot_representation
+        assert self.rot_representation in _ROT_DIMS
+        self.rot_dim = _ROT_DIMS[self.rot_representation]
+        self.trans_dim = 3
+        self.pose_dim = self.trans_dim + self.rot_dim
+        lrelu = lambda: nn.LeakyReLU(inplace=True)
+        self.conv3d_1 = nn.Sequential(nn.Conv3d(128, 64, 3, padding=1, stride=2), nn.BatchNorm3d(64), lrelu(),
+                                      nn.Conv3d(64, 64, 3, padding=1))
+        self.coord_dim = 64
+        self.pose_transformer = PoseTransformer(inp_res=16, dim=64, mlp_ratio=2, coord_dim=self.coord_dim)
+        self.conv3d_2 = nn.Sequential(nn.Conv3d(64, 64, 3, padding=1), nn.BatchNorm3d(64), lrelu(),
+                                      nn.Conv3d(64, 128, 3, padding=1, stride=2), nn.BatchNorm3d(128), lrelu())
+        self.conv3d_3 = nn.Sequential(nn.Conv3d(128, 256, 3, padding=1), nn.BatchNorm3d(256), lrelu(),
+                                      nn.Conv3d(256, 512, 3, padding=1, stride=2), nn.BatchNorm3d(512), lrelu())
+        self.pose_head_1 = nn.Sequential(nn.Conv3d(512, 512, 3, padding=1, stride=2), nn.BatchNorm3d(512), lrelu(),
+                                         nn.Conv3d(512, 1024, 3, padding=1, stride=2))
+        self.pose_head_2 = nn.Sequential(nn.LayerNorm(1024), lrelu())
+        self.out = nn.Sequential(nn.Linear(1024, 256), nn.BatchNorm1d(256), nn.LeakyReLU(),
+                                 nn.Linear(256, self.pose_dim + 1))
+
+    def forward(self, features, return_features=False):
+        """features [b,t,128,D,H,W] -> (pose [b(t-1),pose_dim], conf [b(t-1),1]) or the 1024-d features"""
+        b, t, C1, D1, H1, W1 = features.shape
+        x = self.conv3d_1(features.reshape(b * t, C1, D1, H1, W1))
+        _, C, D, H, W = x.shape
+        x = x.reshape(b, t, C, D * H * W)
+        ref = x[:, 0:1].repeat(1, t - 1, 1, 1).reshape(b * (t - 1), C, -1)
+        cur = x[:, 1:].reshape(b * (t - 1), C, -1)
+        x = self.pose_transformer(q=ref, k=cur).reshape(b * (t - 1), self.coord_dim, D, H, W)
+        x = self.conv3d_3(self.conv3d_2(x))
+        x = self.pose_head_2(self.pose_head_1(x).squeeze())
+        if return_features:
+            return x
+        x = self.out(x)
+        return tuple(x.split([self.pose_dim, 1], dim=-1))
+
+    def toSE3(self, x):
+        return {"euler": geo_utils.euler2mat, "quat": geo_utils.quat2mat,
+                "6D": geo_utils.rot6d2mat, "9D": geo_utils.rot9d2mat}[self.rot_representation](x)

@@ -1,0 +1,64 @@
+"""a2 — voxel-grid pose warp.
+
+Mirror of the reference's models/rotate.py::Rotate_world (:9-156): same constructor / forward
+signature (`forward(voxels, camPoses_cv2, grid_size=32)`) and the same — unused but checkpointed —
+parameters `conv3d_1..4` (:37-45). The warp itself (affine grid + trilinear grid_sample with
+zeros padding and align_corners=False, then cat with view 0; :125-141) is ONE HIP launch
+(forge_rotate_fwd); the 4x4 algebra T = P_0 P_i^-1 (:64-89) stays in torch so that gradients
+reach predicted poses through autograd.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_SUPPORTED = (16, 32, 48, 64, 128)   # grids the reference pre-computes (models/rotate.py:18-35)
+
+
+class Rotate_world(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.padding_mode = config.network.padding_mode      # read but ignored, as in the reference (:138)
+        self.grid_size = 32
+        self.vol_size = config.render.volume_size
+        self.single_voxel_size = self.vol_size / self.grid_size
+        self.grid_coord_max = self.half_extent(32)           # "should be 0.4844" (:23)
+        self.conv3d_1 = nn.Conv3d(16, 16, 3, padding=1)
+        self.conv3d_2 = nn.Conv3d(16, 16, 3, padding=1)
+        self.conv3d_3 = nn.Conv3d(128, 128, 3, padding=1)
+        self.conv3d_4 = nn.Conv3d(128, 128, 3, padding=1)
+        for m in (self.conv3d_1, self.conv3d_2, self.conv3d_3, self.conv3d_4):   # train_utils.normal_init
+            nn.init.normal_(m.weight, 0.0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def half_extent(self, grid_size):
+        """pytorch3d Volumes.get_coord_grid(world_coordinates=True).max() = 0.5 (D-1) vol/D (:22-35)"""
+        return 0.5 * (grid_size - 1) * (self.vol_size / grid_size)
+
+    def get_transformation(self, camPoses_cv2):
+        """models/rotate.py:64-89: T = P_0 @ inverse(P_i), i = 1..t-1 -> [B*(t-1),4,4]"""
+        B, t = camPoses_cv2.shape[:2]
+        pose_0 = camPoses_cv2[:, 0:1].repeat(1, t - 1, 1, 1).reshape(B * (t - 1), 4, 4)
+        pose_1 = camPoses_cv2[:, 1:].reshape(B * (t - 1), 4, 4)
+        return pose_0 @ torch.inverse(pose_1)
+
+    def forward(self, voxels, camPoses_cv2, grid_size=32):
+        """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged)."""
+        B, t, C, D, H, W = voxels.shape
+        if grid_size not in _SUPPORTED:
+            raise ValueError("Rotate_world: grid_size %r not in %s (models/rotate.py:109-123)" % (grid_size, _SUPPORTED))
+        if not (D == H == W == grid_size):
+            raise ValueError("Rotate_world: voxels %s do not match grid_size=%d" % ((D, H, W), grid_size))
+        device = voxels.device
+        e = self.half_extent(grid_size)
+        if t > 1:
+            T = self.get_transformation(camPoses_cv2.to(device=device, dtype=torch.float32))   # [B(t-1),4,4]
+            xf_w = torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(B, t - 1, 12)
+            ident = torch.zeros(B, 1, 12, dtype=torch.float32, device=device)
+            xf = torch.cat([ident, xf_w], dim=1).reshape(B * t, 12)
+        else:
+            xf = torch.zeros(B, 12, dtype=torch.float32, device=device)
+        mode = torch.ones(B, t, dtype=torch.int32, device=device)
+        mode[:, 0] = 0
+        out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode.reshape(B * t))
+        return out.reshape(B, t, C, D, H, W)

@@ -1,0 +1,115 @@
+/*
+ * forge_hip.h — C-ABI of libforge_hip.so, the MI355X (gfx950) kernels behind the FORGE
+ * reconstruction hot path (UT-Austin-RPL/FORGE: models/rotate.py, models/volume_render.py,
+ * models/fusion.py, models/encoder.py).
+ *
+ * The reference is pure Python/PyTorch (no FFI of its own); the drop-in boundary for callers is
+ * the Python nn.Module surface in forge_amd/ (same class/method/state_dict names as
+ * models/model.py etc.).  This header is the boundary ONE level lower: what forge_amd's host
+ * code (or any other host language) binds.  Each entry point cites the
+ * reference call site it replaces.
+ *
+ * Conventions
+ *   - plain C types only: device pointers (const float*), ints, floats, an opaque stream handle
+ *     (hipStream_t passed as void*; NULL = the default stream).  No torch types.
+ *   - every function returns 0 on success, a positive hipError_t when a HIP call failed, or a
+ *     negative FORGE_E* code for a rejected argument; forge_last_error() gives the message
+ *     (thread-local).
+ *   - functions are re-entrant, allocate nothing and keep no global state: all buffers
+ *     (including workspaces) are owned by the caller.
+ *   - launches are asynchronous on `stream`; nothing synchronises.
+ *   - volumes are CHANNELS-LAST fp32: vol[n][D][H][W][C] (torch: an NCDHW tensor in
+ *     torch.channels_last_3d memory format); grid axes (x,y,z) <-> tensor axes (W,H,D)
+ *     exactly as in F.grid_sample / pytorch3d Volumes.
+ */
+#ifndef FORGE_HIP_H
+#define FORGE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* forge_stream_t; /* hipStream_t */
+
+#define FORGE_EINVAL (-1)   /* bad argument value (null pointer, non-positive dim, ...) */
+#define FORGE_ESHAPE (-2)   /* unsupported shape (e.g. C not a multiple of 4)            */
+
+/* Library version: major*10000 + minor*100 + patch. */
+int forge_version(void);
+/* Message for the last non-zero return on this thread ("" if none). */
+const char* forge_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2  voxel-grid pose warp — replaces models/rotate.py:127-141 (affine grid + F.grid_sample
+ * trilinear, zeros padding, align_corners=FALSE, then cat with view 0).
+ *
+ *   vox  [n][D][H][W][C]   input volumes (all views of all scenes, n = B*t)
+ *   xf   [n][12]           row-major 3x4 affine in NORMALISED grid coords: for the output voxel
+ *                          with g = (gx,gy,gz), g_a = 2 i_a/(N_a-1) - 1, the sample coordinate is
+ *                          s = A g + b  (A = R_T, b = t_T / grid_coord_max; rotate.py:132-135)
+ *   mode [n]               0: copy the volume unchanged (view 0, rotate.py:141); 1: warp
+ *   out  [n][D][H][W][C]
+ * pixel coord p_a = ((s_a+1) N_a - 1)/2 (align_corners=False), 8 taps each zeroed when out of range.
+ * Requires C % 4 == 0.
+ */
+int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
+                     int n, int C, int D, int H, int W, forge_stream_t stream);
+
+/* Backward of forge_rotate_fwd w.r.t. the volumes (and optionally the affine).
+ *   dout [n][D][H][W][C]   upstream gradient
+ *   dvox [n][D][H][W][C]   MUST be zero-filled by the caller; receives scatter-added gradients
+ *                          (mode 0 volumes: plain copy of dout)
+ *   dxf  [n][12]           nullable; MUST be zero-filled; d loss / d xf (pose refinement,
+ *                          kubric_eval.py:469-503). Needs vox (nullable when dxf is NULL).
+ */
+int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const int* mode,
+                     float* dvox, float* dxf, int n, int C, int D, int H, int W,
+                     forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6  fused ray sampler + volume sampler + emission-absorption ray-marcher — replaces
+ * models/volume_render.py:53-63 (cameras_from_opencv_projection, NDCGridRaysampler,
+ * VolumeRenderer/VolumeSampler with align_corners=TRUE trilinear zero-pad sampling,
+ * EmissionAbsorptionRaymarcher incl. the README.md:26-33 depth patch).
+ *
+ *   feat     [nvol][D][H][W][C]   render features, channels-last, C % 4 == 0, C <= 32
+ *   dens     [nvol][D][H][W]      densities (>= 0, NOT clamped <= 1: models/model.py:140-141)
+ *   cam      [V][16]              per view: R[9] row-major (OpenCV world->cam), T[3], fx, fy, cx, cy
+ *                                 of the HALF-resolution intrinsics (volume_render.py:50-51)
+ *   view2vol [V]                  volume index rendered by each view (replaces the V-fold
+ *                                 `repeat` of the volumes, models/model.py:138-139)
+ *   out_feat [V][C][Hr][Wr]       sum_s w_s f_s           (NCHW, ready for conv_rgb)
+ *   out_opac [V][Hr][Wr]          1 - prod_s (1 - d_s)
+ *   out_depth[V][Hr][Wr]          sum_s w_s z_s, nullable (render_depth=False)
+ * Ray (h,w): d_cam = ((w+.5-cx)/fx, (h+.5-cy)/fy, 1); p_s = -R^T T + R^T d_cam z_s,
+ * z_s = zmin + s (zmax-zmin)/(S-1); local = p / (hx,hy,hz); pix = (local+1)/2 (N-1).
+ */
+int forge_render_fwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
+                     float* out_feat, float* out_opac, float* out_depth,
+                     int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
+                     float zmin, float zmax, float hx, float hy, float hz,
+                     forge_stream_t stream);
+
+/* Backward of forge_render_fwd w.r.t. volumes (and optionally cameras).
+ *   g_feat [V][C][Hr][Wr], g_opac [V][Hr][Wr], g_depth [V][Hr][Wr] (nullable)
+ *   dfeat  [nvol][D][H][W][C], ddens [nvol][D][H][W]   MUST be zero-filled; scatter-added
+ *   dcam   [V][16] nullable, MUST be zero-filled: d loss / d (R, T, fx, fy, cx, cy)
+ */
+int forge_render_bwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
+                     const float* g_feat, const float* g_opac, const float* g_depth,
+                     float* dfeat, float* ddens, float* dcam,
+                     int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
+                     float zmin, float zmax, float hx, float hy, float hz,
+                     forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.
+ *   src [n][C][P] -> dst [n][P][C]   (P = D*H*W)   and back.
+ */
+int forge_ncdhw_to_ndhwc(const float* src, float* dst, int n, int C, long long P, forge_stream_t stream);
+int forge_ndhwc_to_ncdhw(const float* src, float* dst, int n, int C, long long P, forge_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FORGE_HIP_H */

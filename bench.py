@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py — rendered views/sec of the FORGE reconstruction hot path on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path a1..a7 over one batch of B synthetic scenes
+per GPU: 5 input views 256^2 -> ResNet lift -> 32^3x128 feature volumes -> HIP pose warp -> ConvGRU
+fusion -> heads -> 64^3 (16+1)-channel volume -> HIP ray-march of 5 views x 128^2 rays x 64 samples ->
+conv_rgb -> 5 RGB 256^2 views + masks, through forge_amd.model.FORGE.forward (GT poses, eval-mode BN,
+fp32). Inputs are resident in HBM before the timed region. Weak scaling: every rank processes its own
+B scenes, no data-path collective (scenes are independent); rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant stage/kernel of the step against its bound (HIP-event timings taken inside
+                this process on the launch stream)
+  kernels       per hand-written HIP kernel: algorithmic bytes / avg launch duration vs HBM peak
+  stages_ms     HIP-event split of one step
+  cpu_baseline  the CPU oracle (reference semantics, torch-CPU) timed on this box's host cores on a
+                bounded sample of the same workload (N=1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from forge_amd import _lib, dist as fdist, synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+FP32_MFMA_PEAK_TF = 157.3    # v_mfma_f32_32x32x2_f32 dense peak
+T_IN, V_OUT = 5, 5
+# algorithmic work per scene
+GF_ENCODER = 64.3 * T_IN
+GF_FUSE = 927.7
+GF_HEADS = 45.3
+GF_CONVRGB = 0.80 * V_OUT
+
+
+def stage_hooks(model):
+    """HIP events around the hot-path stages, recorded on the current (launch) stream."""
+    rec = {}
+
+    def add(name, mod):
+        def pre(m, a, kw=None):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec.setdefault(name, []).append([e, None])
+
+        def post(m, a, o):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec[name][-1][1] = e
+        return [mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)]
+
+    hs = []
+    e3 = model.encoder_3d
+    for name, mod in (("encoder_resnet", e3.feature_extraction), ("encoder_conv1", e3.conv1), ("rotate", model.rotate),
+                      ("fuse_h0", e3.fusion_feature.fusion_conv), ("fuse_gru", e3.fusion_feature),
+                      ("density_head", e3.density_head), ("features_head", e3.features_head),
+                      ("render_total", model.render), ("conv_rgb", model.render.conv_rgb)):
+        hs += add(name, mod)
+    return rec, hs
+
+
+def time_kernel(fn, iters=20, warm=3):
+    """Average duration (ms) of one launch of `fn`, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def kernel_rooflines(dev, B):
+    """Hand-written kernels at the bench shapes: ALGORITHMIC bytes per launch / avg duration."""
+    from forge_amd import ops
+    lib = _lib.lib()
+    st = _lib.current_stream()
+    out = {}
+    # rotate: n = B*5 volumes of [32^3, 128]; 4 warped (read + write) + 1 copied per scene
+    C, D, n = 128, 32, B * T_IN
+    vox = torch.randn(n, D, D, D, C, device=dev)
+    dst = torch.empty_like(vox)
+    xf = torch.tensor([1, 0, 0, 0.02, 0, 0.8, -0.6, 0, 0, 0.6, 0.8, 0.01], device=dev).repeat(n, 1).contiguous()
+    mode = torch.ones(n, dtype=torch.int32, device=dev)
+    mode[::T_IN] = 0
+    ms = time_kernel(lambda: _lib.check(lib.forge_rotate_fwd(_lib.ptr(vox), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(dst),
+                                                               n, C, D, D, D, st), "rotate"))
+    byts = n * C * D ** 3 * 4 * 2
+    out["rotate_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+    # render: B volumes 64^3 x (16+1), V = 5 views each, 128^2 rays, 64 samples
+    Dr, Cr, V = 64, 16, B * V_OUT
+    feat, dens = syn.blob_volumes(B, Dr, Cr, seed=0)
+    feat = feat.to(dev).permute(0, 2, 3, 4, 1).contiguous()
+    dens = dens.to(dev).contiguous()
+    _, extr, _ = syn.orbit_cameras(V_OUT, 1.5, 10.0)
+    K = syn.intrinsics(256) / 2.0
+    cam = torch.cat([extr[:, :3, :3].reshape(V_OUT, 9), extr[:, :3, 3], K[0, 0].expand(V_OUT, 1), K[1, 1].expand(V_OUT, 1),
+                     K[0, 2].expand(V_OUT, 1), K[1, 2].expand(V_OUT, 1)], dim=1).repeat(B, 1).contiguous().to(dev)
+    v2v = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(V_OUT).contiguous()
+    of = torch.empty(V, Cr, 128, 128, device=dev)
+    oo = torch.empty(V, 128, 128, device=dev)
+    h = 0.5 * (Dr - 1) / Dr
+    ms = time_kernel(lambda: _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v),
+                                                               _lib.ptr(of), _lib.ptr(oo), None, V, B, Cr, Dr, Dr, Dr, 128, 128, 64,
+                                                               0.5, 2.0, h, h, h, st), "render"))
+    byts = B * 17 * Dr ** 3 * 4 + V * 17 * 128 * 128 * 4
+    taps = V * 128 * 128 * 64 * 17 * 8
+    out["render_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS,
+                                "gather_Gtaps_per_s": taps / ms / 1e6, "views_per_s_kernel_only": V / ms * 1e3}
+    return out
+
+
+def cpu_baseline(sample, weights, cfg, budget_s=25.0):
+    """The oracle (reference semantics, torch-CPU fp32) on this box's host cores: 1 warm-up + as many
+    timed 5-in/5-out hot-path forwards of ONE scene as fit the budget (>= 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import forge_oracle as fo
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    one = {k: v[:1].cpu() for k, v in sample.items()}
+
+    def run():
+        with torch.no_grad():
+            return fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN],
+                                       one["cam_extrinsics_cv2_canonicalized"][:, :T_IN], one["K_cv2"][:, :T_IN],
+                                       weights, cfg, order_by_distance=True)
+    t0 = time.time()
+    ref = run()
+    warm = time.time() - t0
+    n = max(1, min(5, int((budget_s - warm) / max(warm, 1e-3))))
+    t0 = time.time()
+    for _ in range(n):
+        run()
+    dt = (time.time() - t0) / n
+    return {"value": V_OUT / dt, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": "%d timed forward(s) of 1 scene (5x256^2 in, 32^3/64^3 grids, 5x128^2x64 rays out), torch-CPU fp32, "
+                      "%d threads, %.2f s each" % (n, torch.get_num_threads(), dt)}, ref
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step (BASELINE config 2: 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, local_rank, world = fdist.init()
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    _lib.lib()
+    torch.backends.cudnn.benchmark = True      # MIOpen find mode for the (not yet hand-written) dense convs
+
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    weights = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(weights)
+    model = model.to(dev).eval()
+    B = args.scenes
+    sample_cpu = syn.make_sample(B, T_IN, 256, 1.5, seed=1000 + rank)
+    sample = {k: v.to(dev) for k, v in sample_cpu.items()}      # inputs resident in HBM
+    dataset = syn.SyntheticDataset(1.5)
+
+    def step():
+        with torch.no_grad():
+            return model(sample, dataset, dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    fdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    fdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
+    views = world * B * V_OUT * args.steps
+
+    # ---- per-stage HIP-event split of one more step (outside the timed region)
+    rec, hooks = stage_hooks(model)
+    for _ in range(3):
+        rec.clear()
+        step()
+    torch.cuda.synchronize()
+    stages = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in rec.items()}
+    for h in hooks:
+        h.remove()
+    stages["fuse_gru"] = stages["fuse_gru"]                       # 5 GRU steps + fusion_norm
+    stages["render_march"] = stages.pop("render_total") - stages["conv_rgb"]
+
+    result = None
+    if rank == 0:
+        kern = kernel_rooflines(dev, B)
+        fuse_ms = stages["fuse_gru"] + stages["fuse_h0"]
+        fuse_tf = B * GF_FUSE / fuse_ms            # GFLOP / ms = TFLOP/s
+        roofline = {"kernel": "ConvGRU fusion stage (3x3x3 conv, K=6912; MIOpen via PyTorch-ROCm until the HIP MFMA kernel lands)",
+                    "bound": "mfma", "achieved": fuse_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": fuse_tf / FP32_MFMA_PEAK_TF, "traffic": None, "share_of_step": fuse_ms / (dt / args.steps * 1e3)}
+        result = {
+            "metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": views / dt, "unit": "views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
+                                   "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate + "
+                                   "HIP ray-march, dense convs via PyTorch-ROCm/MIOpen, eval BN, random-init seeded weights" % B,
+                       "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
+            "roofline": roofline, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "gflop_per_step_algorithmic": B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(sample_cpu, weights, cfg)
+            result["cpu_baseline"] = cb
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import forge_oracle as fo
+            result["psnr_vs_oracle_db"] = fo.psnr(out[0][:V_OUT].cpu(), ref[0])
+            result["max_abs_err_vs_oracle"] = (out[0][:V_OUT].cpu() - ref[0]).abs().max().item()
+            result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
+        print(json.dumps(result), flush=True)
+    fdist.barrier()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,281 @@
+"""GPU (-m gpu): the HIP path, called through the C-ABI (forge_amd/_lib.py -> libforge_hip.so),
+against the CPU oracle and the committed golden vectors from the reference.
+
+Stated fp32 tolerances (the op is trilinear interpolation / compositing of O(1) values):
+  rotate fwd            max-abs 2e-5          render fwd   max-abs 2e-5 (features/opacity/depth)
+  backward (vs autograd through the oracle)   max-abs 1e-4 relative to the gradient scale
+  full forward vs reference golden            PSNR > 60 dB and max-abs 2e-3 (cuts through ~70 conv layers)
+"""
+import numpy as np
+import pytest
+import torch
+
+import forge_oracle as fo
+from forge_amd import ops, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from forge_amd import _lib
+    _lib.lib()          # fail loudly if libforge_hip.so is missing — no fallback
+    return torch.device("cuda:0")
+
+
+def _cam_pack(R, Tt, Kh):
+    V = R.shape[0]
+    return torch.cat([R.reshape(V, 9), Tt.reshape(V, 3), Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1)
+
+
+# ------------------------------------------------------------------ rotate
+def test_rotate_golden_d16(dev, golden):
+    from forge_amd.rotate import Rotate_world
+    g = golden("rotate_d16")
+    rot = Rotate_world(syn.kubric_config()).to(dev)
+    out = rot(T(g["voxels"]).to(dev), T(g["poses"]).to(dev), grid_size=16).cpu()
+    assert torch.equal(out[:, 0], T(g["voxels"])[:, 0])
+    assert (out - T(g["out"])).abs().max().item() < 2e-5
+
+
+def test_rotate_identity_quirk_d32(dev, golden):
+    from forge_amd.rotate import Rotate_world
+    g = golden("rotate_identity_d32")
+    rot = Rotate_world(syn.kubric_config()).to(dev)
+    vox = T(g["voxels"]).repeat(1, 1, 4, 1, 1, 1)          # C=4 (kernel needs C % 4 == 0)
+    out = rot(vox.to(dev), T(g["poses"]).to(dev), grid_size=32).cpu()
+    assert (out[:, :, :1] - T(g["out"])).abs().max().item() < 2e-5
+    assert (out[:, 1] - vox[:, 1]).abs().max().item() > 0.3      # identity pose is NOT an identity resample
+
+
+@pytest.mark.parametrize("D,C,B,t", [(16, 8, 2, 3), (32, 128, 1, 5), (48, 4, 1, 2), (64, 16, 1, 2)])
+def test_rotate_vs_oracle(dev, D, C, B, t):
+    from forge_amd.rotate import Rotate_world
+    g = torch.Generator().manual_seed(D + C)
+    jit = (torch.rand(10, 2, generator=g) - 0.5) * 0.4
+    poses, _, _ = syn.orbit_cameras(10, 1.5, 20.0, jit)
+    P = torch.stack([poses[torch.randperm(10, generator=g)[:t]] for _ in range(B)])
+    vox = torch.randn(B, t, C, D, D, D, generator=g)
+    ref = fo.rotate_world(vox, P, 1.0)
+    out = Rotate_world(syn.kubric_config()).to(dev)(vox.to(dev), P.to(dev), grid_size=D).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_rotate_layout_agnostic_and_far_pose(dev):
+    """plain-contiguous NCDHW input and channels-last input give the same answer; a pose that throws the
+    volume completely out of the grid gives exact zeros (zeros padding)."""
+    from forge_amd.rotate import Rotate_world
+    rot = Rotate_world(syn.kubric_config()).to(dev)
+    vox = torch.randn(1, 2, 8, 16, 16, 16, device=dev)
+    P = torch.eye(4, device=dev)[None, None].repeat(1, 2, 1, 1)
+    P[0, 1, :3, 3] = torch.tensor([5.0, 0, 0])
+    a = rot(vox, P, grid_size=16)
+    vox_cl = vox.reshape(2, 8, 16, 16, 16).contiguous(memory_format=torch.channels_last_3d).reshape(1, 2, 8, 16, 16, 16)
+    b = rot(vox_cl, P, grid_size=16)
+    assert torch.equal(a, b)
+    assert a[:, 1].abs().max().item() == 0.0
+    with pytest.raises(ValueError):
+        rot(torch.zeros(1, 2, 4, 20, 20, 20, device=dev), P, grid_size=20)
+
+
+def test_rotate_backward_vs_oracle_autograd(dev):
+    from forge_amd.rotate import Rotate_world
+    g = torch.Generator().manual_seed(3)
+    poses, _, _ = syn.orbit_cameras(5, 1.5, 15.0)
+    P = poses[None, :3].contiguous()
+    vox = torch.randn(1, 3, 8, 16, 16, 16, generator=g)
+    wgt = torch.randn(1, 3, 8, 16, 16, 16, generator=g)
+    v_ref = vox.clone().requires_grad_(True)
+    P_ref = P.clone().requires_grad_(True)
+    (fo.rotate_world(v_ref, P_ref, 1.0) * wgt).sum().backward()
+    v = vox.to(dev).requires_grad_(True)
+    Pd = P.to(dev).requires_grad_(True)
+    (Rotate_world(syn.kubric_config()).to(dev)(v, Pd, grid_size=16) * wgt.to(dev)).sum().backward()
+    scale = v_ref.grad.abs().max().item()
+    assert (v.grad.cpu() - v_ref.grad).abs().max().item() < 1e-4 * scale
+    pscale = P_ref.grad.abs().max().item()
+    assert (Pd.grad.cpu() - P_ref.grad).abs().max().item() < 2e-3 * pscale      # pose gradient (row f2)
+
+
+# ------------------------------------------------------------------ render
+def _render_hip(dev, feat, dens, R, Tt, Kh, Hr, Wr, S, zmin, zmax, vol, depth=True, view2vol=None):
+    nvol, C, D, H, W = feat.shape
+    V = R.shape[0]
+    v2v = torch.arange(V, dtype=torch.int32) if view2vol is None else view2vol
+    h = [0.5 * (n - 1) * vol / D for n in (W, H, D)]
+    outs = ops.render_rays(feat.to(dev), dens.to(dev), _cam_pack(R, Tt, Kh).to(dev), v2v.to(dev), Hr, Wr, S, zmin, zmax, h, depth)
+    return torch.cat(outs, dim=1).permute(0, 2, 3, 1).cpu()          # [V,Hr,Wr,C+1(+1)] like pytorch3d
+
+
+def test_render_golden_raw(dev, golden):
+    g = golden("render_d16")
+    feat, dens, R, Tt, K = (T(g[k]) for k in ("feat", "dens", "R", "T", "K"))
+    S, img = int(g["n_pts"]), int(g["img_size"])
+    got = _render_hip(dev, feat, dens, R, Tt, fo.halve_intrinsics(K), img // 2, img // 2, S,
+                      float(g["min_depth"]), float(g["max_depth"]), float(g["vol_size"]))
+    assert (got - T(g["raw"])).abs().max().item() < 2e-5
+
+
+def test_volrender_module_golden(dev, golden):
+    """VolRender.forward incl. conv_rgb / upsampling / origin projection vs the reference module's outputs."""
+    from forge_amd.volume_render import VolRender
+    g = golden("render_d16")
+    cfg = syn.kubric_config(img_size=int(g["img_size"]), n_pts_per_ray=int(g["n_pts"]))
+    vr = VolRender(cfg)
+    vr.load_state_dict({k[len("w.render."):]: T(g[k]) for k in g.files if k.startswith("w.render.")})
+    vr = vr.to(dev).eval()
+    K = T(g["K"]).to(dev)
+    K_before = K.clone()
+    cam = {"R": T(g["R"]).to(dev), "T": T(g["T"]).to(dev), "K": K}
+    with torch.no_grad():
+        imgs, sil, depth, oproj = vr(cam, T(g["feat"]).to(dev), T(g["dens"]).to(dev), render_depth=True, return_origin_proj=True)
+    assert torch.equal(K, K_before)                                 # no in-place halving of the caller's K
+    assert (imgs.cpu() - T(g["imgs"])).abs().max().item() < 1e-4
+    assert (sil.cpu() - T(g["sil"])).abs().max().item() < 2e-5
+    assert (depth.cpu() - T(g["depth"])).abs().max().item() < 2e-5
+    assert (oproj.cpu() - T(g["origin_proj"])).abs().max().item() < 1e-3
+    with torch.no_grad():
+        two = vr(cam, T(g["feat"]).to(dev), T(g["dens"]).to(dev))
+    assert len(two) == 2 and torch.equal(two[0], imgs)
+
+
+@pytest.mark.parametrize("D,C,img,S", [(32, 16, 128, 64), (64, 16, 256, 64), (16, 4, 64, 33), (24, 32, 40, 17), (16, 8, 64, 200)])
+def test_render_vs_oracle(dev, D, C, img, S):
+    feat, dens = syn.blob_volumes(2, D, C, seed=D)
+    _, extr, _ = syn.orbit_cameras(10, 1.5, 15.0)
+    E = extr[[0, 3, 6]].clone()
+    E[2, 1, 3] -= 0.3
+    Kh = fo.halve_intrinsics(syn.intrinsics(img)[None].repeat(3, 1, 1))
+    v2v = torch.tensor([0, 1, 1], dtype=torch.int32)
+    ref = fo.render_rays(feat[v2v.long()], dens[v2v.long()], E[:, :3, :3], E[:, :3, 3], Kh, img // 2, img // 2, S, 0.5, 2.0, 1.0, True)
+    got = _render_hip(dev, feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, img // 2, img // 2, S, 0.5, 2.0, 1.0, view2vol=v2v)
+    assert (got - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_render_edge_cases(dev):
+    """all rays miss the volume -> exact zeros; density exactly 1 somewhere -> T hits 0 exactly (early-out
+    path) and still matches; densities > 1 (negative transmittance) match; non-square render target."""
+    D, C = 16, 16
+    feat = torch.randn(1, C, D, D, D)
+    dens = torch.zeros(1, 1, D, D, D)
+    dens[0, 0, 6:10, 6:10, 6:10] = 1.0          # interior voxels with d == 1 exactly
+    dens[0, 0, 2:4] = 1.7
+    E = syn.SyntheticDataset(1.5).get_canonical_extrinsics_cv2()[None].clone()
+    Kh = fo.halve_intrinsics(syn.intrinsics(64)[None])
+    ref = fo.render_rays(feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, 32, 32, 64, 0.5, 2.0, 1.0, True)
+    got = _render_hip(dev, feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, 32, 32, 64, 0.5, 2.0, 1.0)
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    far = E.clone()
+    far[0, 0, 3] = 10.0
+    got = _render_hip(dev, feat, dens, far[:, :3, :3], far[:, :3, 3], Kh, 32, 32, 64, 0.5, 2.0, 1.0)
+    assert got.abs().max().item() == 0.0
+    # non-square, odd sizes
+    ref = fo.render_rays(feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, 19, 37, 31, 0.5, 2.0, 1.0, False)
+    got = _render_hip(dev, feat, dens, E[:, :3, :3], E[:, :3, 3], Kh, 19, 37, 31, 0.5, 2.0, 1.0, depth=False)
+    assert got.shape == ref.shape and (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_render_backward_vs_oracle_autograd(dev):
+    D, C, img, S = 16, 16, 48, 40
+    feat, dens = syn.blob_volumes(2, D, C, seed=11)
+    dens[0, 0, 7:9, 7:9, 7:9] = 1.0              # exact-zero transmittance inside the march
+    _, extr, _ = syn.orbit_cameras(10, 1.5, 15.0)
+    E = extr[[1, 4, 8]]
+    Kh = fo.halve_intrinsics(syn.intrinsics(img)[None].repeat(3, 1, 1))
+    v2v = torch.tensor([0, 1, 0], dtype=torch.int32)
+    Hr = img // 2
+    g = torch.Generator().manual_seed(5)
+    wgt = torch.randn(3, Hr, Hr, C + 2, generator=g)
+    f_ref = feat.clone().requires_grad_(True)
+    d_ref = dens.clone().requires_grad_(True)
+    ref = fo.render_rays(f_ref[v2v.long()], d_ref[v2v.long()], E[:, :3, :3], E[:, :3, 3], Kh, Hr, Hr, S, 0.5, 2.0, 1.0, True)
+    (ref * wgt).sum().backward()
+    f = feat.to(dev).requires_grad_(True)
+    d = dens.to(dev).requires_grad_(True)
+    h = [fo.grid_half_extent(D, 1.0)] * 3
+    outs = ops.render_rays(f, d, _cam_pack(E[:, :3, :3], E[:, :3, 3], Kh).to(dev), v2v.to(dev), Hr, Hr, S, 0.5, 2.0, h, True)
+    got = torch.cat(outs, dim=1).permute(0, 2, 3, 1)
+    (got * wgt.to(dev)).sum().backward()
+    assert (got.detach().cpu() - ref.detach()).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    fs, ds = f_ref.grad.abs().max().item(), d_ref.grad.abs().max().item()
+    assert (f.grad.cpu() - f_ref.grad).abs().max().item() < 1e-4 * fs
+    assert (d.grad.cpu() - d_ref.grad).abs().max().item() < 1e-4 * ds
+
+
+def test_layout_helpers(dev):
+    from forge_amd import _lib
+    x = torch.randn(2, 12, 5, 6, 7, device=dev)
+    y = torch.empty(2, 5, 6, 7, 12, device=dev)
+    _lib.check(_lib.lib().forge_ncdhw_to_ndhwc(_lib.ptr(x), _lib.ptr(y), 2, 12, 5 * 6 * 7, _lib.current_stream()), "to_ndhwc")
+    assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous())
+    z = torch.empty_like(x)
+    _lib.check(_lib.lib().forge_ndhwc_to_ncdhw(_lib.ptr(y), _lib.ptr(z), 2, 12, 5 * 6 * 7, _lib.current_stream()), "to_ncdhw")
+    assert torch.equal(z, x)
+
+
+# ------------------------------------------------------------------ whole model
+def test_forward_pose3d_golden_and_oracle(dev, golden):
+    """FORGE_poseEstimator3D gt-pose forward at reference shapes (5x256^2 in, 10 views out, 32^3/64^3 grids)
+    vs the reference model's own output (golden, subsampled)."""
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    g = golden("forward_pose3d")
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=int(g["sample_seed"]))
+    K_before = sample["K_cv2"].clone()
+    with torch.no_grad():
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+    assert torch.equal(sample["K_cv2"], K_before)
+    imgs, masks = imgs.cpu(), masks.cpu()
+    ref_i, ref_m = T(g["imgs_sub"]), T(g["masks_sub"])
+    assert (imgs[:, :, ::4, ::4] - ref_i).abs().max().item() < 2e-3
+    assert (masks[:, :, ::4, ::4] - ref_m).abs().max().item() < 5e-4
+    assert fo.psnr(imgs[:, :, ::4, ::4], ref_i) > 60.0
+    assert (imgs.mean(dim=(1, 2, 3)) - T(g["imgs_mean"])).abs().max().item() < 1e-4
+
+
+def test_forge_gt_pose_5in5out_vs_oracle(dev):
+    """The bench configuration: FORGE, GT poses, 5 input views -> 1 fusion -> 5 rendered views."""
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(w)
+    model = model.to(dev).eval()
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=2)
+    with torch.no_grad():
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+        oi, om = fo.forward_hot_path(sample["images"], sample["cam_poses_cv2_canonicalized"],
+                                     sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
+                                     order_by_distance=True)
+    assert imgs.shape == (5, 3, 256, 256)
+    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
+    assert (masks.cpu() - om).abs().max().item() < 5e-4
+
+
+def test_training_step_runs(dev):
+    """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).train()
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=4)
+    imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+    tgt_i = sample["images"][0].repeat(2, 1, 1, 1).to(dev)
+    tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1).to(dev)
+    loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, tgt_m)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    opt.step()
+    assert torch.isfinite(loss)
+    g = model.encoder_3d.fusion_feature.cells[0].conv_gate.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+    g0 = model.encoder_3d.feature_extraction[0].weight.grad
+    assert g0 is not None and torch.isfinite(g0).all()

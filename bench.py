@@ -135,7 +135,6 @@ def cpu_baseline(sample, weights, cfg, budget_s=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     one = {k: v[:1].cpu() for k, v in sample.items()}
 
     def run():
@@ -143,17 +142,30 @@ def cpu_baseline(sample, weights, cfg, budget_s=25.0):
             return fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN],
                                        one["cam_extrinsics_cv2_canonicalized"][:, :T_IN], one["K_cv2"][:, :T_IN],
                                        weights, cfg, order_by_distance=True)
-    t0 = time.time()
-    ref = run()
-    warm = time.time() - t0
-    n = max(1, min(5, int((budget_s - warm) / max(warm, 1e-3))))
-    t0 = time.time()
-    for _ in range(n):
-        run()
-    dt = (time.time() - t0) / n
-    return {"value": V_OUT / dt, "unit": "views/s", "cores": cores, "kind": "port",
+    # torch-CPU does not scale to every hardware thread of a 2-socket box (256 threads ran 30x slower than 32):
+    # probe a few thread counts inside the time budget and report the fastest one.
+    cands = sorted({c for c in (8, 16, 32, 64, cores // 2) if 1 <= c <= cores})
+    best, ref, t_start = None, None, time.time()
+    for nt in cands:
+        torch.set_num_threads(nt)
+        t0 = time.time()
+        r = run()                                   # warm-up for this thread count
+        t1 = time.time()
+        if ref is None:
+            ref = r
+        if t1 - t0 > budget_s / 2 and best is not None:
+            continue
+        r = run()
+        dt_nt = time.time() - t1
+        if best is None or dt_nt < best[0]:
+            best = (dt_nt, nt)
+        if time.time() - t_start > budget_s:
+            break
+    dt, nthreads = best
+    n = 1
+    return {"value": V_OUT / dt, "unit": "views/s", "cores": nthreads, "host_hw_threads": cores, "kind": "port",
             "sample": "%d timed forward(s) of 1 scene (5x256^2 in, 32^3/64^3 grids, 5x128^2x64 rays out), torch-CPU fp32, "
-                      "%d threads, %.2f s each" % (n, torch.get_num_threads(), dt)}, ref
+                      "best of thread counts %s: %d threads, %.2f s per forward" % (n, cands, nthreads, dt)}, ref
 
 
 def main():

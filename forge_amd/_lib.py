@@ -3,6 +3,11 @@ missing or a call fails, a RuntimeError is raised — the product never routes t
 import ctypes
 import os
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64; libforge_hip.so must bind to the HIP runtime that
+# owns torch's streams and allocations. Loading our library before torch would pull in /opt/rocm's copy
+# and every launch on a torch stream would fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libforge_hip.so")
 _lib = None
@@ -20,6 +25,7 @@ SIGNATURES = {
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
+    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 9 + [_P],
     "forge_ncdhw_to_ndhwc": [_P, _P, _I, _I, _LL, _P],
     "forge_ndhwc_to_ncdhw": [_P, _P, _I, _I, _LL, _P],
 }
@@ -54,5 +60,4 @@ def ptr(t):
 
 
 def current_stream():
-    import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,97 @@
+"""Host-side plumbing for the fp32-MFMA implicit-GEMM convolution kernel (forge_conv_igemm).
+
+Weight packing ([Cout,Cin,k..] -> [tap][Cout][Cin]), eval-mode BatchNorm folding, tap lists,
+ConvTranspose phase decomposition and the launch wrapper. No arithmetic of the hot path happens
+here apart from the one-off weight repacks (cached per parameter version).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+EPI_BIAS, EPI_AFFINE_ACT, EPI_GRU_GATES, EPI_GRU_OUT = 0, 1, 2, 3
+
+
+def _taps_array(taps):
+    flat = [int(v) for t in taps for v in t]
+    return (ctypes.c_int * len(flat))(*flat)
+
+
+TAPS_3x3x3 = [(kz - 1, ky - 1, kx - 1) for kz in range(3) for ky in range(3) for kx in range(3)]
+
+
+def pack_conv3d_weight(w):
+    """nn.Conv3d weight [Cout,Cin,3,3,3] (cross-correlation, pad 1) -> [27][Cout][Cin]; tap t = (kz*3+ky)*3+kx
+    multiplies in[z+kz-1, y+ky-1, x+kx-1]."""
+    co, ci = w.shape[:2]
+    return w.detach().reshape(co, ci, -1).permute(2, 0, 1).contiguous()
+
+
+def pad_cin(wp, cin_pad):
+    """Zero-pad packed weights [T][Cout][Cin] along Cin (inputs narrower than the 32-channel K-step)."""
+    t, co, ci = wp.shape
+    if ci == cin_pad:
+        return wp
+    out = torch.zeros(t, co, cin_pad, dtype=wp.dtype, device=wp.device)
+    out[:, :, :ci] = wp
+    return out
+
+
+def convT3d_k4s2p1_phases(w):
+    """nn.ConvTranspose3d(k=4, s=2, p=1) weight [Cin,Cout,4,4,4] -> 8 output-phase GEMMs.
+    Output o = 2 z + p gets, per axis, for p=0: (di=0,k=1), (di=-1,k=3); for p=1: (di=+1,k=0), (di=0,k=2).
+    Returns [(phase (pz,py,px), taps [(dz,dy,dx)]*8, wp [8][Cout][Cin])]."""
+    axis = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
+    out = []
+    wd = w.detach()
+    for pz in (0, 1):
+        for py in (0, 1):
+            for px in (0, 1):
+                taps, mats = [], []
+                for dz, kz in axis[pz]:
+                    for dy, ky in axis[py]:
+                        for dx, kx in axis[px]:
+                            taps.append((dz, dy, dx))
+                            mats.append(wd[:, :, kz, ky, kx].t())          # [Cout][Cin]
+                out.append(((pz, py, px), taps, torch.stack(mats).contiguous()))
+    return out
+
+
+def bn_affine(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean.detach() * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+class PackCache:
+    """Re-pack derived tensors only when a source parameter/buffer changed (optimizer step, load_state_dict, .to())."""
+
+    def __init__(self):
+        self._key = None
+        self.val = None
+
+    def get(self, sources, build):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
+        if key != self._key:
+            self.val = build()
+            self._key = key
+        return self.val
+
+
+def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
+               grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
+               bs1=0, bs2=0):
+    """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid)."""
+    n, D, H, W = grid
+    Di, Hi, Wi = in_grid
+    Do, Ho, Wo = out_grid if out_grid is not None else (D, H, W)
+    if wp.shape != (len(taps), Cout, C1 + C2):
+        raise ValueError("packed weight %s does not match taps=%d Cout=%d Cin=%d" % (tuple(wp.shape), len(taps), Cout, C1 + C2))
+    p = _lib.ptr
+    _lib.check(_lib.lib().forge_conv_igemm(
+        p(in1), C1, ld1, int(bs1), p(in2), C2, ld2, int(bs2), p(wp), p(bias), p(scale), p(shift), float(slope), p(residual), p(aux_h), p(aux_z),
+        p(out), p(out2), n, D, H, W, istride, Di, Hi, Wi, Cout, ldo, _taps_array(taps), len(taps), ostride,
+        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, _lib.current_stream()), "forge_conv_igemm")
+    return out

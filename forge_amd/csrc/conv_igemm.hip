@@ -1,0 +1,285 @@
+// conv_igemm.hip — implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+// Replaces the dense convolutions of the hot path that the reference runs through cuDNN:
+// the ConvGRU fusion (models/fusion.py:29-35, 61-68: 71 % of the hot-path FLOPs), conv1
+// (models/encoder.py:36-40) and the heads (models/encoder.py:16-34), with the element-wise tails
+// (bias, eval-mode BN, LeakyReLU, GRU sigmoid/tanh/lerp, the cat([x, h])) fused into the GEMM.
+//
+//   GEMM view:  M = output voxels, N = C_out, K = taps * C_in
+//   A[m][k]     = in[voxel(m) + tap offset][ci]      gathered on the fly (zero outside the grid)
+//   B[k][n]     = Wp[tap][n][ci]                      weights pre-packed [tap][C_out][C_in]
+//
+// Arithmetic is exact fp32: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bitwise an fmaf
+// chain; 157 TFLOP/s chip peak = 1/16 of bf16) — the reference is fp32 and parity is stated in
+// fp32. There is no xf32/TF32 on gfx950.
+//
+// Tiling: 256 threads = 4 waves as 2x2, workgroup tile 128(M) x BN(N) x 32(K), wave tile
+// 64 x BN/2 made of 32x32 MFMA tiles. Both operands are staged as [row][32 k] images in LDS
+// (128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 so that the 16-lane groups of
+// ds_read_b128 hit 16 distinct slots), filled through registers (global_load_dwordx4 ->
+// ds_write_b128: zero-fill of out-of-grid taps is a select on the loaded value, and fp32 MFMA is
+// slow enough - 64 cycles each - that the staging path has >10x slack), double-buffered with one
+// barrier per K-step and the next K-step's global loads in flight under the current MFMAs.
+// The K order inside a 32-chunk is permuted identically for A and B: a lane's 16-byte read
+// supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of MFMA j.
+#include "common.h"
+#include <type_traits>
+
+namespace forge {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+enum ConvEpilogue : int {
+    EPI_BIAS = 0,        // y = acc + bias
+    EPI_AFFINE_ACT = 1,  // y = lrelu((acc + bias) * scale + shift, slope)   (eval BN folded; slope 1 = none, 0 = ReLU)
+    EPI_GRU_GATES = 2,   // cols [0,Ch): out[m][c] = sigmoid(v) (update z); cols [Ch,2Ch): out2[m][c-Ch] = h * sigmoid(v)
+    EPI_GRU_OUT = 3,     // cand = tanh(v); hn = h (1 - z) + cand z; out = hn; out2 (nullable) = hn * scale + shift
+};
+
+struct ConvArgs {
+    const float* in1; const float* in2;   // channel-concatenated inputs, channels-last; in2 nullable
+    int C1, C2, ld1, ld2;                  // channels taken from each input and their row strides (floats)
+    long long bs1, bs2;                    // batch strides of in1/in2 in rows (voxels)
+    const float* wp;                       // [ntaps][Cout][C1 + C2]
+    const float* bias;                     // [Cout] nullable
+    const float* scale; const float* shift; float slope;
+    const float* aux_h; const float* aux_z;
+    float* out; float* out2;
+    int n, D, H, W;                        // GEMM-row grid (M = n D H W rows)
+    int is, Di, Hi, Wi;                    // input voxel = (z is + dz, y is + dy, x is + dx) in an (n,Di,Hi,Wi) grid
+    const float* residual;                 // EPI_AFFINE_ACT: added before the activation (nullable), [rows][ldo]
+    int Cout, ldo;                         // output channels, output row stride (floats)
+    int ntaps;
+    int os, pz, py, px, Do, Ho, Wo;        // output voxel = (z os + pz, y os + py, x os + px) in an (Do,Ho,Wo) grid
+    int epi;
+    signed char tap[27][4];                // (dz, dy, dx, 0)
+};
+
+constexpr int BM = 128, BK = 32;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset of a 16-byte chunk
+    return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int NT = BN / 64;                     // 32-col MFMA tiles per wave (wave tile 64 x BN/2)
+    constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
+    constexpr int BCH = BN / 32;                    // 16-byte B chunks per thread per K-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const int ntile_n = (a.Cout + BN - 1) / BN;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)(bid / ntile_n) * BM;
+    const int n0 = (bid % ntile_n) * BN;
+    const int Cin = a.C1 + a.C2;
+    const int kchunks = Cin / BK;
+    const int nsteps = a.ntaps * kchunks;
+
+    // ---- per-thread staging geometry: 4 A rows, BCH B rows, one 16-byte chunk each
+    const int cp = tid & 7;                                      // physical chunk in the 128-byte row
+    int ar[4]; long long am[4]; int az[4], ay[4], ax[4], an[4]; int asrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ar[j] = (tid >> 3) + 32 * j;
+        am[j] = m0 + ar[j];
+        long long v = am[j] < M ? am[j] : M - 1;
+        ax[j] = (int)(v % a.W); v /= a.W;
+        ay[j] = (int)(v % a.H); v /= a.H;
+        az[j] = (int)(v % a.D); v /= a.D;
+        an[j] = (int)v;
+        asrc[j] = (cp ^ ((ar[j] >> 1) & 7)) << 2;                // logical channel offset inside the 32-chunk
+    }
+    int br[BCH]; int bsrc[BCH]; bool bval[BCH];
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+        br[j] = (tid >> 3) + 32 * j;
+        bsrc[j] = (cp ^ ((br[j] >> 1) & 7)) << 2;
+        bval[j] = (n0 + br[j]) < a.Cout;
+    }
+
+    float4 ra[4], rb[BCH];
+    auto load_step = [&](int s) {
+        const int t = s / kchunks, c0 = (s - t * kchunks) * BK;
+        const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
+        const float* src; int cs, cl; long long bs;
+        if (c0 < a.C1) { src = a.in1; cs = a.ld1; cl = c0; bs = a.bs1; } else { src = a.in2; cs = a.ld2; cl = c0 - a.C1; bs = a.bs2; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int zi = az[j] * a.is + dz, yi = ay[j] * a.is + dy, xi = ax[j] * a.is + dx;
+            const bool ok = (am[j] < M) && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+            const long long vox = ok ? (long long)an[j] * bs + ((long long)zi * a.Hi + yi) * a.Wi + xi : 0;
+            const float4 v = *reinterpret_cast<const float4*>(src + vox * cs + cl + asrc[j]);
+            ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* wsrc = a.wp + ((long long)t * a.Cout) * Cin + c0;
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) {
+            const int row = bval[j] ? n0 + br[j] : 0;
+            const float4 v = *reinterpret_cast<const float4*>(wsrc + (long long)row * Cin + bsrc[j]);
+            rb[j] = bval[j] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+        float* sb = sa + A_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK + (cp << 2)) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) *reinterpret_cast<float4*>(sb + br[j] * BK + (cp << 2)) = rb[j];
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load_step(s + 1);
+        const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+        const float* sb = sa + A_FLOATS;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                             // 8 k-values per group
+            float4 fa[2], fb[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off(wm * 64 + i * 32 + l31, 2 * g + half));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / 2) + j * 32 + l31, 2 * g + half));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nsteps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // (fully unrolled per epilogue kind: the accumulators must stay in registers)
+    const int Ch = a.Cout / 2;
+    const bool remap = (a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W);
+    auto epilogue = [&](auto EPI_TAG) {
+        constexpr int EPI = decltype(EPI_TAG)::value;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+            const bool cok = col < a.Cout;
+            const int colc = cok ? col : 0;
+            const float bias = a.bias ? a.bias[colc] : 0.f;
+            float sc = 1.f, sh = 0.f;
+            if ((EPI == EPI_AFFINE_ACT || (EPI == EPI_GRU_OUT && a.out2)) && a.scale) { sc = a.scale[colc]; sh = a.shift[colc]; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias;
+                    if (cok && m < M) {
+                        long long orow = m;
+                        if (remap) {
+                            long long q = m;
+                            const int x = (int)(q % a.W); q /= a.W;
+                            const int y = (int)(q % a.H); q /= a.H;
+                            const int z = (int)(q % a.D); q /= a.D;
+                            orow = ((q * a.Do + (z * a.os + a.pz)) * a.Ho + (y * a.os + a.py)) * a.Wo + (x * a.os + a.px);
+                        }
+                        if constexpr (EPI == EPI_BIAS) {
+                            a.out[orow * a.ldo + col] = v;
+                        } else if constexpr (EPI == EPI_AFFINE_ACT) {
+                            v = fmaf(v, sc, sh);
+                            if (a.residual) v += a.residual[orow * a.ldo + col];
+                            a.out[orow * a.ldo + col] = v > 0.f ? v : v * a.slope;
+                        } else if constexpr (EPI == EPI_GRU_GATES) {
+                            const float g = 1.f / (1.f + __expf(-v));
+                            if (col < Ch) a.out[orow * Ch + col] = g;
+                            else a.out2[orow * Ch + (col - Ch)] = a.aux_h[orow * Ch + (col - Ch)] * g;
+                        } else {   // EPI_GRU_OUT
+                            const float cand = tanhf(v);
+                            const float z = a.aux_z[orow * a.Cout + col], h = a.aux_h[orow * a.Cout + col];
+                            const float hn = h * (1.f - z) + cand * z;
+                            a.out[orow * a.ldo + col] = hn;
+                            if (a.out2) a.out2[orow * a.ldo + col] = fmaf(hn, sc, sh);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    switch (a.epi) {
+        case EPI_BIAS: epilogue(std::integral_constant<int, EPI_BIAS>{}); break;
+        case EPI_AFFINE_ACT: epilogue(std::integral_constant<int, EPI_AFFINE_ACT>{}); break;
+        case EPI_GRU_GATES: epilogue(std::integral_constant<int, EPI_GRU_GATES>{}); break;
+        default: epilogue(std::integral_constant<int, EPI_GRU_OUT>{}); break;
+    }
+}
+
+}  // namespace forge
+
+using namespace forge;
+
+// Generic entry; see include/forge_hip.h for the contract.
+extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
+                                const float* wp,
+                                const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                                const float* aux_h, const float* aux_z, float* out, float* out2,
+                                int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
+                                const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
+                                int epilogue, forge_stream_t stream) {
+    FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
+    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= 27, FORGE_EINVAL,
+                  "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
+    FORGE_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0, FORGE_ESHAPE,
+                  "forge_conv_igemm: C1=%d / C2=%d must be multiples of 32 (K-step)", C1, C2);
+    FORGE_REQUIRE((C2 == 0) == (in2 == nullptr), FORGE_EINVAL, "forge_conv_igemm: in2/C2 mismatch");
+    FORGE_REQUIRE(epilogue >= 0 && epilogue <= 3, FORGE_EINVAL, "forge_conv_igemm: unknown epilogue %d", epilogue);
+    FORGE_REQUIRE(epilogue != EPI_AFFINE_ACT || (scale && shift), FORGE_EINVAL, "forge_conv_igemm: affine epilogue needs scale/shift");
+    FORGE_REQUIRE(epilogue != EPI_GRU_GATES || (aux_h && out2 && Cout % 2 == 0), FORGE_EINVAL, "forge_conv_igemm: GRU gate epilogue needs aux_h, out2");
+    FORGE_REQUIRE(epilogue != EPI_GRU_OUT || (aux_h && aux_z), FORGE_EINVAL, "forge_conv_igemm: GRU out epilogue needs aux_h, aux_z");
+    FORGE_REQUIRE(os >= 1 && Do > 0 && Ho > 0 && Wo > 0, FORGE_EINVAL, "forge_conv_igemm: bad output mapping");
+    FORGE_REQUIRE(is >= 1 && Di > 0 && Hi > 0 && Wi > 0, FORGE_EINVAL, "forge_conv_igemm: bad input mapping");
+    FORGE_REQUIRE(ld1 >= C1 && ld1 % 4 == 0 && (C2 == 0 || (ld2 >= C2 && ld2 % 4 == 0)) && ldo >= 1, FORGE_EINVAL,
+                  "forge_conv_igemm: row strides must cover the channels and keep 16-byte alignment");
+    ConvArgs a;
+    a.in1 = in1; a.in2 = in2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.bs1 = bs1 > 0 ? bs1 : (long long)Di * Hi * Wi; a.bs2 = bs2 > 0 ? bs2 : (long long)Di * Hi * Wi; a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+    a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
+    a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
+    for (int t = 0; t < 27; ++t) {
+        for (int k = 0; k < 3; ++k) a.tap[t][k] = (signed char)(t < ntaps ? taps[t * 3 + k] : 0);
+        a.tap[t][3] = 0;
+    }
+    const long long M = (long long)n * D * H * W;
+    const long long mt = (M + BM - 1) / BM;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout > 64) {
+        constexpr int BN = 128;
+        const long long grid = mt * ((Cout + BN - 1) / BN);
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
+        const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(256), lds, st, a);
+    } else {
+        constexpr int BN = 64;
+        const long long grid = mt * ((Cout + BN - 1) / BN);
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
+        const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
+        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(256), lds, st, a);
+    }
+    FORGE_LAUNCH_CHECK("forge_conv_igemm");
+    return 0;
+}

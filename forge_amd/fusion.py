@@ -9,6 +9,15 @@ last_state_list, torch.stack of every h) is not reproduced — only the returned
 import torch
 import torch.nn as nn
 
+from . import convops as co
+
+
+def hip_inference(module, x):
+    """The fused HIP convolution path is taken for inference: eval-mode BN (folded into the GEMM epilogue)
+    and no autograd graph. Training keeps the stock torch ops for the dense convs (their backward kernels are
+    the next row to be hand-written), the HIP rotate/render ops have their own backward kernels."""
+    return x.is_cuda and x.dtype == torch.float32 and not module.training and not torch.is_grad_enabled()
+
 
 class ConvGRUCell_3D(nn.Module):
     """models/fusion.py:7-35. Gate split order is (update, reset) (:30)."""
@@ -50,6 +59,57 @@ class ConvGRU_3D(nn.Module):
             nn.BatchNorm3d(input_size),
             nn.LeakyReLU(inplace=True),
         )
+
+    # ---------------------------------------------------------------- fused HIP inference path
+    def _packed(self):
+        cell = self.cells[0]
+        fc = self.fusion_conv
+        src = [cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias,
+               fc[0].weight, fc[0].bias, fc[3].weight, fc[3].bias] + \
+              [t for bn in (fc[1], fc[4], self.fusion_norm) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+        if not hasattr(self, "_pack_cache"):
+            self._pack_cache = co.PackCache()
+
+        def build():
+            return {
+                "gate_w": co.pack_conv3d_weight(cell.conv_gate.weight), "gate_b": cell.conv_gate.bias.detach().contiguous(),
+                "out_w": co.pack_conv3d_weight(cell.out_gate.weight), "out_b": cell.out_gate.bias.detach().contiguous(),
+                "fc0_w": co.pack_conv3d_weight(fc[0].weight), "fc0_b": fc[0].bias.detach().contiguous(),
+                "fc3_w": co.pack_conv3d_weight(fc[3].weight), "fc3_b": fc[3].bias.detach().contiguous(),
+                "bn1": co.bn_affine(fc[1]), "bn4": co.bn_affine(fc[4]), "norm": co.bn_affine(self.fusion_norm),
+            }
+        return self._pack_cache.get(src, build)
+
+    def fuse_hip(self, x):
+        """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs, then per view
+        two implicit-GEMM launches (gates: cat/conv/sigmoid/h*r fused; state: cat/conv/tanh/lerp fused, the final
+        fusion_norm folded into the last one). x [b,t,C,D,H,W] -> [b,C,D,H,W] (channels-last memory)."""
+        assert self.n_layers == 1 and self.input_size == self.hidden_size
+        b, t, C, D, H, W = x.shape
+        xr = x.permute(0, 1, 3, 4, 5, 2)                          # [b,t,D,H,W,C] rows view
+        if not xr.is_contiguous():
+            xr = xr.contiguous()
+        p = self._packed()
+        dev, M, vol = x.device, b * D * H * W, D * H * W
+        grid, ig = (b, D, H, W), (D, H, W)
+        new = lambda: torch.empty(M, C, dtype=torch.float32, device=dev)
+        mean = xr.mean(dim=1).reshape(M, C)
+        taps = co.TAPS_3x3x3
+        t0, h = new(), new()
+        co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None,
+                      t0, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+        co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None,
+                      h, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+        z, hr, h2, out = new(), new(), t0, new()
+        for ti in range(t):
+            xt = xr[:, ti]                                        # base pointer of view ti; batch stride t*vol rows
+            co.conv_igemm(xt, C, C, h, C, C, p["gate_w"], p["gate_b"], None, None, 1.0, None, h, None, z, hr,
+                          grid, ig, 2 * C, C, taps, epilogue=co.EPI_GRU_GATES, bs1=t * vol)
+            last = ti == t - 1
+            co.conv_igemm(xt, C, C, hr, C, C, p["out_w"], p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z,
+                          h2, out if last else None, grid, ig, C, C, taps, epilogue=co.EPI_GRU_OUT, bs1=t * vol)
+            h, h2 = h2, h
+        return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
     def forward(self, x, hidden=None):
         """x [b,t,c,d,h,w] -> fusion_norm(h_T) [b,c',d,h,w]"""

@@ -103,6 +103,42 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
                      forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1/a4/a5  implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)
+ * with fused element-wise tails — replaces the cuDNN convolutions + separate element-wise ops of
+ * models/fusion.py:29-35 (ConvGRU cell: cat, conv, split, sigmoid, mul, cat, conv, tanh, lerp),
+ * models/fusion.py:61-68 (fusion_conv), models/encoder.py:36-40 (conv1) and :16-34 (heads; the
+ * ConvTranspose3d k4 s2 p1 runs as 8 output-phase GEMMs of 8 taps each).
+ *
+ *   rows                        the GEMM rows enumerate an (n,D,H,W) grid, M = n D H W
+ *   in1 / in2                   channels-last inputs on an (n,Di,Hi,Wi) grid; row of GEMM-grid voxel
+ *                               (z,y,x) and tap (dz,dy,dx) is input voxel (z is+dz, y is+dy, x is+dx),
+ *                               zero outside the grid. The conv sees C1 channels of in1 followed by C2 of
+ *                               in2 (in2 NULL <=> C2 = 0); ld1/ld2 = row strides in floats (>= C1/C2, so a
+ *                               channel slice of a wider tensor can be fed). C1, C2 % 32 == 0. bs1/bs2 = batch
+ *                               strides in rows (0 = dense Di Hi Wi): lets view t of a [b][t] stack be fed in place.
+ *   wp  [ntaps][Cout][C1+C2]    packed weights: wp[t][co][ci] multiplies in[voxel + taps[t]][ci]
+ *   taps [ntaps][3]             HOST array of (dz,dy,dx) input offsets, ntaps <= 27
+ *   out rows                    output voxel of GEMM-grid voxel (z,y,x) is (z os+pz, y os+py, x os+px)
+ *                               in an (n,Do,Ho,Wo) grid; row stride ldo floats.
+ *                               plain conv: is=os=1, Di=Do=D..; strided conv: is=2; ConvTranspose phase: os=2.
+ *   epilogue 0  out = acc + bias
+ *            1  out = lrelu((acc + bias) * scale + shift + residual, slope)   eval-BN folded; residual
+ *               [rows][ldo] nullable (ResNet shortcut); slope 1 = identity, 0 = ReLU
+ *            2  GRU gates (Cout = 2 Ch): out[m][c] = sigmoid(v_c), c < Ch (update);
+ *                                        out2[m][c] = aux_h[m][c] * sigmoid(v_{Ch+c})  (h * reset)
+ *            3  GRU state: hn = aux_h (1 - aux_z) + tanh(v) aux_z; out = hn;
+ *                          out2 (nullable) = hn * scale + shift          (fusion_norm on the last step)
+ * bias/scale/shift [Cout]; bias nullable.
+ */
+int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
+                     const float* wp,
+                     const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                     const float* aux_h, const float* aux_z, float* out, float* out2,
+                     int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
+                     const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
+                     int epilogue, forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.
  *   src [n][C][P] -> dst [n][P][C]   (P = D*H*W)   and back.
  */

@@ -279,3 +279,111 @@ def test_training_step_runs(dev):
     assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
     g0 = model.encoder_3d.feature_extraction[0].weight.grad
     assert g0 is not None and torch.isfinite(g0).all()
+
+
+# ------------------------------------------------------------------ fp32-MFMA implicit-GEMM convolution
+def _rows(x):      # [N,C,D,H,W] -> channels-last rows [N,D,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("Cin,Cout,dims", [(64, 96, (6, 7, 5)), (32, 16, (5, 4, 9)), (128, 256, (4, 4, 4))])
+def test_conv_igemm_plain_vs_conv3d(dev, Cin, Cout, dims):
+    """stated tolerance: 2e-5 * sqrt(K/1000) * |out|max (fp32 accumulation-order differences only)"""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(Cin + Cout)
+    D, H, W = dims
+    x = torch.randn(2, Cin, D, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv3d(x, w, b, padding=1)
+    out = torch.empty(2, D, H, W, Cout, device=dev)
+    co.conv_igemm(_rows(x).to(dev), Cin, Cin, None, 0, 0, co.pack_conv3d_weight(w).to(dev), b.to(dev), None, None, 1.0,
+                  None, None, None, out, None, (2, D, H, W), (D, H, W), Cout, Cout, co.TAPS_3x3x3, epilogue=co.EPI_BIAS)
+    got = out.permute(0, 4, 1, 2, 3).cpu()
+    tol = 2e-5 * max(1.0, (27 * Cin / 1000) ** 0.5) * ref.abs().max().item()
+    assert (got - ref).abs().max().item() < tol
+
+
+def test_conv_igemm_concat_affine_residual(dev):
+    """two channel-concatenated inputs (the cat([x,h]) of the GRU), folded BN + LeakyReLU + residual epilogue."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(1)
+    x1, x2 = torch.randn(1, 32, 5, 6, 7, generator=g), torch.randn(1, 64, 5, 6, 7, generator=g)
+    w = torch.randn(48, 96, 3, 3, 3, generator=g) / 50
+    b, sc, sh = torch.randn(48, generator=g), torch.rand(48, generator=g) + 0.5, torch.randn(48, generator=g)
+    res = torch.randn(1, 48, 5, 6, 7, generator=g)
+    ref = torch.nn.functional.conv3d(torch.cat([x1, x2], 1), w, b, padding=1) * sc[None, :, None, None, None] + sh[None, :, None, None, None] + res
+    ref = torch.nn.functional.leaky_relu(ref, 0.01)
+    out = torch.empty(1, 5, 6, 7, 48, device=dev)
+    co.conv_igemm(_rows(x1).to(dev), 32, 32, _rows(x2).to(dev), 64, 64, co.pack_conv3d_weight(w).to(dev), b.to(dev), sc.to(dev),
+                  sh.to(dev), 0.01, _rows(res).to(dev), None, None, out, None, (1, 5, 6, 7), (5, 6, 7), 48, 48, co.TAPS_3x3x3,
+                  epilogue=co.EPI_AFFINE_ACT)
+    assert (out.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
+
+
+def test_conv_igemm_strided2d_and_transpose_phases(dev):
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(2)
+    # 3x3 stride-2 2-D conv as a D=1 grid (ResNet layer2[0].conv2 shape family)
+    x = torch.randn(2, 64, 18, 14, generator=g)
+    w = torch.randn(96, 64, 3, 3, generator=g) / 24
+    ref = torch.nn.functional.conv2d(x, w, None, stride=2, padding=1)
+    Ho, Wo = ref.shape[-2:]
+    taps = [(0, ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+    wp = w.reshape(96, 64, 9).permute(2, 0, 1).contiguous()
+    out = torch.empty(2, 1, Ho, Wo, 96, device=dev)
+    co.conv_igemm(x.permute(0, 2, 3, 1).contiguous().to(dev), 64, 64, None, 0, 0, wp.to(dev), None, None, None, 1.0, None, None, None,
+                  out, None, (2, 1, Ho, Wo), (1, 18, 14), 96, 96, taps, istride=2, epilogue=co.EPI_BIAS)
+    # NB: with is=2 the D axis also scales (z*2+dz with z=0, dz=0 -> 0): fine for D=1
+    assert (out[:, 0].permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+    # ConvTranspose3d(k4,s2,p1) as 8 phase GEMMs
+    x = torch.randn(1, 32, 4, 5, 3, generator=g)
+    wt = torch.randn(32, 40, 4, 4, 4, generator=g) / 16
+    b = torch.randn(40, generator=g)
+    ref = torch.nn.functional.conv_transpose3d(x, wt, b, stride=2, padding=1)
+    out = torch.empty(1, 8, 10, 6, 40, device=dev)
+    for (pz, py, px), tp, wp in co.convT3d_k4s2p1_phases(wt):
+        co.conv_igemm(_rows(x).to(dev), 32, 32, None, 0, 0, wp.to(dev), b.to(dev), None, None, 1.0, None, None, None, out, None,
+                      (1, 4, 5, 3), (4, 5, 3), 40, 40, tp, out_grid=(8, 10, 6), ostride=2, phase=(pz, py, px), epilogue=co.EPI_BIAS)
+    assert (out.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+def test_fuse_hip_vs_oracle(dev):
+    """ConvGRU fusion (fusion_conv h0 + t GRU steps + fusion_norm) through the fused MFMA path vs the oracle."""
+    from forge_amd.fusion import ConvGRU_3D
+    gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=32, hidden_size=32)
+    pre = "encoder_3d.fusion_feature."
+    w = syn.seeded_state_dict({pre + k: v for k, v in gru.state_dict().items()}, 9)
+    gru.load_state_dict({k[len(pre):]: v for k, v in w.items()})
+    gru = gru.to(dev).eval()
+    x = torch.randn(2, 3, 32, 8, 8, 8, generator=torch.Generator().manual_seed(4))
+    ref = fo.fuse(x, w)
+    with torch.no_grad():
+        got = gru.fuse_hip(x.to(dev)).cpu()
+        stock = gru(x.to(dev), [gru.fusion_conv(x.to(dev).mean(dim=1))]).cpu()     # torch/MIOpen path, same module
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert (stock - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_heads_and_conv1_hip_vs_golden(dev, golden):
+    from forge_amd.encoder import Encoder3D
+    g = golden("heads_toy")
+    enc = Encoder3D(syn.kubric_config())
+    tmpl = {"encoder_3d." + k: v for k, v in enc.state_dict().items()}
+    w = syn.seeded_state_dict(tmpl, int(g["weight_seed"]))
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()})
+    enc = enc.to(dev).eval()
+    z = T(g["z"]).to(dev)
+    with torch.no_grad():
+        dens = enc.get_density3D(z).cpu()
+        feat = enc.get_render_features(z).cpu()
+    assert (dens - T(g["density"])).abs().max().item() < 5e-5
+    assert (feat - T(g["features"])).abs().max().item() < 5e-5
+    # conv1 on a random 64-channel volume
+    x = torch.randn(2, 64, 32, 6, 6, generator=torch.Generator().manual_seed(8))
+    ref = torch.nn.functional.leaky_relu(fo._bn(torch.nn.functional.conv3d(x, w["encoder_3d.conv1.0.weight"], w["encoder_3d.conv1.0.bias"], padding=1),
+                                                w, "encoder_3d.conv1.1"), 0.01)
+    with torch.no_grad():
+        got = enc._conv1_hip(x.to(dev)).cpu()
+    assert (got - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())

@@ -43,30 +43,34 @@ GF_HEADS = 45.3
 GF_CONVRGB = 0.80 * V_OUT
 
 
-def stage_hooks(model):
-    """HIP events around the hot-path stages, recorded on the current (launch) stream."""
-    rec = {}
+def stage_timers(model):
+    """HIP events around the hot-path stages, recorded on the current (launch) stream. Wraps the sub-module
+    entry points FORGE.forward calls; returns (records, undo)."""
+    rec, undo = {}, []
 
-    def add(name, mod):
-        def pre(m, a, kw=None):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            rec.setdefault(name, []).append([e, None])
+    def wrap(obj, attr, name):
+        fn = getattr(obj, attr)
 
-        def post(m, a, o):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            rec[name][-1][1] = e
-        return [mod.register_forward_pre_hook(pre), mod.register_forward_hook(post)]
+        def timed(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            rec.setdefault(name, []).append((e0, e1))
+            return out
+        setattr(obj, attr, timed)          # instance attribute shadows the class method
+        undo.append(lambda: delattr(obj, attr))
 
-    hs = []
     e3 = model.encoder_3d
-    for name, mod in (("encoder_resnet", e3.feature_extraction), ("encoder_conv1", e3.conv1), ("rotate", model.rotate),
-                      ("fuse_h0", e3.fusion_feature.fusion_conv), ("fuse_gru", e3.fusion_feature),
-                      ("density_head", e3.density_head), ("features_head", e3.features_head),
-                      ("render_total", model.render), ("conv_rgb", model.render.conv_rgb)):
-        hs += add(name, mod)
-    return rec, hs
+    wrap(e3.feature_extraction, "forward", "encoder_resnet")
+    wrap(e3, "get_feat3D", "encoder_total")
+    wrap(model.rotate, "forward", "rotate")
+    wrap(e3, "fuse", "fuse")
+    wrap(e3, "get_density3D", "heads_density(+shared convT)")
+    wrap(e3, "get_render_features", "heads_features")
+    wrap(model.render, "forward", "render_total")
+    wrap(model.render.conv_rgb, "forward", "conv_rgb")
+    return rec, undo
 
 
 def time_kernel(fn, iters=20, warm=3):
@@ -122,6 +126,25 @@ def kernel_rooflines(dev, B):
     out["render_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS,
                                 "gather_Gtaps_per_s": taps / ms / 1e6, "views_per_s_kernel_only": V / ms * 1e3}
+    # dense stage: the fp32-MFMA implicit-GEMM conv at the three ConvGRU shapes (32^3 grid, 3x3x3 taps)
+    from forge_amd import convops as co
+    M, Cc = B * D ** 3, 128
+    x = torch.randn(M, Cc, device=dev)
+    hbuf = torch.randn(M, Cc, device=dev)
+    zbuf = torch.rand(M, Cc, device=dev)
+    o1, o2 = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+    grid, ig = (B, D, D, D), (D, D, D)
+    for name, Cout, C2, epi in (("convgru_gates N=256 K=6912", 256, Cc, co.EPI_GRU_GATES), ("convgru_state N=128 K=6912", 128, Cc, co.EPI_GRU_OUT),
+                                ("fusion_conv N=128 K=3456", 128, 0, co.EPI_AFFINE_ACT)):
+        wp = torch.randn(27, Cout, Cc + C2, device=dev) * 0.01
+        bias = torch.zeros(Cout, device=dev)
+        sc, sh = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+        ms = time_kernel(lambda: co.conv_igemm(x, Cc, Cc, hbuf if C2 else None, C2, C2, wp, bias, sc, sh, 0.01, None, hbuf, zbuf, o1,
+                                               o2 if epi == co.EPI_GRU_GATES else None, grid, ig, Cout, Cc if epi == co.EPI_GRU_GATES else Cout,
+                                               co.TAPS_3x3x3, epilogue=epi), iters=10, warm=2)
+        flops = 2.0 * M * Cout * 27 * (Cc + C2)
+        out["conv_igemm_kernel<128> " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9,
+                                                  "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF}
     return out
 
 
@@ -218,32 +241,34 @@ def main():
     views = world * B * V_OUT * args.steps
 
     # ---- per-stage HIP-event split of one more step (outside the timed region)
-    rec, hooks = stage_hooks(model)
+    rec, undo = stage_timers(model)
     for _ in range(3):
         rec.clear()
         step()
     torch.cuda.synchronize()
     stages = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in rec.items()}
-    for h in hooks:
-        h.remove()
-    stages["fuse_gru"] = stages["fuse_gru"]                       # 5 GRU steps + fusion_norm
-    stages["render_march"] = stages.pop("render_total") - stages["conv_rgb"]
+    for u in undo:
+        u()
+    stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages["encoder_resnet"]
+    stages["render_march(+cam pack)"] = stages.pop("render_total") - stages["conv_rgb"]
 
     result = None
     if rank == 0:
         kern = kernel_rooflines(dev, B)
-        fuse_ms = stages["fuse_gru"] + stages["fuse_h0"]
-        fuse_tf = B * GF_FUSE / fuse_ms            # GFLOP / ms = TFLOP/s
-        roofline = {"kernel": "ConvGRU fusion stage (3x3x3 conv, K=6912; MIOpen via PyTorch-ROCm until the HIP MFMA kernel lands)",
-                    "bound": "mfma", "achieved": fuse_tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": fuse_tf / FP32_MFMA_PEAK_TF, "traffic": None, "share_of_step": fuse_ms / (dt / args.steps * 1e3)}
+        kg = kern["conv_igemm_kernel<128> convgru_gates N=256 K=6912"]
+        fuse_tf = B * GF_FUSE / stages["fuse"]            # GFLOP / ms = TFLOP/s over the whole fusion stage (12 launches + mean)
+        roofline = {"kernel": "conv_igemm_kernel<128> (fp32 MFMA implicit GEMM; ConvGRU gates launch: M=%d, N=256, K=6912)" % (B * 32 ** 3),
+                    "bound": "mfma", "achieved": kg["achieved"], "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": kg["frac"],
+                    "traffic": None, "avg_launch_ms": kg["ms"], "fusion_stage_tflops": fuse_tf,
+                    "fusion_stage_share_of_step": stages["fuse"] / (dt / args.steps * 1e3)}
         result = {
             "metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": views / dt, "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
-                                   "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate + "
-                                   "HIP ray-march, dense convs via PyTorch-ROCm/MIOpen, eval BN, random-init seeded weights" % B,
+                                   "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
+                                   "fp32-MFMA implicit-GEMM conv1/ConvGRU/heads, HIP ray-march; ResNet-50 trunk + conv_rgb via PyTorch-ROCm/MIOpen; "
+                                   "eval BN, random-init seeded weights" % B,
                        "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
             "roofline": roofline, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "gflop_per_step_algorithmic": B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB),

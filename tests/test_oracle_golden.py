@@ -109,3 +109,26 @@ def test_forward_golden(golden):
     assert (imgs[:, :, ::4, ::4] - T(g["imgs_sub"])).abs().max().item() < 5e-4
     assert (masks[:, :, ::4, ::4] - T(g["masks_sub"])).abs().max().item() < 1e-4
     assert fo.psnr(imgs[:, :, ::4, ::4], T(g["imgs_sub"])) > 80.0
+
+
+def test_c_restatement_matches_golden(golden):
+    """oracle/c/forge_oracle.c (scalar loops, no grid_sample) reproduces the reference's rotate and ray-march
+    outputs: pins the trilinear / align_corners / compositing conventions independently of torch."""
+    import c_oracle
+    g = golden("rotate_d16")
+    vox, P = T(g["voxels"]), T(g["poses"])
+    B, t = vox.shape[:2]
+    Tm = torch.eye(4).repeat(B, t, 1, 1)
+    Tm[:, 1:] = fo.relative_transforms(P).reshape(B, t - 1, 4, 4)
+    mode = np.ones((B, t), np.int32)
+    mode[:, 0] = 0
+    out = c_oracle.rotate(vox.reshape(B * t, *vox.shape[2:]).numpy(), Tm.reshape(B * t, 4, 4).numpy(), mode.reshape(-1),
+                          float(g["half_extent"]))
+    assert np.abs(out.reshape(g["out"].shape) - g["out"]).max() < 2e-5
+    g = golden("render_d16")
+    Kh = fo.halve_intrinsics(T(g["K"])).numpy()
+    img = int(g["img_size"])
+    h = fo.grid_half_extent(g["feat"].shape[2], float(g["vol_size"]))
+    raw = c_oracle.render(g["feat"], g["dens"], g["R"], g["T"], Kh, img // 2, img // 2, int(g["n_pts"]),
+                          float(g["min_depth"]), float(g["max_depth"]), (h, h, h))
+    assert np.abs(raw - g["raw"]).max() < 3e-5

@@ -39,7 +39,8 @@ enum ConvEpilogue : int {
 struct ConvArgs {
     const float* in1; const float* in2;   // channel-concatenated inputs, channels-last; in2 nullable
     int C1, C2, ld1, ld2;                  // channels taken from each input and their row strides (floats)
-    long long bs1, bs2;                    // batch strides of in1/in2 in rows (voxels)
+    long long bs1r, bs2r;                  // batch strides of in1/in2 in rows (voxels)
+    long long span1, span2;                // byte spans of in1/in2 (buffer-descriptor bounds, < 2 GiB)
     const float* wp;                       // [ntaps][Cout][C1 + C2]
     const float* bias;                     // [Cout] nullable
     const float* scale; const float* shift; float slope;
@@ -55,17 +56,29 @@ struct ConvArgs {
     signed char tap[27][4];                // (dz, dy, dx, 0)
 };
 
-constexpr int BM = 128, BK = 32;
+constexpr int BM = 128, BK = 32, NTHREADS = 512;
+
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+constexpr unsigned OOB = 0x80000000u;      // byte offset beyond any buffer (< 2 GiB spans enforced on the host side)
+
+// Raw buffer load: out-of-range offsets return 0 — the zero padding of out-of-grid taps and of
+// rows/cols beyond M / Cout costs neither a branch nor a select.
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset of a 16-byte chunk
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int NT = BN / 64;                     // 32-col MFMA tiles per wave (wave tile 64 x BN/2)
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int NT = BN / 64;                     // 32-col MFMA tiles per wave (8 waves as 4(M) x 2(N); wave tile 32 x BN/2)
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
-    constexpr int BCH = BN / 32;                    // 16-byte B chunks per thread per K-step
+    constexpr int ACH = 2, BCH = BN / 64;           // 16-byte chunks per thread per K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -79,94 +92,108 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int kchunks = Cin / BK;
     const int nsteps = a.ntaps * kchunks;
 
-    // ---- per-thread staging geometry: 4 A rows, BCH B rows, one 16-byte chunk each
-    const int cp = tid & 7;                                      // physical chunk in the 128-byte row
-    int ar[4]; long long am[4]; int az[4], ay[4], ax[4], an[4]; int asrc[4];
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
+
+    // ---- per-thread staging geometry: ACH A rows, BCH B rows, one 16-byte chunk each
+    const int cp = tid & 7;                                      // physical chunk in the 128-byte LDS row
+    int ar[ACH], az[ACH], ay[ACH], ax[ACH], an[ACH], asrc[ACH];
+    bool aval[ACH];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ar[j] = (tid >> 3) + 32 * j;
-        am[j] = m0 + ar[j];
-        long long v = am[j] < M ? am[j] : M - 1;
-        ax[j] = (int)(v % a.W); v /= a.W;
-        ay[j] = (int)(v % a.H); v /= a.H;
-        az[j] = (int)(v % a.D); v /= a.D;
+    for (int j = 0; j < ACH; ++j) {
+        ar[j] = (tid >> 3) + 64 * j;
+        long long v = m0 + ar[j];
+        aval[j] = v < M;
+        v = aval[j] ? v : 0;
+        ax[j] = (int)(v % a.W) * a.is; v /= a.W;
+        ay[j] = (int)(v % a.H) * a.is; v /= a.H;
+        az[j] = (int)(v % a.D) * a.is; v /= a.D;
         an[j] = (int)v;
         asrc[j] = (cp ^ ((ar[j] >> 1) & 7)) << 2;                // logical channel offset inside the 32-chunk
     }
-    int br[BCH]; int bsrc[BCH]; bool bval[BCH];
+    int br[BCH]; unsigned boff[BCH];
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-        br[j] = (tid >> 3) + 32 * j;
-        bsrc[j] = (cp ^ ((br[j] >> 1) & 7)) << 2;
-        bval[j] = (n0 + br[j]) < a.Cout;
+        br[j] = (tid >> 3) + 64 * j;
+        const int bsrc = (cp ^ ((br[j] >> 1) & 7)) << 2;
+        boff[j] = (n0 + br[j]) < a.Cout ? (unsigned)(((n0 + br[j]) * Cin + bsrc) * 4) : OOB;
     }
 
-    float4 ra[4], rb[BCH];
-    auto load_step = [&](int s) {
-        const int t = s / kchunks, c0 = (s - t * kchunks) * BK;
+    int erow[ACH], erow2[ACH];                                   // input row index (in1 / in2) of each A row for the current tap (-1: outside)
+    auto prep_tap = [&](int t) {
         const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
-        const float* src; int cs, cl; long long bs;
-        if (c0 < a.C1) { src = a.in1; cs = a.ld1; cl = c0; bs = a.bs1; } else { src = a.in2; cs = a.ld2; cl = c0 - a.C1; bs = a.bs2; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int zi = az[j] * a.is + dz, yi = ay[j] * a.is + dy, xi = ax[j] * a.is + dx;
-            const bool ok = (am[j] < M) && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
-            const long long vox = ok ? (long long)an[j] * bs + ((long long)zi * a.Hi + yi) * a.Wi + xi : 0;
-            const float4 v = *reinterpret_cast<const float4*>(src + vox * cs + cl + asrc[j]);
-            ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < ACH; ++j) {
+            const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
+            const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+            const int sp = (zi * a.Hi + yi) * a.Wi + xi;
+            erow[j] = ok ? an[j] * (int)a.bs1r + sp : -1;
+            erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
         }
-        const float* wsrc = a.wp + ((long long)t * a.Cout) * Cin + c0;
+    };
+    float4 ra[ACH], rb[BCH];
+    auto load_step = [&](int t, int kc) {
+        const int c0 = kc * BK;
+        if (c0 < a.C1) {
 #pragma unroll
-        for (int j = 0; j < BCH; ++j) {
-            const int row = bval[j] ? n0 + br[j] : 0;
-            const float4 v = *reinterpret_cast<const float4*>(wsrc + (long long)row * Cin + bsrc[j]);
-            rb[j] = bval[j] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < ACH; ++j)
+                ra[j] = buf_load16(r1, erow[j] < 0 ? OOB : (unsigned)((erow[j] * a.ld1 + c0 + asrc[j]) * 4));
+        } else {
+#pragma unroll
+            for (int j = 0; j < ACH; ++j)
+                ra[j] = buf_load16(r2, erow2[j] < 0 ? OOB : (unsigned)((erow2[j] * a.ld2 + (c0 - a.C1) + asrc[j]) * 4));
         }
+        const unsigned wbase = (unsigned)((t * a.Cout * Cin + c0) * 4);
+#pragma unroll
+        for (int j = 0; j < BCH; ++j) rb[j] = buf_load16(rw, boff[j] == OOB ? OOB : boff[j] + wbase);
     };
     auto store_step = [&](int buf) {
         float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         float* sb = sa + A_FLOATS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK + (cp << 2)) = ra[j];
+        for (int j = 0; j < ACH; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK + (cp << 2)) = ra[j];
 #pragma unroll
         for (int j = 0; j < BCH; ++j) *reinterpret_cast<float4*>(sb + br[j] * BK + (cp << 2)) = rb[j];
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    load_step(0);
+    int t = 0, kc = 0;
+    prep_tap(0);
+    load_step(0, 0);
     store_step(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_step(s + 1);
+        const bool more = s + 1 < nsteps;
+        if (more) {
+            if (++kc == kchunks) { kc = 0; ++t; prep_tap(t); }
+            load_step(t, kc);                                     // in flight under this step's MFMAs
+        }
         const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         const float* sb = sa + A_FLOATS;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                             // 8 k-values per group
-            float4 fa[2], fb[NT];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off(wm * 64 + i * 32 + l31, 2 * g + half));
+            const float4 fa = *reinterpret_cast<const float4*>(sa + lds_off(wm * 32 + l31, 2 * g + half));
+            float4 fb[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / 2) + j * 32 + l31, 2 * g + half));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[j], 0, 0, 0);
         }
-        if (s + 1 < nsteps) store_step(buf ^ 1);
+        if (more) store_step(buf ^ 1);
         __syncthreads();
     }
 
@@ -184,12 +211,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             const float bias = a.bias ? a.bias[colc] : 0.f;
             float sc = 1.f, sh = 0.f;
             if ((EPI == EPI_AFFINE_ACT || (EPI == EPI_GRU_OUT && a.out2)) && a.scale) { sc = a.scale[colc]; sh = a.shift[colc]; }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[i][j][r] + bias;
+                    const long long m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[j][r] + bias;
                     if (cok && m < M) {
                         long long orow = m;
                         if (remap) {
@@ -256,7 +282,11 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     FORGE_REQUIRE(ld1 >= C1 && ld1 % 4 == 0 && (C2 == 0 || (ld2 >= C2 && ld2 % 4 == 0)) && ldo >= 1, FORGE_EINVAL,
                   "forge_conv_igemm: row strides must cover the channels and keep 16-byte alignment");
     ConvArgs a;
-    a.in1 = in1; a.in2 = in2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.bs1 = bs1 > 0 ? bs1 : (long long)Di * Hi * Wi; a.bs2 = bs2 > 0 ? bs2 : (long long)Di * Hi * Wi; a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+    a.in1 = in1; a.in2 = in2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.bs1r = bs1 > 0 ? bs1 : (long long)Di * Hi * Wi; a.bs2r = bs2 > 0 ? bs2 : (long long)Di * Hi * Wi;
+    a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
+    a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
+    FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
+                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     for (int t = 0; t < 27; ++t) {
@@ -272,13 +302,13 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
         (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
     } else {
         constexpr int BN = 64;
         const long long grid = mt * ((Cout + BN - 1) / BN);
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
-        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

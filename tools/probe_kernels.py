@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Launch each hand-written kernel a few times at the bench shapes (b=1) — the target of the rocprofv3 PMC passes
+(HBM traffic / SQ counters), kept separate from bench.py so counter runs are short and contain only our kernels.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python tools/probe_kernels.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from forge_amd import _lib, convops as co, synthetic as syn  # noqa: E402
+
+dev = torch.device("cuda:0")
+iters = int(os.environ.get("PROBE_ITERS", "5"))
+which = os.environ.get("PROBE_KERNELS", "rotate,render,conv").split(",")
+lib, st = _lib.lib(), _lib.current_stream()
+
+if "rotate" in which:
+    C, D, n = 128, 32, 5
+    vox = torch.randn(n, D, D, D, C, device=dev)
+    dst = torch.empty_like(vox)
+    xf = torch.tensor([1, 0, 0, 0.02, 0, 0.8, -0.6, 0, 0, 0.6, 0.8, 0.01], device=dev).repeat(n, 1).contiguous()
+    mode = torch.ones(n, dtype=torch.int32, device=dev)
+    mode[0] = 0
+    for _ in range(iters):
+        _lib.check(lib.forge_rotate_fwd(_lib.ptr(vox), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(dst), n, C, D, D, D, st), "rotate")
+
+if "render" in which:
+    Dr, Cr, V = 64, 16, 5
+    feat, dens = syn.blob_volumes(1, Dr, Cr, seed=0)
+    feat = feat.to(dev).permute(0, 2, 3, 4, 1).contiguous()
+    dens = dens.to(dev).contiguous()
+    _, extr, _ = syn.orbit_cameras(V, 1.5, 10.0)
+    K = syn.intrinsics(256) / 2.0
+    cam = torch.cat([extr[:, :3, :3].reshape(V, 9), extr[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1),
+                     K[0, 2].expand(V, 1), K[1, 2].expand(V, 1)], dim=1).contiguous().to(dev)
+    v2v = torch.zeros(V, dtype=torch.int32, device=dev)
+    of, oo = torch.empty(V, Cr, 128, 128, device=dev), torch.empty(V, 128, 128, device=dev)
+    h = 0.5 * (Dr - 1) / Dr
+    for _ in range(iters):
+        _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(of), _lib.ptr(oo), None,
+                                        V, 1, Cr, Dr, Dr, Dr, 128, 128, 64, 0.5, 2.0, h, h, h, st), "render")
+
+if "conv" in which:
+    D, Cc = 32, 128
+    M = D ** 3
+    x, hbuf, zbuf = torch.randn(M, Cc, device=dev), torch.randn(M, Cc, device=dev), torch.rand(M, Cc, device=dev)
+    o1, o2 = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+    wp = torch.randn(27, 256, 256, device=dev) * 0.01
+    bias = torch.zeros(256, device=dev)
+    for _ in range(iters):
+        co.conv_igemm(x, Cc, Cc, hbuf, Cc, Cc, wp, bias, None, None, 1.0, None, hbuf, None, o1, o2, (1, D, D, D), (D, D, D), 256, Cc,
+                      co.TAPS_3x3x3, epilogue=co.EPI_GRU_GATES)
+torch.cuda.synchronize()
+print("probe done")

@@ -89,6 +89,23 @@ def stage_timers(model):
     return rec, undo
 
 
+def pmc_traffic(prefix):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_summary.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of tools/probe_kernels.py, FETCH_SIZE doubled per MI355X_MICROARCH.md). PMC counters
+    cannot be read from inside this process; null when no summary is committed."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_corrected" in v:
+                return {"hbm_bytes_per_launch": v["hbm_bytes_corrected"], "algorithmic_bytes": v.get("algorithmic_bytes"),
+                        "launch": k, "source": os.path.basename(f)}
+    return None
+
+
 def time_kernel(fn, iters=20, warm=3):
     """Average duration (ms) of one launch of `fn`, HIP events on the current stream."""
     for _ in range(warm):
@@ -120,7 +137,7 @@ def kernel_rooflines(dev, B):
                                                                n, C, D, D, D, st), "rotate"))
     byts = n * C * D ** 3 * 4 * 2
     out["rotate_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("rotate_fwd_kernel")}
     # render: B volumes 64^3 x (16+1), V = 5 views each, 128^2 rays, 64 samples
     Dr, Cr, V = 64, 16, B * V_OUT
     feat, dens = syn.blob_volumes(B, Dr, Cr, seed=0)
@@ -141,7 +158,8 @@ def kernel_rooflines(dev, B):
     taps = V * 128 * 128 * 64 * 17 * 8
     out["render_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS,
-                                "gather_Gtaps_per_s": taps / ms / 1e6, "views_per_s_kernel_only": V / ms * 1e3}
+                                "gather_Gtaps_per_s": taps / ms / 1e6, "views_per_s_kernel_only": V / ms * 1e3,
+                                "traffic": pmc_traffic("render_fwd_kernel")}
     # dense stage: the fp32-MFMA implicit-GEMM conv at the three ConvGRU shapes (32^3 grid, 3x3x3 taps)
     from forge_amd import convops as co
     M, Cc = B * D ** 3, 128
@@ -282,7 +300,8 @@ def main():
         roofline = {"kernel": "conv_igemm_kernel<128> (fp32 MFMA implicit-GEMM conv, all %d launches of one step: conv1, fusion_conv x2, "
                               "ConvGRU gates/state x5)" % ck["launches_per_step"],
                     "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
-                    "traffic": None, "avg_launch_ms": ck["total_ms"] / ck["launches_per_step"], "gflop_per_step": ck["gflop"],
+                    "traffic": pmc_traffic("conv_igemm_kernel<128>"), "avg_launch_ms": ck["total_ms"] / ck["launches_per_step"],
+                    "gflop_per_step": ck["gflop"],
                     "share_of_step": ck["total_ms"] / (dt / args.steps * 1e3),
                     "note": "avg_launch_ms includes ~5 us of host launch gap per launch (HIP events around each call); "
                             "profiles/ holds the rocprofv3 kernel-trace average for the same kernel"}

@@ -148,7 +148,7 @@ def kernel_rooflines(dev, B):
     cam = torch.cat([extr[:, :3, :3].reshape(V_OUT, 9), extr[:, :3, 3], K[0, 0].expand(V_OUT, 1), K[1, 1].expand(V_OUT, 1),
                      K[0, 2].expand(V_OUT, 1), K[1, 2].expand(V_OUT, 1)], dim=1).repeat(B, 1).contiguous().to(dev)
     v2v = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(V_OUT).contiguous()
-    of = torch.empty(V, Cr, 128, 128, device=dev)
+    of = torch.empty(V, 128, 128, Cr, device=dev)
     oo = torch.empty(V, 128, 128, device=dev)
     h = 0.5 * (Dr - 1) / Dr
     ms = time_kernel(lambda: _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v),

@@ -38,24 +38,37 @@ def pad_cin(wp, cin_pad):
     return out
 
 
-def convT3d_k4s2p1_phases(w):
-    """nn.ConvTranspose3d(k=4, s=2, p=1) weight [Cin,Cout,4,4,4] -> 8 output-phase GEMMs.
-    Output o = 2 z + p gets, per axis, for p=0: (di=0,k=1), (di=-1,k=3); for p=1: (di=+1,k=0), (di=0,k=2).
-    Returns [(phase (pz,py,px), taps [(dz,dy,dx)]*8, wp [8][Cout][Cin])]."""
-    axis = {0: [(0, 1), (-1, 3)], 1: [(1, 0), (0, 2)]}
-    out = []
+def convT_phases(w, pad, nd):
+    """nn.ConvTranspose{2,3}d(stride=2, padding=pad) weight [Cin,Cout,k(,k),k] -> 2^nd output-phase GEMMs.
+    Per axis, output o = 2 z + ph receives in[z + d] * W[k] for every k with k = ph + pad (mod 2), d = (ph + pad - k) / 2
+    (from o = 2 i - pad + k). Returns [(phase (pz,py,px), taps [(dz,dy,dx)], wp [ntaps][Cout][Cin])]; 2-D uses pz = dz = 0."""
+    k = w.shape[-1]
+    per_axis = {ph: [((ph + pad - kk) // 2, kk) for kk in range(k) if (kk - ph - pad) % 2 == 0] for ph in (0, 1)}
     wd = w.detach()
-    for pz in (0, 1):
+    out = []
+    for pz in ((0, 1) if nd == 3 else (0,)):
         for py in (0, 1):
             for px in (0, 1):
                 taps, mats = [], []
-                for dz, kz in axis[pz]:
-                    for dy, ky in axis[py]:
-                        for dx, kx in axis[px]:
+                for dz, kz in (per_axis[pz] if nd == 3 else [(0, None)]):
+                    for dy, ky in per_axis[py]:
+                        for dx, kx in per_axis[px]:
                             taps.append((dz, dy, dx))
-                            mats.append(wd[:, :, kz, ky, kx].t())          # [Cout][Cin]
+                            mats.append((wd[:, :, kz, ky, kx] if nd == 3 else wd[:, :, ky, kx]).t())     # [Cout][Cin]
                 out.append(((pz, py, px), taps, torch.stack(mats).contiguous()))
     return out
+
+
+def convT3d_k4s2p1_phases(w):
+    """nn.ConvTranspose3d(k=4, s=2, p=1): 8 phases x 8 taps (per axis p=0: (d=0,k=1), (d=-1,k=3); p=1: (d=+1,k=0), (d=0,k=2))."""
+    return convT_phases(w, 1, 3)
+
+
+def pack_conv2d_weight(w):
+    """nn.Conv2d weight [Cout,Cin,kh,kw] (pad k//2) -> ([kh*kw][Cout][Cin], taps (0,dy,dx)) for a D=1 grid."""
+    co, ci, kh, kw = w.shape
+    taps = [(0, ky - kh // 2, kx - kw // 2) for ky in range(kh) for kx in range(kw)]
+    return w.detach().reshape(co, ci, kh * kw).permute(2, 0, 1).contiguous(), taps
 
 
 def bn_affine(bn):

@@ -36,6 +36,8 @@ enum ConvEpilogue : int {
     EPI_GRU_OUT = 3,     // cand = tanh(v); hn = h (1 - z) + cand z; out = hn; out2 (nullable) = hn * scale + shift
 };
 
+constexpr int MAX_TAPS = 64;
+
 struct ConvArgs {
     const float* in1; const float* in2;   // channel-concatenated inputs, channels-last; in2 nullable
     int C1, C2, ld1, ld2;                  // channels taken from each input and their row strides (floats)
@@ -53,7 +55,7 @@ struct ConvArgs {
     int ntaps;
     int os, pz, py, px, Do, Ho, Wo;        // output voxel = (z os + pz, y os + py, x os + px) in an (Do,Ho,Wo) grid
     int epi;
-    signed char tap[27][4];                // (dz, dy, dx, 0)
+    signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
 
 constexpr int BM = 128, BK = 32, NTHREADS = 512;
@@ -255,6 +257,155 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Narrow-N variant for Cout <= 16 (render-feature / density convs of the heads, conv_rgb): a 128-wide
+// N tile would waste >= 75 % of the matrix-core work, so this one uses v_mfma_f32_16x16x4_f32
+// (16 output channels per MFMA, same 64 FLOP/clk/SIMD), tile 256(M) x 16(N) x 16(K), 8 waves x 32 rows.
+// LDS images are [row][16 k] (64-byte rows); chunk c of row r is stored at c ^ g[(r>>2)&3], g = {0,3,2,1},
+// which makes the 16-lane groups of ds_read_b128 (rows r..r+15, chunk = lane>>4) conflict-free.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int BM16 = 256, BK16 = 16;
+
+__device__ __forceinline__ int lds_off16(int row, int chunk) {
+    return row * BK16 + ((chunk ^ ((4 - ((row >> 2) & 3)) & 3)) << 2);
+}
+
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs a) {
+    constexpr int A_FLOATS = BM16 * BK16, B_FLOATS = 16 * BK16;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)bid * BM16;
+    const int Cin = a.C1 + a.C2;
+    const int kchunks = Cin / BK16;
+    const int nsteps = a.ntaps * kchunks;
+
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
+
+    const int cp = tid & 3;                                      // physical chunk in the 64-byte LDS row
+    int ar[2], az[2], ay[2], ax[2], an[2], asrc[2];
+    bool aval[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        ar[j] = (tid >> 2) + 128 * j;
+        long long v = m0 + ar[j];
+        aval[j] = v < M;
+        v = aval[j] ? v : 0;
+        ax[j] = (int)(v % a.W) * a.is; v /= a.W;
+        ay[j] = (int)(v % a.H) * a.is; v /= a.H;
+        az[j] = (int)(v % a.D) * a.is; v /= a.D;
+        an[j] = (int)v;
+        asrc[j] = (cp ^ ((4 - ((ar[j] >> 2) & 3)) & 3)) << 2;
+    }
+    const int brow = tid >> 2;                                   // threads 0..63 stage the 16 x 16 weight tile
+    const unsigned boff = (tid < 64 && brow < a.Cout) ? (unsigned)((brow * Cin + ((cp ^ ((4 - ((brow >> 2) & 3)) & 3)) << 2)) * 4) : OOB;
+
+    int erow[2], erow2[2];
+    auto prep_tap = [&](int t) {
+        const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
+            const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+            const int sp = (zi * a.Hi + yi) * a.Wi + xi;
+            erow[j] = ok ? an[j] * (int)a.bs1r + sp : -1;
+            erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
+        }
+    };
+    float4 ra[2], rb;
+    auto load_step = [&](int t, int kc) {
+        const int c0 = kc * BK16;
+        if (c0 < a.C1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[j] = buf_load16(r1, erow[j] < 0 ? OOB : (unsigned)((erow[j] * a.ld1 + c0 + asrc[j]) * 4));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[j] = buf_load16(r2, erow2[j] < 0 ? OOB : (unsigned)((erow2[j] * a.ld2 + (c0 - a.C1) + asrc[j]) * 4));
+        }
+        rb = buf_load16(rw, boff == OOB ? OOB : boff + (unsigned)((t * a.Cout * Cin + c0) * 4));
+    };
+    auto store_step = [&](int buf) {
+        float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK16 + (cp << 2)) = ra[j];
+        if (tid < 64) *reinterpret_cast<float4*>(sa + A_FLOATS + brow * BK16 + (cp << 2)) = rb;
+    };
+
+    f32x4 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+
+    const int kq = lane >> 4, l15 = lane & 15;
+    int t = 0, kc = 0;
+    prep_tap(0);
+    load_step(0, 0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) {
+            if (++kc == kchunks) { kc = 0; ++t; prep_tap(t); }
+            load_step(t, kc);
+        }
+        const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+        const float* sb = sa + A_FLOATS;
+        const float4 fb = *reinterpret_cast<const float4*>(sb + lds_off16(l15, kq));
+        float4 fa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off16(wave * 32 + i * 16 + l15, kq));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (bias / folded-BN + LeakyReLU + residual only). 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+    const int col = l15;
+    if (col < a.Cout) {
+        const float bias = a.bias ? a.bias[col] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (a.epi == EPI_AFFINE_ACT) { sc = a.scale[col]; sh = a.shift[col]; }
+        const bool remap = (a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long m = m0 + wave * 32 + i * 16 + kq * 4 + r;
+                if (m < M) {
+                    long long orow = m;
+                    if (remap) {
+                        long long q = m;
+                        const int x = (int)(q % a.W); q /= a.W;
+                        const int y = (int)(q % a.H); q /= a.H;
+                        const int z = (int)(q % a.D); q /= a.D;
+                        orow = ((q * a.Do + (z * a.os + a.pz)) * a.Ho + (y * a.os + a.py)) * a.Wo + (x * a.os + a.px);
+                    }
+                    float v = acc[i][r] + bias;
+                    if (a.epi == EPI_AFFINE_ACT) {
+                        v = fmaf(v, sc, sh);
+                        if (a.residual) v += a.residual[orow * a.ldo + col];
+                        v = v > 0.f ? v : v * a.slope;
+                    }
+                    a.out[orow * a.ldo + col] = v;
+                }
+            }
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
@@ -268,10 +419,11 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
                                 int epilogue, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
-    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= 27, FORGE_EINVAL,
+    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
-    FORGE_REQUIRE(C1 > 0 && C1 % 32 == 0 && C2 >= 0 && C2 % 32 == 0, FORGE_ESHAPE,
-                  "forge_conv_igemm: C1=%d / C2=%d must be multiples of 32 (K-step)", C1, C2);
+    const int kstep = Cout <= 16 ? 16 : 32;
+    FORGE_REQUIRE(C1 > 0 && C1 % kstep == 0 && C2 >= 0 && C2 % kstep == 0, FORGE_ESHAPE,
+                  "forge_conv_igemm: C1=%d / C2=%d must be multiples of the K-step %d (16 for Cout <= 16, else 32)", C1, C2, kstep);
     FORGE_REQUIRE((C2 == 0) == (in2 == nullptr), FORGE_EINVAL, "forge_conv_igemm: in2/C2 mismatch");
     FORGE_REQUIRE(epilogue >= 0 && epilogue <= 3, FORGE_EINVAL, "forge_conv_igemm: unknown epilogue %d", epilogue);
     FORGE_REQUIRE(epilogue != EPI_AFFINE_ACT || (scale && shift), FORGE_EINVAL, "forge_conv_igemm: affine epilogue needs scale/shift");
@@ -289,14 +441,19 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                   "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
-    for (int t = 0; t < 27; ++t) {
+    for (int t = 0; t < MAX_TAPS; ++t) {
         for (int k = 0; k < 3; ++k) a.tap[t][k] = (signed char)(t < ntaps ? taps[t * 3 + k] : 0);
         a.tap[t][3] = 0;
     }
     const long long M = (long long)n * D * H * W;
     const long long mt = (M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
-    if (Cout > 64) {
+    if (Cout <= 16) {
+        FORGE_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT, FORGE_EINVAL, "forge_conv_igemm: GRU epilogues need Cout > 16");
+        const long long grid = (M + BM16 - 1) / BM16;
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
+        hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+    } else if (Cout > 64) {
         constexpr int BN = 128;
         const long long grid = mt * ((Cout + BN - 1) / BN);
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");

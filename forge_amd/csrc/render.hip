@@ -167,8 +167,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
         if (T == 0.f) break;                      // all later weights are exactly 0
     }
     const long long plane = (long long)Hr * Wr, pix = (long long)h * Wr + w;
-    float* of = out_feat + ((long long)v * (C4 * 4) + cg * 4) * plane + pix;
-    of[0] = acc.x; of[plane] = acc.y; of[2 * plane] = acc.z; of[3 * plane] = acc.w;
+    // channels-last feature map [V][Hr][Wr][C]: one 16-byte store per lane, what the conv_rgb GEMM consumes
+    reinterpret_cast<float4*>(out_feat)[((long long)v * plane + pix) * C4 + cg] = acc;
     if (cg == 0) {
         out_opac[(long long)v * plane + pix] = 1.f - T;
         if (out_depth) out_depth[(long long)v * plane + pix] = depth;
@@ -235,8 +235,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     float gop = 0.f, gdep = 0.f;
     if (inside) {
-        const float* gf = g_feat + ((long long)v * (C4 * 4) + cg * 4) * plane + pix;
-        g = make_float4(gf[0], gf[plane], gf[2 * plane], gf[3 * plane]);
+        g = reinterpret_cast<const float4*>(g_feat)[((long long)v * plane + pix) * C4 + cg];
         gop = g_opac[(long long)v * plane + pix];
         if (g_depth) gdep = g_depth[(long long)v * plane + pix];
     }

@@ -81,7 +81,7 @@ class _RenderRays(torch.autograd.Function):
         dens_c = dens.to(torch.float32).contiguous()
         cam_c = cam.detach().to(torch.float32).contiguous()
         V = cam_c.shape[0]
-        out_feat = torch.empty((V, C, Hr, Wr), dtype=torch.float32, device=feat.device)
+        out_feat = torch.empty((V, Hr, Wr, C), dtype=torch.float32, device=feat.device).permute(0, 3, 1, 2)   # NCHW view of NHWC memory
         out_opac = torch.empty((V, 1, Hr, Wr), dtype=torch.float32, device=feat.device)
         out_depth = torch.empty((V, 1, Hr, Wr), dtype=torch.float32, device=feat.device) if want_depth else None
         _lib.check(_lib.lib().forge_render_fwd(
@@ -104,7 +104,7 @@ class _RenderRays(torch.autograd.Function):
                                       "(pose-refinement row f2); detach the camera parameters")
         nvol, C, D, H, W = feat_cl.shape
         V = cam_c.shape[0]
-        g_feat = g_feat.contiguous()
+        g_feat = g_feat.contiguous(memory_format=torch.channels_last)      # [V,Hr,Wr,C] in memory
         g_opac = g_opac.contiguous()
         g_depth = g_depth.contiguous() if (want_depth and g_depth is not None) else None
         dfeat = _zeros_like_cl(feat_cl)

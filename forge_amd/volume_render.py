@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import convops as co, ops
+from .fusion import hip_inference
 
 
 class VolRender(nn.Module):
@@ -78,7 +79,7 @@ class VolRender(nn.Module):
         half = (0.5 * (W - 1) * vox, 0.5 * (H - 1) * vox, 0.5 * (D - 1) * vox)
         outs = ops.render_rays(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray,
                                self.min_depth, self.max_depth, half, want_depth=render_depth)
-        rendered_imgs = F.relu(self.conv_rgb(outs[0]))
+        rendered_imgs = self._conv_rgb_hip(outs[0]) if hip_inference(self, outs[0]) else F.relu(self.conv_rgb(outs[0]))
         rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
         result = [rendered_imgs, rendered_silhouettes]
         if render_depth:
@@ -86,6 +87,43 @@ class VolRender(nn.Module):
         if return_origin_proj:
             result.append(self._origin_proj(T, K))
         return tuple(result)
+
+    def _conv_rgb_hip(self, x):
+        """conv_rgb + ReLU (models/volume_render.py:29-37,73) on the MFMA GEMM kernel: ConvTranspose2d(16,16,k+1,s2,p) as 4
+        output-phase GEMMs + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
+        channels-last memory (what the ray-marcher writes) -> [V,3,2Hr,2Wr] (channels-last memory)."""
+        cr = self.conv_rgb
+        if not hasattr(self, "_rgb_cache"):
+            self._rgb_cache = co.PackCache()
+        src = [cr[0].weight, cr[0].bias, cr[3].weight, cr[3].bias, cr[6].weight, cr[6].bias] + \
+              [t for bn in (cr[1], cr[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+
+        def build():
+            w3, taps3 = co.pack_conv2d_weight(cr[3].weight)
+            w6, taps6 = co.pack_conv2d_weight(cr[6].weight)
+            return {"ct": co.convT_phases(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
+                    "w3": w3, "taps3": taps3, "b3": cr[3].bias.detach().contiguous(), "bn4": co.bn_affine(cr[4]),
+                    "w6": co.pad_cin(w6, 16), "taps6": taps6, "b6": cr[6].bias.detach().contiguous(),
+                    "one": torch.ones(3, device=x.device), "zero": torch.zeros(3, device=x.device)}
+        p = self._rgb_cache.get(src, build)
+        V, C, Hr, Wr = x.shape
+        xr = x.permute(0, 2, 3, 1)
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        H2, W2 = 2 * Hr, 2 * Wr
+        dev = x.device
+        up = torch.empty(V, H2, W2, 16, dtype=torch.float32, device=dev)
+        for (pz, py, px), taps, wp in p["ct"]:
+            co.conv_igemm(xr, C, C, None, 0, 0, wp, p["ct_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, up, None,
+                          (V, 1, Hr, Wr), (1, Hr, Wr), 16, 16, taps, out_grid=(1, H2, W2), ostride=2, phase=(0, py, px),
+                          epilogue=co.EPI_AFFINE_ACT)
+        g2, ig2 = (V, 1, H2, W2), (1, H2, W2)
+        mid = torch.zeros(V, H2, W2, 16, dtype=torch.float32, device=dev)             # 8 real channels + 8 zero (16-wide K-step)
+        co.conv_igemm(up, 16, 16, None, 0, 0, p["w3"], p["b3"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, mid, None,
+                      g2, ig2, 8, 16, p["taps3"], epilogue=co.EPI_AFFINE_ACT)
+        rgb = torch.empty(V, H2, W2, 3, dtype=torch.float32, device=dev)
+        co.conv_igemm(mid, 16, 16, None, 0, 0, p["w6"], p["b6"], p["one"], p["zero"], 0.0, None, None, None, rgb, None,
+                      g2, ig2, 3, 3, p["taps6"], epilogue=co.EPI_AFFINE_ACT)
+        return rgb.permute(0, 3, 1, 2)
 
     def proj_origin(self, camera_params, device):
         """models/volume_render.py:91-103"""

@@ -78,7 +78,7 @@ int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const
  *                                 of the HALF-resolution intrinsics (volume_render.py:50-51)
  *   view2vol [V]                  volume index rendered by each view (replaces the V-fold
  *                                 `repeat` of the volumes, models/model.py:138-139)
- *   out_feat [V][C][Hr][Wr]       sum_s w_s f_s           (NCHW, ready for conv_rgb)
+ *   out_feat [V][Hr][Wr][C]       sum_s w_s f_s           (channels-last, what the conv_rgb GEMM consumes)
  *   out_opac [V][Hr][Wr]          1 - prod_s (1 - d_s)
  *   out_depth[V][Hr][Wr]          sum_s w_s z_s, nullable (render_depth=False)
  * Ray (h,w): d_cam = ((w+.5-cx)/fx, (h+.5-cy)/fy, 1); p_s = -R^T T + R^T d_cam z_s,
@@ -91,7 +91,7 @@ int forge_render_fwd(const float* feat, const float* dens, const float* cam, con
                      forge_stream_t stream);
 
 /* Backward of forge_render_fwd w.r.t. volumes (and optionally cameras).
- *   g_feat [V][C][Hr][Wr], g_opac [V][Hr][Wr], g_depth [V][Hr][Wr] (nullable)
+ *   g_feat [V][Hr][Wr][C], g_opac [V][Hr][Wr], g_depth [V][Hr][Wr] (nullable)
  *   dfeat  [nvol][D][H][W][C], ddens [nvol][D][H][W]   MUST be zero-filled; scatter-added
  *   dcam   [V][16] nullable, MUST be zero-filled: d loss / d (R, T, fx, fy, cx, cy)
  */

@@ -387,3 +387,44 @@ def test_heads_and_conv1_hip_vs_golden(dev, golden):
     with torch.no_grad():
         got = enc._conv1_hip(x.to(dev)).cpu()
     assert (got - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 16), (16, 8), (16, 1), (48, 12)])
+def test_conv_igemm_narrow_n(dev, Cin, Cout):
+    """Cout <= 16 -> the v_mfma_f32_16x16x4_f32 variant (K-step 16)."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(2, Cin, 5, 9, 7, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b, sc, sh = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(x, w, b, padding=1) * sc[None, :, None, None, None]
+                                         + sh[None, :, None, None, None], 0.01)
+    out = torch.zeros(2, 5, 9, 7, 16, device=dev)                      # row stride 16 > Cout: padded output
+    co.conv_igemm(_rows(x).to(dev), Cin, Cin, None, 0, 0, co.pack_conv3d_weight(w).to(dev), b.to(dev), sc.to(dev), sh.to(dev), 0.01,
+                  None, None, None, out, None, (2, 5, 9, 7), (5, 9, 7), Cout, 16, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+    got = out[..., :Cout].permute(0, 4, 1, 2, 3).cpu()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    assert out[..., Cout:].abs().max().item() == 0.0 if Cout < 16 else True
+
+
+def test_conv_igemm_2d_5x5_and_transpose2d(dev):
+    """the conv_rgb shapes: 25-tap 5x5 conv and ConvTranspose2d(k6,s2,p2) as 4 phase GEMMs of 9 taps."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 16, 11, 13, generator=g)
+    w = torch.randn(8, 16, 5, 5, generator=g) / 20
+    b = torch.randn(8, generator=g)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=2)
+    wp, taps = co.pack_conv2d_weight(w)
+    out = torch.empty(2, 11, 13, 8, device=dev)
+    co.conv_igemm(x.permute(0, 2, 3, 1).contiguous().to(dev), 16, 16, None, 0, 0, wp.to(dev), b.to(dev), None, None, 1.0, None, None, None,
+                  out, None, (2, 1, 11, 13), (1, 11, 13), 8, 8, taps, epilogue=co.EPI_BIAS)
+    assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+    wt = torch.randn(16, 16, 6, 6, generator=g) / 24
+    ref = torch.nn.functional.conv_transpose2d(x, wt, b.repeat(2), stride=2, padding=2)
+    out = torch.empty(2, 22, 26, 16, device=dev)
+    for (pz, py, px), tp, wpp in co.convT_phases(wt, 2, 2):
+        co.conv_igemm(x.permute(0, 2, 3, 1).contiguous().to(dev), 16, 16, None, 0, 0, wpp.to(dev), b.repeat(2).to(dev), None, None, 1.0,
+                      None, None, None, out, None, (2, 1, 11, 13), (1, 11, 13), 16, 16, tp, out_grid=(1, 22, 26), ostride=2,
+                      phase=(0, py, px), epilogue=co.EPI_BIAS)
+    assert (out.permute(0, 3, 1, 2).cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()

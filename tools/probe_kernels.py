@@ -37,7 +37,7 @@ if "render" in which:
     cam = torch.cat([extr[:, :3, :3].reshape(V, 9), extr[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1),
                      K[0, 2].expand(V, 1), K[1, 2].expand(V, 1)], dim=1).contiguous().to(dev)
     v2v = torch.zeros(V, dtype=torch.int32, device=dev)
-    of, oo = torch.empty(V, Cr, 128, 128, device=dev), torch.empty(V, 128, 128, device=dev)
+    of, oo = torch.empty(V, 128, 128, Cr, device=dev), torch.empty(V, 128, 128, device=dev)
     h = 0.5 * (Dr - 1) / Dr
     for _ in range(iters):
         _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(of), _lib.ptr(oo), None,

@@ -69,7 +69,7 @@ def stage_timers(model):
     wrap(e3, "get_density3D", "heads_density(+shared convT)")
     wrap(e3, "get_render_features", "heads_features")
     wrap(model.render, "forward", "render_total")
-    wrap(model.render.conv_rgb, "forward", "conv_rgb")
+    wrap(model.render, "_conv_rgb_hip", "conv_rgb")
     # every forge_conv_igemm launch: events + algorithmic FLOPs, keyed by kernel instantiation
     from forge_amd import convops as co, encoder as enc_mod, fusion as fus_mod
     orig = co.conv_igemm
@@ -81,7 +81,7 @@ def stage_timers(model):
         out = orig(in1, C1, ld1, in2, C2, ld2, wp, *a, **kw)
         e1.record()
         M = grid[0] * grid[1] * grid[2] * grid[3]
-        key = "conv_igemm_kernel<%d>" % (128 if Cout > 64 else 64)
+        key = "conv_igemm_n16_kernel" if Cout <= 16 else "conv_igemm_kernel<%d>" % (128 if Cout > 64 else 64)
         rec.setdefault(key, []).append((e0, e1, 2.0 * M * Cout * len(taps) * (C1 + C2)))
         return out
     co.conv_igemm = conv_timed
@@ -287,8 +287,8 @@ def main():
                        "gflop": sum(x[2] for x in v) / 1e9} for k, v in conv_rec.items()}
     for u in undo:
         u()
-    stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages["encoder_resnet"]
-    stages["render_march(+cam pack)"] = stages.pop("render_total") - stages["conv_rgb"]
+    stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages.get("encoder_resnet", 0.0)
+    stages["render_march(+cam pack)"] = stages.pop("render_total") - stages.get("conv_rgb", 0.0)
 
     result = None
     if rank == 0:

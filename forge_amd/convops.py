@@ -95,7 +95,7 @@ class PackCache:
 
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
-               bs1=0, bs2=0):
+               bs1=0, bs2=0, lift=0):
     """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid)."""
     n, D, H, W = grid
     Di, Hi, Wi = in_grid
@@ -106,5 +106,5 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
     _lib.check(_lib.lib().forge_conv_igemm(
         p(in1), C1, ld1, int(bs1), p(in2), C2, ld2, int(bs2), p(wp), p(bias), p(scale), p(shift), float(slope), p(residual), p(aux_h), p(aux_z),
         p(out), p(out2), n, D, H, W, istride, Di, Hi, Wi, Cout, ldo, _taps_array(taps), len(taps), ostride,
-        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, _lib.current_stream()), "forge_conv_igemm")
+        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.current_stream()), "forge_conv_igemm")
     return out

@@ -23,6 +23,7 @@
 // The K order inside a 32-chunk is permuted identically for A and B: a lane's 16-byte read
 // supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of MFMA j.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace forge {
@@ -50,15 +51,16 @@ struct ConvArgs {
     float* out; float* out2;
     int n, D, H, W;                        // GEMM-row grid (M = n D H W rows)
     int is, Di, Hi, Wi;                    // input voxel = (z is + dz, y is + dy, x is + dx) in an (n,Di,Hi,Wi) grid
-    const float* residual;                 // EPI_AFFINE_ACT: added before the activation (nullable), [rows][ldo]
+    const float* residual; int ldr;        // EPI_AFFINE_ACT: added before the activation (nullable), [rows][ldr]
     int Cout, ldo;                         // output channels, output row stride (floats)
     int ntaps;
     int os, pz, py, px, Do, Ho, Wo;        // output voxel = (z os + pz, y os + py, x os + px) in an (Do,Ho,Wo) grid
     int epi;
+    int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
 
-constexpr int BM = 128, BK = 32, NTHREADS = 512;
+constexpr int BK = 32, NTHREADS = 512;
 
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
 constexpr unsigned OOB = 0x80000000u;      // byte offset beyond any buffer (< 2 GiB spans enforced on the host side)
@@ -76,15 +78,17 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BN>
+template <int BM, int BN>
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int NT = BN / 64;                     // 32-col MFMA tiles per wave (8 waves as 4(M) x 2(N); wave tile 32 x BN/2)
+    constexpr int WM = BM / 32, WN = 8 / WM;        // 8 waves as WM(M) x WN(N); wave tile 32 x (BN / WN)
+    constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
+    static_assert(NT >= 1 && WM * WN == 8, "unsupported tile");
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
-    constexpr int ACH = 2, BCH = BN / 64;           // 16-byte chunks per thread per K-step
+    constexpr int ACH = BM / 64, BCH = BN / 64;     // 16-byte chunks per thread per K-step
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int ntile_n = (a.Cout + BN - 1) / BN;
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
             const float4 fa = *reinterpret_cast<const float4*>(sa + lds_off(wm * 32 + l31, 2 * g + half));
             float4 fb[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / 2) + j * 32 + l31, 2 * g + half));
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / WN) + j * 32 + l31, 2 * g + half));
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
 #pragma unroll
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
         constexpr int EPI = decltype(EPI_TAG)::value;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + l31;
+            const int col = n0 + wn * (BN / WN) + j * 32 + l31;
             const bool cok = col < a.Cout;
             const int colc = cok ? col : 0;
             const float bias = a.bias ? a.bias[colc] : 0.f;
@@ -231,8 +235,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
                             a.out[orow * a.ldo + col] = v;
                         } else if constexpr (EPI == EPI_AFFINE_ACT) {
                             v = fmaf(v, sc, sh);
-                            if (a.residual) v += a.residual[orow * a.ldo + col];
-                            a.out[orow * a.ldo + col] = v > 0.f ? v : v * a.slope;
+                            if (a.residual) v += a.residual[orow * a.ldr + col];
+                            v = v > 0.f ? v : v * a.slope;
+                            if (a.lift > 0) {
+                                // columns are (z, c) with c fastest: row (n, hw), col z*Cl + c  ->  out[n][z][hw][c]
+                                const int Cl = a.Cout / a.lift, zc = col / Cl, cc = col - zc * Cl;
+                                const long long HW = (long long)a.H * a.W, nn = m / HW, hw = m - nn * HW;
+                                a.out[((nn * a.lift + zc) * HW + hw) * Cl + cc] = v;
+                            } else {
+                                a.out[orow * a.ldo + col] = v;
+                            }
                         } else if constexpr (EPI == EPI_GRU_GATES) {
                             const float g = 1.f / (1.f + __expf(-v));
                             if (col < Ch) a.out[orow * Ch + col] = g;
@@ -397,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
                     float v = acc[i][r] + bias;
                     if (a.epi == EPI_AFFINE_ACT) {
                         v = fmaf(v, sc, sh);
-                        if (a.residual) v += a.residual[orow * a.ldo + col];
+                        if (a.residual) v += a.residual[orow * a.ldr + col];
                         v = v > 0.f ? v : v * a.slope;
                     }
                     a.out[orow * a.ldo + col] = v;
@@ -417,7 +429,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const float* aux_h, const float* aux_z, float* out, float* out2,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, forge_stream_t stream) {
+                                int epilogue, int lift, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
@@ -431,6 +443,8 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     FORGE_REQUIRE(epilogue != EPI_GRU_OUT || (aux_h && aux_z), FORGE_EINVAL, "forge_conv_igemm: GRU out epilogue needs aux_h, aux_z");
     FORGE_REQUIRE(os >= 1 && Do > 0 && Ho > 0 && Wo > 0, FORGE_EINVAL, "forge_conv_igemm: bad output mapping");
     FORGE_REQUIRE(is >= 1 && Di > 0 && Hi > 0 && Wi > 0, FORGE_EINVAL, "forge_conv_igemm: bad input mapping");
+    FORGE_REQUIRE(lift == 0 || (lift > 0 && epilogue == EPI_AFFINE_ACT && Cout % lift == 0 && D == 1 && os == 1 && Cout > 64), FORGE_EINVAL,
+                  "forge_conv_igemm: lift needs the affine epilogue on a 2-D (D=1) conv with Cout %% lift == 0 and Cout > 64");
     FORGE_REQUIRE(ld1 >= C1 && ld1 % 4 == 0 && (C2 == 0 || (ld2 >= C2 && ld2 % 4 == 0)) && ldo >= 1, FORGE_EINVAL,
                   "forge_conv_igemm: row strides must cover the channels and keep 16-byte alignment");
     ConvArgs a;
@@ -438,7 +452,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
     a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
-                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     for (int t = 0; t < MAX_TAPS; ++t) {
@@ -446,7 +460,6 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         a.tap[t][3] = 0;
     }
     const long long M = (long long)n * D * H * W;
-    const long long mt = (M + BM - 1) / BM;
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 16) {
         FORGE_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT, FORGE_EINVAL, "forge_conv_igemm: GRU epilogues need Cout > 16");
@@ -455,17 +468,27 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
     } else if (Cout > 64) {
         constexpr int BN = 128;
-        const long long grid = mt * ((Cout + BN - 1) / BN);
-        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-        const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
-        (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+        const long long nt = (Cout + BN - 1) / BN;
+        // small problems: 64-row tiles double the workgroup count (the chip wants >= 2 workgroups per CU)
+        const char* force = getenv("FORGE_CONV_BM");
+        const bool bm64 = force ? (atoi(force) == 64) : (((M + 127) / 128) * nt < 512);
+        const size_t lds = 2 * ((bm64 ? 64 : 128) * BK + BN * BK) * sizeof(float);
+        if (bm64) {
+            const long long grid = ((M + 63) / 64) * nt;
+            FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
+            hipLaunchKernelGGL((conv_igemm_kernel<64, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+        } else {
+            const long long grid = ((M + 127) / 128) * nt;
+            FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
+            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((conv_igemm_kernel<128, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+        }
     } else {
         constexpr int BN = 64;
-        const long long grid = mt * ((Cout + BN - 1) / BN);
+        const long long grid = ((M + 127) / 128) * ((Cout + BN - 1) / BN);
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-        const size_t lds = 2 * (BM * BK + BN * BK) * sizeof(float);
-        hipLaunchKernelGGL(conv_igemm_kernel<BN>, dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+        const size_t lds = 2 * (128 * BK + BN * BK) * sizeof(float);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

@@ -105,11 +105,11 @@ class Encoder3D(nn.Module):
     def get_feat3D(self, img):
         """[N,3,H,W] -> [N,128,32,H/8,W/8]; the 2048 trunk channels are re-read as 64 ch x 32 depth
         (channel c = c3d*32 + z, models/encoder.py:49)."""
+        if hip_inference(self, img):
+            return self._conv1_hip(self._trunk_hip(img))
         z_2d = self.feature_extraction(img)
         B, C, H, W = z_2d.shape
         z_3d = z_2d.view(-1, 64, 32, H, W)
-        if hip_inference(self, z_3d):
-            return self._conv1_hip(z_3d)
         return self.conv1(z_3d)
 
     def get_density3D(self, z_3d):
@@ -135,18 +135,96 @@ class Encoder3D(nn.Module):
         r = x.permute(0, 2, 3, 4, 1)
         return r if r.is_contiguous() else r.contiguous()
 
-    def _conv1_hip(self, z_3d):
-        """conv1 = Conv3d(64,128,3,p1)+BN+LeakyReLU as one GEMM (models/encoder.py:36-40)."""
+    LIFT_Z, LIFT_C = 32, 64          # z_2d.view(-1, 64, 32, H, W): trunk channel c = c3d*32 + z (models/encoder.py:49)
+
+    def _trunk_packed(self):
+        """Packed weights of ResNet layers 1-4 for the GEMM kernel. The 2048-wide residual stream of layer4 is kept in
+        the permuted channel order j = z*64 + c3d (original channel c3d*32 + z): a pure relabelling (applied to Cout of
+        layer4's conv3/downsample and to Cin of the following conv1) that lets the last GEMM store the lifted
+        [N,32,H,W,64] volume with contiguous 256-byte segments."""
+        fe = self.feature_extraction
+        if not hasattr(self, "_trunk_cache"):
+            self._trunk_cache = co.PackCache()
+        src = [t for li in (4, 5, 6, 7) for blk in fe[li] for t in list(blk.parameters()) + list(blk.buffers())]
+
+        def build():
+            dev = fe[0].weight.device
+            j = torch.arange(self.LIFT_Z * self.LIFT_C, device=dev)
+            perm = (j % self.LIFT_C) * self.LIFT_Z + j // self.LIFT_C
+            blocks = []
+            for li in (4, 5, 6, 7):
+                for bi, blk in enumerate(fe[li]):
+                    pin = perm if (li == 7 and bi > 0) else None          # block input already in permuted order
+                    pout = perm if li == 7 else None
+                    w1 = blk.conv1.weight.detach()[:, :, 0, 0]
+                    if pin is not None:
+                        w1 = w1[:, pin]
+                    w2, taps2 = co.pack_conv2d_weight(blk.conv2.weight)
+                    w3 = blk.conv3.weight.detach()[:, :, 0, 0]
+                    a3 = co.bn_affine(blk.bn3)
+                    if pout is not None:
+                        w3, a3 = w3[pout], (a3[0][pout].contiguous(), a3[1][pout].contiguous())
+                    d = {"w1": w1[None].contiguous(), "a1": co.bn_affine(blk.bn1), "w2": w2, "taps2": taps2, "a2": co.bn_affine(blk.bn2),
+                         "stride": blk.conv2.stride[0], "w3": w3[None].contiguous(), "a3": a3, "planes": w1.shape[0], "ds": None}
+                    if blk.downsample is not None:
+                        wd = blk.downsample[0].weight.detach()[:, :, 0, 0]
+                        ad = co.bn_affine(blk.downsample[1])
+                        if pout is not None:
+                            wd, ad = wd[pout], (ad[0][pout].contiguous(), ad[1][pout].contiguous())
+                        d["ds"] = (wd[None].contiguous(), ad, blk.downsample[0].stride[0])
+                    blocks.append(d)
+            return blocks
+        return self._trunk_cache.get(src, build)
+
+    def _trunk_hip(self, img):
+        """ResNet-50 layers 1-4 as im2col-free implicit GEMMs on the fp32 matrix cores (1x1 = plain GEMM, 3x3 = 9 taps,
+        strides via the input-stride argument), BN folded, ReLU and the residual add in the epilogue, activations NHWC.
+        The stem (7x7 s2 conv + BN + ReLU + max-pool, 2.4 % of the trunk FLOPs) still runs through PyTorch-ROCm.
+        img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1)."""
+        fe = self.feature_extraction
+        x = fe[3](fe[2](fe[1](fe[0](img))))
+        N, C, H, W = x.shape
+        xr = x.permute(0, 2, 3, 1).contiguous()                                    # NHWC rows
+        blocks = self._trunk_packed()
+        dev = img.device
+        T1 = [(0, 0, 0)]
+        for bi, b in enumerate(blocks):
+            last = bi == len(blocks) - 1
+            Cin, P, s = xr.shape[-1], b["planes"], b["stride"]
+            Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+            y1 = torch.empty(N, H, W, P, dtype=torch.float32, device=dev)
+            co.conv_igemm(xr, Cin, Cin, None, 0, 0, b["w1"], None, b["a1"][0], b["a1"][1], 0.0, None, None, None, y1, None,
+                          (N, 1, H, W), (1, H, W), P, P, T1, epilogue=co.EPI_AFFINE_ACT)
+            y2 = torch.empty(N, Ho, Wo, P, dtype=torch.float32, device=dev)
+            co.conv_igemm(y1, P, P, None, 0, 0, b["w2"], None, b["a2"][0], b["a2"][1], 0.0, None, None, None, y2, None,
+                          (N, 1, Ho, Wo), (1, H, W), P, P, b["taps2"], istride=s, epilogue=co.EPI_AFFINE_ACT)
+            if b["ds"] is not None:
+                wd, ad, sd = b["ds"]
+                idn = torch.empty(N, Ho, Wo, 4 * P, dtype=torch.float32, device=dev)
+                co.conv_igemm(xr, Cin, Cin, None, 0, 0, wd, None, ad[0], ad[1], 1.0, None, None, None, idn, None,
+                              (N, 1, Ho, Wo), (1, H, W), 4 * P, 4 * P, T1, istride=sd, epilogue=co.EPI_AFFINE_ACT)
+            else:
+                idn = xr
+            if last:
+                out = torch.empty(N, self.LIFT_Z, Ho, Wo, self.LIFT_C, dtype=torch.float32, device=dev)
+            else:
+                out = torch.empty(N, Ho, Wo, 4 * P, dtype=torch.float32, device=dev)
+            co.conv_igemm(y2, P, P, None, 0, 0, b["w3"], None, b["a3"][0], b["a3"][1], 0.0, idn, None, None, out, None,
+                          (N, 1, Ho, Wo), (1, Ho, Wo), 4 * P, 4 * P, T1, epilogue=co.EPI_AFFINE_ACT, lift=self.LIFT_Z if last else 0)
+            xr, H, W = out, Ho, Wo
+        return xr
+
+    def _conv1_hip(self, vol_rows):
+        """conv1 = Conv3d(64,128,3,p1)+BN+LeakyReLU as one GEMM (models/encoder.py:36-40). vol_rows [N,D,H,W,64]."""
         conv, bn = self.conv1[0], self.conv1[1]
         if not hasattr(self, "_c1_cache"):
             self._c1_cache = co.PackCache()
         w, bias, sc, sh = self._c1_cache.get(
             [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var],
             lambda: (co.pack_conv3d_weight(conv.weight), conv.bias.detach().contiguous()) + co.bn_affine(bn))
-        n, C, D, H, W = z_3d.shape
-        xr = self._rows(z_3d)
-        out = torch.empty(n, D, H, W, 128, dtype=torch.float32, device=z_3d.device)
-        co.conv_igemm(xr, C, C, None, 0, 0, w, bias, sc, sh, 0.01, None, None, None, out, None,
+        n, D, H, W, C = vol_rows.shape
+        out = torch.empty(n, D, H, W, 128, dtype=torch.float32, device=vol_rows.device)
+        co.conv_igemm(vol_rows, C, C, None, 0, 0, w, bias, sc, sh, 0.01, None, None, None, out, None,
                       (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
         return out.permute(0, 4, 1, 2, 3)
 

@@ -129,6 +129,9 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *            3  GRU state: hn = aux_h (1 - aux_z) + tanh(v) aux_z; out = hn;
  *                          out2 (nullable) = hn * scale + shift          (fusion_norm on the last step)
  * bias/scale/shift [Cout]; bias nullable.
+ *   lift > 0 (epilogue 1, 2-D conv i.e. D = 1): fuses the 2D->3D feature lift of models/encoder.py:49 into the store —
+ *            GEMM column j = z*(Cout/lift) + c of row (n, h, w) is written to out[n][z][h][w][c] (a channels-last
+ *            (n, lift, H, W) volume with Cout/lift channels). The caller orders the weight rows accordingly.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
                      const float* wp,
@@ -136,7 +139,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const float* aux_h, const float* aux_z, float* out, float* out2,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, forge_stream_t stream);
+                     int epilogue, int lift, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.

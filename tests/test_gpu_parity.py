@@ -385,8 +385,29 @@ def test_heads_and_conv1_hip_vs_golden(dev, golden):
     ref = torch.nn.functional.leaky_relu(fo._bn(torch.nn.functional.conv3d(x, w["encoder_3d.conv1.0.weight"], w["encoder_3d.conv1.0.bias"], padding=1),
                                                 w, "encoder_3d.conv1.1"), 0.01)
     with torch.no_grad():
-        got = enc._conv1_hip(x.to(dev)).cpu()
+        got = enc._conv1_hip(x.permute(0, 2, 3, 4, 1).contiguous().to(dev)).cpu()
     assert (got - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_encoder_trunk_hip_vs_oracle(dev):
+    """ResNet-50 layers 1-4 on the GEMM kernel + fused 2D->3D lift + conv1 vs the oracle's get_feat3D
+    (tolerance: 53 conv layers deep, activations O(1..25))."""
+    from forge_amd.encoder import Encoder3D
+    enc = Encoder3D(syn.kubric_config())
+    w = syn.seeded_state_dict({"encoder_3d." + k: v for k, v in enc.state_dict().items()}, 0)
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()})
+    enc = enc.to(dev).eval()
+    img = torch.rand(2, 3, 128, 96, generator=torch.Generator().manual_seed(21))       # non-square, small
+    ref = fo.get_feat3D(img, w)
+    with torch.no_grad():
+        got = enc.get_feat3D(img.to(dev)).cpu()
+        z2d = enc.feature_extraction(img.to(dev))                                       # stock trunk, same device
+        lifted = enc._trunk_hip(img.to(dev))
+    assert got.shape == ref.shape == (2, 128, 32, 16, 12)
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    # the fused lift equals view(-1,64,32,H,W) of the stock trunk output
+    ref_l = z2d.view(-1, 64, 32, 16, 12).permute(0, 2, 3, 4, 1)
+    assert (lifted - ref_l).abs().max().item() < 2e-4 * max(1.0, ref_l.abs().max().item())
 
 
 @pytest.mark.parametrize("Cin,Cout", [(32, 16), (16, 8), (16, 1), (48, 12)])

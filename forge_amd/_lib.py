@@ -22,6 +22,7 @@ SIGNATURES = {
     "forge_version": [],
     "forge_last_error": [],
     "forge_rotate_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_rotate_xf_from_poses": [_P, _P, _P, _I, _I, _F, _P],
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],

@@ -189,6 +189,48 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
     }
 }
 
+// poses [B][t][16] row-major camera poses -> xf [B*t][12], mode [B*t]: T = P_0 P_i^-1 (models/rotate.py:64-89, general
+// 4x4 inverse by cofactors — the reference calls torch.inverse), xf = [R_T | t_T / e] (rotate.py:132-135). One thread per view.
+__global__ void pose_xf_kernel(const float* __restrict__ poses, float* __restrict__ xf, int* __restrict__ mode, int B, int t, float e) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * t) return;
+    const int v = i % t;
+    float* o = xf + i * 12;
+    mode[i] = v == 0 ? 0 : 1;
+    if (v == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = 0.f;
+        return;
+    }
+    const float* m = poses + (long long)i * 16;
+    const float* p0 = poses + (long long)(i - v) * 16;
+    float inv[16];
+    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const float s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const float c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+    const float id = 1.f / det;
+    inv[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;   inv[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+    inv[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id; inv[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+    inv[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;  inv[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+    inv[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id; inv[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+    inv[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;   inv[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+    inv[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id; inv[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+    inv[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id; inv[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+    inv[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id; inv[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fmaf(p0[r * 4 + k], inv[k * 4 + c], acc);
+            o[r * 4 + c] = c == 3 ? acc / e : acc;
+        }
+    }
+}
+
 static int check_rotate_args(const void* a, const void* b, const void* c, const void* d, int n, int C, int D, int H, int W) {
     FORGE_REQUIRE(a && b && c && d, FORGE_EINVAL, "forge_rotate: null pointer argument");
     FORGE_REQUIRE(n > 0 && C > 0 && D > 1 && H > 1 && W > 1, FORGE_EINVAL,
@@ -211,6 +253,16 @@ extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mo
     hipLaunchKernelGGL(rotate_fwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_fwd");
+    return 0;
+}
+
+extern "C" int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, int t, float half_extent,
+                                         forge_stream_t stream) {
+    FORGE_REQUIRE(poses && xf && mode, FORGE_EINVAL, "forge_rotate_xf_from_poses: null pointer argument");
+    FORGE_REQUIRE(B > 0 && t > 0 && half_extent > 0.f, FORGE_EINVAL, "forge_rotate_xf_from_poses: bad B=%d t=%d e=%g", B, t, half_extent);
+    const int n = B * t;
+    hipLaunchKernelGGL(pose_xf_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, xf, mode, B, t, half_extent);
+    FORGE_LAUNCH_CHECK("forge_rotate_xf_from_poses");
     return 0;
 }
 

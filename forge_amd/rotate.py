@@ -51,8 +51,19 @@ class Rotate_world(nn.Module):
             raise ValueError("Rotate_world: voxels %s do not match grid_size=%d" % ((D, H, W), grid_size))
         device = voxels.device
         e = self.half_extent(grid_size)
+        poses = camPoses_cv2.to(device=device, dtype=torch.float32)
+        if not (torch.is_grad_enabled() and poses.requires_grad):
+            # no gradient to the poses: T = P_0 P_i^-1 and the affine packing run in one tiny kernel (no torch.inverse,
+            # whose LU + info check costs more host time than the whole warp)
+            from . import _lib
+            xf = torch.empty(B * t, 12, dtype=torch.float32, device=device)
+            mode = torch.empty(B * t, dtype=torch.int32, device=device)
+            _lib.check(_lib.lib().forge_rotate_xf_from_poses(_lib.ptr(poses.contiguous()), _lib.ptr(xf), _lib.ptr(mode), B, t, e,
+                                                             _lib.current_stream()), "forge_rotate_xf_from_poses")
+            out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode)
+            return out.reshape(B, t, C, D, H, W)
         if t > 1:
-            T = self.get_transformation(camPoses_cv2.to(device=device, dtype=torch.float32))   # [B(t-1),4,4]
+            T = self.get_transformation(poses)                                                  # [B(t-1),4,4]
             xf_w = torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(B, t - 1, 12)
             ident = torch.zeros(B, 1, 12, dtype=torch.float32, device=device)
             xf = torch.cat([ident, xf_w], dim=1).reshape(B * t, 12)

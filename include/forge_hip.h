@@ -55,6 +55,14 @@ const char* forge_last_error(void);
 int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
                      int n, int C, int D, int H, int W, forge_stream_t stream);
 
+/* models/rotate.py:64-89,132-135 on the device: poses [B][t][4][4] (row-major camera poses, view 0 = reference) ->
+ * xf [B*t][12] = [R_T | t_T / half_extent] with T = P_0 P_i^-1 (general 4x4 inverse), mode [B*t] = (0,1,1,...).
+ * Feeds forge_rotate_fwd without any host round trip. (Gradients w.r.t. poses go through the host-side torch
+ * algebra instead, see forge_amd/rotate.py.)
+ */
+int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, int t, float half_extent,
+                               forge_stream_t stream);
+
 /* Backward of forge_rotate_fwd w.r.t. the volumes (and optionally the affine).
  *   dout [n][D][H][W][C]   upstream gradient
  *   dvox [n][D][H][W][C]   MUST be zero-filled by the caller; receives scatter-added gradients

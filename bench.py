@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step (BASELINE config 2: 1)")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
     args = ap.parse_args()
@@ -262,9 +263,16 @@ def main():
     sample = {k: v.to(dev) for k, v in sample_cpu.items()}      # inputs resident in HBM
     dataset = syn.SyntheticDataset(1.5)
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             return model(sample, dataset, dev)
+
+    if args.no_graph:
+        step = eager_step
+    else:
+        from forge_amd.graph import GraphedForward
+        graphed = GraphedForward(model, sample, dataset, dev)      # hipGraph of the whole step; replays do all the work
+        step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the static buffers)
 
     for _ in range(args.warmup):
         out = step()
@@ -285,7 +293,7 @@ def main():
     rec, undo = stage_timers(model)
     for _ in range(3):
         rec.clear()
-        step()
+        eager_step()
     torch.cuda.synchronize()
     conv_rec = {k: rec.pop(k) for k in list(rec) if k.startswith("conv_igemm")}
     stages = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in rec.items()}
@@ -321,7 +329,7 @@ def main():
                                    "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
                                    "fp32-MFMA implicit-GEMM conv1/ConvGRU/heads, HIP ray-march; ResNet-50 trunk + conv_rgb via PyTorch-ROCm/MIOpen; "
                                    "eval BN, random-init seeded weights" % B,
-                       "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
+                       "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
             "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "gflop_per_step_algorithmic": B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB),
         }

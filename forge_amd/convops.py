@@ -13,9 +13,16 @@ from . import _lib
 EPI_BIAS, EPI_AFFINE_ACT, EPI_GRU_GATES, EPI_GRU_OUT = 0, 1, 2, 3
 
 
+_TAPS_CACHE = {}
+
+
 def _taps_array(taps):
-    flat = [int(v) for t in taps for v in t]
-    return (ctypes.c_int * len(flat))(*flat)
+    key = tuple(tuple(t) for t in taps)
+    arr = _TAPS_CACHE.get(key)
+    if arr is None:
+        flat = [int(v) for t in key for v in t]
+        arr = _TAPS_CACHE[key] = (ctypes.c_int * len(flat))(*flat)
+    return arr
 
 
 TAPS_3x3x3 = [(kz - 1, ky - 1, kx - 1) for kz in range(3) for ky in range(3) for kx in range(3)]

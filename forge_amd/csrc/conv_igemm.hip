@@ -480,7 +480,8 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         } else {
             const long long grid = ((M + 127) / 128) * nt;
             FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-            (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<128, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<128, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)attr_once;   // set once per process: safe under stream capture
             hipLaunchKernelGGL((conv_igemm_kernel<128, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
         }
     } else {

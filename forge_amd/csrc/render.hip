@@ -81,6 +81,8 @@ struct Taps {
     long long i000;                 // voxel index of the clamped (z0,y0,x0) tap
     int ox, oy, oz;                 // voxel-index offsets to the +x/+y/+z taps (0 when clamped)
     float w[8];                     // trilinear weights, 0 for out-of-range taps
+    float ax[2], ay[2], az[2];      // per-axis weights (0 when that index is out of range)
+    float bx[2], by[2], bz[2];      // d(axis weight)/d(pixel coord): -1 / +1 for in-range indices, else 0
     bool any;
 };
 
@@ -103,6 +105,10 @@ __device__ __forceinline__ void taps_ac_true(float px, float py, float pz, int W
     const int za = min(max(z0, 0), D - 1), zb = min(max(z0 + 1, 0), D - 1);
     t.i000 = ((long long)za * H + ya) * W + xa;
     t.ox = xb - xa; t.oy = (yb - ya) * W; t.oz = (zb - za) * H * W;
+    t.ax[0] = wxa; t.ax[1] = wxb; t.ay[0] = wya; t.ay[1] = wyb; t.az[0] = wza; t.az[1] = wzb;
+    t.bx[0] = vx0 ? -1.f : 0.f; t.bx[1] = vx1 ? 1.f : 0.f;
+    t.by[0] = vy0 ? -1.f : 0.f; t.by[1] = vy1 ? 1.f : 0.f;
+    t.bz[0] = vz0 ? -1.f : 0.f; t.bz[1] = vz1 ? 1.f : 0.f;
     t.w[0] = wxa * wya * wza; t.w[1] = wxb * wya * wza; t.w[2] = wxa * wyb * wza; t.w[3] = wxb * wyb * wza;
     t.w[4] = wxa * wya * wzb; t.w[5] = wxb * wya * wzb; t.w[6] = wxa * wyb * wzb; t.w[7] = wxb * wyb * wzb;
 }
@@ -180,12 +186,13 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
 //     dL/dd_s = T_s (a_s - Q_s),  Q_{s-1} = a_s d_s + (1 - d_s) Q_s,  Q_{S-1} = -g_opacity,
 //     a_s = sum_c g_c f_sc + g_depth z_s          (no division by (1 - d_s): densities may be 1)
 // and scatter-adds through the same 8 taps with hardware fp32 atomics.
-template <int C4>
+template <int C4, bool CAM>
 __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
                                                          const float* __restrict__ cams, const int* __restrict__ view2vol,
                                                          const float* __restrict__ g_feat, const float* __restrict__ g_opac,
                                                          const float* __restrict__ g_depth, float* __restrict__ dfeat,
-                                                         float* __restrict__ ddens, int D, int H, int W, int Hr, int Wr,
+                                                         float* __restrict__ ddens, float* __restrict__ dcam,
+                                                         int D, int H, int W, int Hr, int Wr,
                                                          int S, float zmin, float zmax, float hx, float hy, float hz) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][S][RPB]
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
             Q = fmaf(a, d, (1.f - d) * Q);
         }
     }
+    float Go[3] = {0.f, 0.f, 0.f}, Gd[3] = {0.f, 0.f, 0.f};   // d loss / d (ray origin, ray direction), this lane's share
     // pass 2: reverse march over the samples the forward pass visited.
     // NOTE: all C4 lanes of a ray have identical (s0, s_last), so the xor-shuffles below are
     // executed by all lanes of each ray group together.
@@ -295,6 +303,26 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
         a = fmaf(gdep, z, a);
         const float dLdd = Ts * (a - Q);
         Q = fmaf(a, d, (1.f - d) * Q);
+        if (CAM && t.any) {
+            // d loss / d pixel coordinate of this sample, this lane's share (its 4 channels; lane cg==0 adds the density
+            // term). Everything downstream is linear, so lanes and rays are summed once at the end.
+            const float wgt = d * Ts;
+            float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                const long long o = tap_off(t, k);
+                const float4 fv = F[o * C4];
+                float q = wgt * (fv.x * g.x + fv.y * g.y + fv.z * g.z + fv.w * g.w);
+                if (cg == 0) q = fmaf(Dn[o], dLdd, q);
+                gpx = fmaf(t.bx[dx] * t.ay[dy] * t.az[dz], q, gpx);
+                gpy = fmaf(t.ax[dx] * t.by[dy] * t.az[dz], q, gpy);
+                gpz = fmaf(t.ax[dx] * t.ay[dy] * t.bz[dz], q, gpz);
+            }
+            const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;
+            Go[0] = fmaf(kx, gpx, Go[0]); Go[1] = fmaf(ky, gpy, Go[1]); Go[2] = fmaf(kz, gpz, Go[2]);
+            Gd[0] = fmaf(kx * z, gpx, Gd[0]); Gd[1] = fmaf(ky * z, gpy, Gd[1]); Gd[2] = fmaf(kz * z, gpz, Gd[2]);
+        }
         if (t.any) {
             const float wgt = d * Ts;
             const float4 gw = make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w);
@@ -311,6 +339,35 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
                 }
             }
         }
+    }
+    if (CAM) {
+        // chain to the packed camera (R[9], T[3], fx, fy, cx, cy): o = -R^T T, dir = R^T (dxc, dyc, 1),
+        // dxc = (w + .5 - cx)/fx, dyc = (h + .5 - cy)/fy; then one block reduction and 16 atomics per workgroup.
+        float dc[16];
+        const float dxc = ((float)min(w, Wr - 1) + 0.5f - cam[14]) / cam[12], dyc = ((float)min(h, Hr - 1) + 0.5f - cam[15]) / cam[13];
+        const float dcv[3] = {dxc, dyc, 1.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dc[j * 3 + i] = inside ? (-Go[i] * cam[9 + j] + Gd[i] * dcv[j]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dc[9 + j] = inside ? -(Go[0] * cam[j * 3] + Go[1] * cam[j * 3 + 1] + Go[2] * cam[j * 3 + 2]) : 0.f;
+        const float gdx = Gd[0] * cam[0] + Gd[1] * cam[1] + Gd[2] * cam[2], gdy = Gd[0] * cam[3] + Gd[1] * cam[4] + Gd[2] * cam[5];
+        dc[12] = inside ? -gdx * dxc / cam[12] : 0.f;
+        dc[13] = inside ? -gdy * dyc / cam[13] : 0.f;
+        dc[14] = inside ? -gdx / cam[12] : 0.f;
+        dc[15] = inside ? -gdy / cam[13] : 0.f;
+        __shared__ float red[16][4];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float sacc = dc[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sacc += __shfl_down(sacc, o, 64);
+            if (lane == 0) red[i][wv] = sacc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) atomic_add_f32(dcam + v * 16 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
 }
 
@@ -360,16 +417,22 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
                                 float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
     if (int rc = check_render_args("forge_render_bwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
     FORGE_REQUIRE(g_feat && g_opac && dfeat && ddens, FORGE_EINVAL, "forge_render_bwd: null gradient pointer");
-    FORGE_REQUIRE(dcam == nullptr, FORGE_EINVAL, "forge_render_bwd: camera gradients (dcam) are not implemented yet");
     const size_t lds_bytes = (size_t)2 * S * (256 / (C / 4)) * sizeof(float);
     FORGE_REQUIRE(lds_bytes <= 160 * 1024, FORGE_ESHAPE, "forge_render_bwd: S=%d needs %zu B of LDS (> 160 KiB)", S, lds_bytes);
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
         dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
-        if (lds_bytes > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)render_bwd_kernel<C4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        hipLaunchKernelGGL(render_bwd_kernel<C4>, grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                           view2vol, g_feat, g_opac, g_depth, dfeat, ddens, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+        if (dcam) {
+            if (lds_bytes > 60 * 1024)
+                (void)hipFuncSetAttribute((const void*)render_bwd_kernel<C4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL((render_bwd_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                               view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+        } else {
+            if (lds_bytes > 60 * 1024)
+                (void)hipFuncSetAttribute((const void*)render_bwd_kernel<C4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            hipLaunchKernelGGL((render_bwd_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                               view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+        }
     });
     FORGE_LAUNCH_CHECK("forge_render_bwd");
     return 0;

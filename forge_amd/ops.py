@@ -99,9 +99,6 @@ class _RenderRays(torch.autograd.Function):
     def backward(ctx, g_feat, g_opac, g_depth=None):
         feat_cl, dens_c, cam_c, view2vol = ctx.saved_tensors
         Hr, Wr, S, zmin, zmax, half, want_depth = ctx.cfg
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError("forge_amd: gradients w.r.t. render cameras are not implemented yet "
-                                      "(pose-refinement row f2); detach the camera parameters")
         nvol, C, D, H, W = feat_cl.shape
         V = cam_c.shape[0]
         g_feat = g_feat.contiguous(memory_format=torch.channels_last)      # [V,Hr,Wr,C] in memory
@@ -109,12 +106,13 @@ class _RenderRays(torch.autograd.Function):
         g_depth = g_depth.contiguous() if (want_depth and g_depth is not None) else None
         dfeat = _zeros_like_cl(feat_cl)
         ddens = torch.zeros_like(dens_c)
+        dcam = torch.zeros_like(cam_c) if ctx.needs_input_grad[2] else None        # pose refinement / joint training
         _lib.check(_lib.lib().forge_render_bwd(
             _lib.ptr(feat_cl), _lib.ptr(dens_c), _lib.ptr(cam_c), _lib.ptr(view2vol),
-            _lib.ptr(g_feat), _lib.ptr(g_opac), _lib.ptr(g_depth), _lib.ptr(dfeat), _lib.ptr(ddens), None,
+            _lib.ptr(g_feat), _lib.ptr(g_opac), _lib.ptr(g_depth), _lib.ptr(dfeat), _lib.ptr(ddens), _lib.ptr(dcam),
             V, nvol, C, D, H, W, Hr, Wr, S, zmin, zmax, half[0], half[1], half[2], _lib.current_stream()),
             "forge_render_bwd")
-        return (dfeat, ddens) + (None,) * 9
+        return (dfeat, ddens, dcam) + (None,) * 8
 
 
 def render_rays(feat, dens, cam, view2vol, Hr, Wr, S, zmin, zmax, half, want_depth=False):

@@ -81,13 +81,17 @@ def stage_timers(model):
         out = orig(in1, C1, ld1, in2, C2, ld2, wp, *a, **kw)
         e1.record()
         M = grid[0] * grid[1] * grid[2] * grid[3]
-        # same dispatch rule as forge_conv_igemm (csrc/conv_igemm.hip): names match the rocprofv3 kernel names
+        # same tile-selection rule as forge_conv_igemm (csrc/conv_igemm.hip): names match the rocprofv3 kernel names
+        nblk = lambda bm, bn: ((M + bm - 1) // bm) * ((Cout + bn - 1) // bn)
         if Cout <= 16:
             key = "conv_igemm_n16_kernel"
-        elif Cout <= 64:
-            key = "conv_igemm_kernel<128, 64>"
         else:
-            key = "conv_igemm_kernel<64, 128>" if ((M + 127) // 128) * ((Cout + 127) // 128) < 512 else "conv_igemm_kernel<128, 128>"
+            tile = "A" if Cout > 64 else "C"
+            if Cout > 64 and nblk(128, 128) < 512:
+                tile = "B" if nblk(64, 128) >= 512 else "D"
+            if Cout <= 64 and nblk(128, 64) < 512:
+                tile = "D"
+            key = "conv_igemm_kernel<%s>" % {"A": "128, 128, 8", "B": "64, 128, 8", "C": "128, 64, 8", "D": "64, 64, 4"}[tile]
         rec.setdefault(key, []).append((e0, e1, 2.0 * M * Cout * len(taps) * (C1 + C2)))
         return out
     co.conv_igemm = conv_timed
@@ -309,11 +313,11 @@ def main():
         kern = {} if args.no_microbench else kernel_rooflines(dev, B)
         # dominant kernel of the step: conv_igemm_kernel<128> (conv1 + fusion_conv + 10 ConvGRU launches per scene batch);
         # ALGORITHMIC FLOPs of all its launches in one step / their summed HIP-event durations
-        big = {k: v for k, v in conv_launch.items() if k.endswith(", 128>")}     # the BN=128 template (128- and 64-row tiles)
+        big = {k: v for k, v in conv_launch.items() if k.startswith("conv_igemm_kernel<")}     # every tile instantiation of the template
         ck = {"launches_per_step": sum(v["launches_per_step"] for v in big.values()), "total_ms": sum(v["total_ms"] for v in big.values()),
               "gflop": sum(v["gflop"] for v in big.values())}
         tf = ck["gflop"] / ck["total_ms"]
-        roofline = {"kernel": "conv_igemm_kernel<BM, 128> (fp32 MFMA implicit-GEMM conv; all %d launches of one step: ResNet layers 1-4, conv1, "
+        roofline = {"kernel": "conv_igemm_kernel<BM, BN, NW> (fp32 MFMA implicit-GEMM conv; all %d launches of one step: ResNet layers 1-4, conv1, "
                               "fusion_conv, ConvGRU gates/state)" % ck["launches_per_step"],
                     "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
                     "traffic": pmc_traffic("conv_igemm_kernel<128>"), "avg_launch_ms": ck["total_ms"] / ck["launches_per_step"],

@@ -78,13 +78,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int WM = BM / 32, WN = 8 / WM;        // 8 waves as WM(M) x WN(N); wave tile 32 x (BN / WN)
+template <int BM, int BN, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int WM = BM / 32, WN = NW / WM;       // NW waves as WM(M) x WN(N); wave tile 32 x (BN / WN)
     constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
-    static_assert(NT >= 1 && WM * WN == 8, "unsupported tile");
+    static_assert(NT >= 1 && WM * WN == NW && NT * 32 * WN == BN, "unsupported tile");
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
-    constexpr int ACH = BM / 64, BCH = BN / 64;     // 16-byte chunks per thread per K-step
+    constexpr int RPP = NW * 8;                     // tile rows staged per pass (8 threads per 128-byte row)
+    constexpr int ACH = BM / RPP, BCH = BN / RPP;   // 16-byte chunks per thread per K-step
+    static_assert(ACH >= 1 && BCH >= 1, "tile too small for the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     bool aval[ACH];
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
-        ar[j] = (tid >> 3) + 64 * j;
+        ar[j] = (tid >> 3) + RPP * j;
         long long v = m0 + ar[j];
         aval[j] = v < M;
         v = aval[j] ? v : 0;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     int br[BCH]; unsigned boff[BCH];
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-        br[j] = (tid >> 3) + 64 * j;
+        br[j] = (tid >> 3) + RPP * j;
         const int bsrc = (cp ^ ((br[j] >> 1) & 7)) << 2;
         boff[j] = (n0 + br[j]) < a.Cout ? (unsigned)(((n0 + br[j]) * Cin + bsrc) * 4) : OOB;
     }
@@ -466,30 +468,32 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         const long long grid = (M + BM16 - 1) / BM16;
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
-    } else if (Cout > 64) {
-        constexpr int BN = 128;
-        const long long nt = (Cout + BN - 1) / BN;
-        // small problems: 64-row tiles double the workgroup count (the chip wants >= 2 workgroups per CU)
-        const char* force = getenv("FORGE_CONV_BM");
-        const bool bm64 = force ? (atoi(force) == 64) : (((M + 127) / 128) * nt < 512);
-        const size_t lds = 2 * ((bm64 ? 64 : 128) * BK + BN * BK) * sizeof(float);
-        if (bm64) {
-            const long long grid = ((M + 63) / 64) * nt;
-            FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-            hipLaunchKernelGGL((conv_igemm_kernel<64, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
-        } else {
-            const long long grid = ((M + 127) / 128) * nt;
-            FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-            static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<128, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr_once;   // set once per process: safe under stream capture
-            hipLaunchKernelGGL((conv_igemm_kernel<128, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
-        }
     } else {
-        constexpr int BN = 64;
-        const long long grid = ((M + 127) / 128) * ((Cout + BN - 1) / BN);
-        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-        const size_t lds = 2 * (128 * BK + BN * BK) * sizeof(float);
-        hipLaunchKernelGGL((conv_igemm_kernel<128, BN>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, a);
+        // Tile choice: the chip wants >= 2 workgroups per CU (512); take the largest tile that still gives that many,
+        // else the smallest one. FORGE_CONV_TILE=A|B|C|D forces a variant (experiments).
+        //   A 128x128 / 8 waves   B 64x128 / 8 waves   C 128x64 / 8 waves   D 64x64 / 4 waves
+        auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+        char tile = Cout > 64 ? 'A' : 'C';
+        if (Cout > 64 && nblk(128, 128) < 512) tile = nblk(64, 128) >= 512 ? 'B' : 'D';
+        if (Cout <= 64 && nblk(128, 64) < 512) tile = 'D';
+        if (const char* f = getenv("FORGE_CONV_TILE")) { if (*f >= 'A' && *f <= 'D' && (Cout > 64 || *f == 'C' || *f == 'D')) tile = *f; }
+#define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
+    do {                                                                                                                   \
+        const long long grid = nblk(BMv, BNv);                                                                             \
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
+        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
+        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv>,            \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        (void)attr_once; /* set once per process: safe under stream capture */                                             \
+        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
+    } while (0)
+        switch (tile) {
+            case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
+            case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
+            case 'C': FORGE_LAUNCH_CONV(128, 64, 8); break;
+            default: FORGE_LAUNCH_CONV(64, 64, 4); break;
+        }
+#undef FORGE_LAUNCH_CONV
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

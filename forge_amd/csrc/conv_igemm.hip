@@ -78,11 +78,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN, int NW>
+template <int BM, int BN, int NW, int MT = 1, bool PRIO = false>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
-    constexpr int WM = BM / 32, WN = NW / WM;       // NW waves as WM(M) x WN(N); wave tile 32 x (BN / WN)
+    constexpr int WM = BM / (32 * MT), WN = NW / WM; // NW waves as WM(M) x WN(N); wave tile (32 MT) x (BN / WN)
     constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
-    static_assert(NT >= 1 && WM * WN == NW && NT * 32 * WN == BN, "unsupported tile");
+    static_assert(NT >= 1 && WM * WN == NW && NT * 32 * WN == BN && WM * 32 * MT == BM, "unsupported tile");
     constexpr int A_FLOATS = BM * BK, B_FLOATS = BN * BK;
     constexpr int RPP = NW * 8;                     // tile rows staged per pass (8 threads per 128-byte row)
     constexpr int ACH = BM / RPP, BCH = BN / RPP;   // 16-byte chunks per thread per K-step
@@ -165,11 +165,13 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         for (int j = 0; j < BCH; ++j) *reinterpret_cast<float4*>(sb + br[j] * BK + (cp << 2)) = rb[j];
     };
 
-    f32x16 acc[NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
     int t = 0, kc = 0;
@@ -188,18 +190,29 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         const float* sb = sa + A_FLOATS;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                             // 8 k-values per group
-            const float4 fa = *reinterpret_cast<const float4*>(sa + lds_off(wm * 32 + l31, 2 * g + half));
-            float4 fb[NT];
+            float4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off(wm * (32 * MT) + i * 32 + l31, 2 * g + half));
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / WN) + j * 32 + l31, 2 * g + half));
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb[j].x, acc[j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb[j].y, acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb[j].z, acc[j], 0, 0, 0);
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb[j].w, acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
@@ -219,11 +232,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             const float bias = a.bias ? a.bias[colc] : 0.f;
             float sc = 1.f, sh = 0.f;
             if ((EPI == EPI_AFFINE_ACT || (EPI == EPI_GRU_OUT && a.out2)) && a.scale) { sc = a.scale[colc]; sh = a.shift[colc]; }
-            {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    float v = acc[j][r] + bias;
+                    const long long m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float v = acc[i][j][r] + bias;
                     if (cok && m < M) {
                         long long orow = m;
                         if (remap) {
@@ -487,6 +501,21 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         (void)attr_once; /* set once per process: safe under stream capture */                                             \
         hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
     } while (0)
+#define FORGE_LAUNCH_CONV_X(BMv, BNv, NWv, MTv, PRv)                                                                       \
+    do {                                                                                                                   \
+        const long long grid = nblk(BMv, BNv);                                                                             \
+        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
+        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv, MTv, PRv>,  \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        (void)attr_once;                                                                                                   \
+        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv, MTv, PRv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a); \
+    } while (0)
+        const char* var = getenv("FORGE_CONV_VARIANT");     // experiments on the big tile only
+        if (tile == 'A' && var && *var == '1') { FORGE_LAUNCH_CONV_X(128, 128, 8, 1, true); }
+        else if (tile == 'A' && var && *var == '2') { FORGE_LAUNCH_CONV_X(256, 128, 8, 2, false); }
+        else if (tile == 'A' && var && *var == '3') { FORGE_LAUNCH_CONV_X(256, 128, 8, 2, true); }
+        else if (tile == 'A' && var && *var == '4') { FORGE_LAUNCH_CONV_X(128, 128, 4, 2, false); }
+        else
         switch (tile) {
             case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
             case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
@@ -494,6 +523,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
             default: FORGE_LAUNCH_CONV(64, 64, 4); break;
         }
 #undef FORGE_LAUNCH_CONV
+#undef FORGE_LAUNCH_CONV_X
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

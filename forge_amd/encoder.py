@@ -177,17 +177,41 @@ class Encoder3D(nn.Module):
         return self._trunk_cache.get(src, build)
 
     def _trunk_hip(self, img):
-        """ResNet-50 layers 1-4 as im2col-free implicit GEMMs on the fp32 matrix cores (1x1 = plain GEMM, 3x3 = 9 taps,
-        strides via the input-stride argument), BN folded, ReLU and the residual add in the epilogue, activations NHWC.
-        The stem (7x7 s2 conv + BN + ReLU + max-pool, 2.4 % of the trunk FLOPs) still runs through PyTorch-ROCm.
+        """The whole ResNet-50 trunk on the fp32 matrix cores: stem (patch gather + GEMM, max-pool kernel), layers 1-4 as
+        im2col-free implicit GEMMs (1x1 = plain GEMM, 3x3 = 9 taps, strides via the input-stride argument), BN folded, ReLU
+        and the residual add in the epilogue, activations NHWC, the 2D->3D lift fused into the last store.
         img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1)."""
+        from . import _lib
         fe = self.feature_extraction
-        x = fe[3](fe[2](fe[1](fe[0](img))))
-        N, C, H, W = x.shape
-        xr = x.permute(0, 2, 3, 1).contiguous()                                    # NHWC rows
-        blocks = self._trunk_packed()
         dev = img.device
         T1 = [(0, 0, 0)]
+        # ---- stem: 7x7/s2 conv as patch-gather + one-tap GEMM (BN + ReLU folded), then the 3x3/s2 max-pool, all channels-last
+        conv0, bn0, pool = fe[0], fe[1], fe[3]
+        if not hasattr(self, "_stem_cache"):
+            self._stem_cache = co.PackCache()
+        kh, kw = conv0.kernel_size
+        Kp = ((kh * kw * conv0.in_channels + 31) // 32) * 32
+
+        def build_stem():
+            w = conv0.weight.detach().permute(0, 2, 3, 1).reshape(conv0.out_channels, -1)          # [Cout][(ky,kx,c)]
+            return (co.pad_cin(w[None].contiguous(), Kp),) + co.bn_affine(bn0)
+        w0, sc0, sh0 = self._stem_cache.get([conv0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var], build_stem)
+        N, Ci, Hi, Wi = img.shape
+        s0, p0 = conv0.stride[0], conv0.padding[0]
+        Hc, Wc = (Hi + 2 * p0 - kh) // s0 + 1, (Wi + 2 * p0 - kw) // s0 + 1
+        img_c = img.contiguous()
+        patches = torch.empty(N * Hc * Wc, Kp, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().forge_im2col_nchw(_lib.ptr(img_c), _lib.ptr(patches), N, Ci, Hi, Wi, kh, kw, s0, p0, Kp, _lib.current_stream()),
+                   "forge_im2col_nchw")
+        c0 = torch.empty(N, Hc, Wc, conv0.out_channels, dtype=torch.float32, device=dev)
+        co.conv_igemm(patches, Kp, Kp, None, 0, 0, w0, None, sc0, sh0, 0.0, None, None, None, c0, None,
+                      (N, 1, Hc, Wc), (1, Hc, Wc), conv0.out_channels, conv0.out_channels, T1, epilogue=co.EPI_AFFINE_ACT)
+        pk, ps, pp = pool.kernel_size, pool.stride, pool.padding
+        H, W = (Hc + 2 * pp - pk) // ps + 1, (Wc + 2 * pp - pk) // ps + 1
+        xr = torch.empty(N, H, W, conv0.out_channels, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().forge_maxpool2d_nhwc(_lib.ptr(c0), _lib.ptr(xr), N, Hc, Wc, conv0.out_channels, pk, ps, pp, _lib.current_stream()),
+                   "forge_maxpool2d_nhwc")
+        blocks = self._trunk_packed()
         for bi, b in enumerate(blocks):
             last = bi == len(blocks) - 1
             Cin, P, s = xr.shape[-1], b["planes"], b["stride"]

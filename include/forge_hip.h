@@ -150,6 +150,18 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      int epilogue, int lift, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a1  ResNet stem helpers (torchvision conv1/bn1/relu/maxpool behind models/encoder.py:71-73).
+ * forge_im2col_nchw: img [N][C][H][W] -> patch rows out [N*Ho*Wo][Kpad], k = (ky*kw + kx)*C + c, zeros outside the image and
+ *   for k >= kh*kw*C; Ho = (H + 2 pad - kh)/stride + 1. The 7x7/s2 stem conv then runs as forge_conv_igemm with one tap and
+ *   C1 = Kpad (BN + ReLU in its epilogue).
+ * forge_maxpool2d_nhwc: in [N][H][W][C] -> out [N][Ho][Wo][C], window k, -inf padding (nn.MaxPool2d semantics), C % 4 == 0.
+ */
+int forge_im2col_nchw(const float* img, float* out, int N, int C, int H, int W, int kh, int kw, int stride, int pad,
+                      int Kpad, forge_stream_t stream);
+int forge_maxpool2d_nhwc(const float* in, float* out, int N, int H, int W, int C, int k, int stride, int pad,
+                         forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.
  *   src [n][C][P] -> dst [n][P][C]   (P = D*H*W)   and back.
  */

@@ -124,3 +124,25 @@ def test_synthetic_sample_schema():
     sd = syn.seeded_state_dict({"a.weight": (4, 3, 3, 3), "a.bias": (4,)}, 0)
     sd2 = syn.seeded_state_dict({"a.bias": (4,), "a.weight": (4, 3, 3, 3)}, 0)
     assert torch.equal(sd["a.weight"], sd2["a.weight"])                 # per-key streams: order independent
+
+
+def test_look_at_view_transform_kat_and_shim():
+    """row f3: at azim=180 the PyTorch3D look-at camera IS the canonical OpenCV camera (R = I, T = (0,0,dist)) — the reason
+    demo.py:85-87 can feed PyTorch3D (R,T) to render(); and the restatement agrees with the oracle-side shim."""
+    import sys
+    from forge_amd import nvs
+    R, T = nvs.look_at_view_transform(dist=1.5, elev=0.0, azim=180.0)
+    assert torch.allclose(R[0], torch.eye(3), atol=1e-6) and torch.allclose(T[0], torch.tensor([0.0, 0.0, 1.5]), atol=1e-6)
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+    try:
+        from pytorch3d.renderer import look_at_view_transform as shim
+    finally:
+        sys.path.remove(os.path.join(ROOT, "oracle", "shims"))
+    elev = torch.tensor([0.0, 10.0, -25.0, 40.0])
+    azim = torch.tensor([180.0, 13.0, 250.0, 359.0])
+    R1, T1 = nvs.look_at_view_transform(dist=1.5, elev=elev, azim=azim)
+    R2, T2 = shim(dist=1.5, elev=elev, azim=azim)
+    assert torch.allclose(R1, R2, atol=1e-6) and torch.allclose(T1, T2, atol=1e-6)
+    R, T = nvs.nvs_cameras(1.5)
+    assert R.shape == (28, 3, 3) and torch.allclose(T.norm(dim=1), torch.full((28,), 1.5), atol=1e-5)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(28, 3, 3), atol=1e-5)

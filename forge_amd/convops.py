@@ -115,3 +115,74 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
         p(out), p(out2), n, D, H, W, istride, Di, Hi, Wi, Cout, ldo, _taps_array(taps), len(taps), ostride,
         phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.current_stream()), "forge_conv_igemm")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# autograd: stride-1 3x3x3 convolution on channels-last rows, forward / data-gradient on forge_conv_igemm, weight-gradient
+# on forge_conv_wgrad. Used by the training / pose-refinement paths of the ConvGRU fusion and conv1.
+# ------------------------------------------------------------------------------------------------------------------
+def conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, in_grid, Cout, taps, istride=1, bs1=0, bs2=0):
+    n, D, H, W = grid
+    Di, Hi, Wi = in_grid
+    p = _lib.ptr
+    _lib.check(_lib.lib().forge_conv_wgrad(p(dy), dy.shape[-1], p(x1), C1, x1.shape[-1], int(bs1), p(x2), C2, 0 if x2 is None else x2.shape[-1],
+                                           int(bs2), p(dwp), n, D, H, W, istride, Di, Hi, Wi, Cout, _taps_array(taps), len(taps),
+                                           _lib.current_stream()), "forge_conv_wgrad")
+    return dwp
+
+
+def _batch_stride_rows(x):
+    """rows tensor [n,D,H,W,C] whose only non-dense stride may be the batch one -> batch stride in rows (0 = dense)."""
+    n, D, H, W, C = x.shape
+    if x.stride()[1:] != (H * W * C, W * C, C, 1):
+        raise ValueError("conv_rows needs channels-last rows [n,D,H,W,C] dense within a batch element; got strides %s" % (x.stride(),))
+    return 0 if (n == 1 or x.stride(0) == D * H * W * C) else x.stride(0) // C
+
+
+class _Conv3x3x3Rows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias):
+        n, D, H, W, C1 = x1.shape
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cout = weight.shape[0]
+        wp = pack_conv3d_weight(weight)
+        out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x1.device)
+        bs1 = _batch_stride_rows(x1)
+        bs2 = 0 if x2 is None else _batch_stride_rows(x2)
+        conv_igemm(x1, C1, C1, x2, C2, C2, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
+                   TAPS_3x3x3, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
+        ctx.save_for_backward(x1, x2, wp)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, wp = ctx.saved_tensors
+        n, D, H, W, C1 = x1.shape
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cin, Cout = C1 + C2, wp.shape[1]
+        dy = dy.contiguous()
+        grid, ig = (n, D, H, W), (D, H, W)
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # data gradient = the same implicit GEMM on dy with negated taps and transposed weights
+            wd = wp.transpose(1, 2).contiguous()
+            dx = torch.empty(n, D, H, W, Cin, dtype=torch.float32, device=dy.device)
+            conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, grid, ig, Cin, Cin,
+                       [(-a, -b, -c) for a, b, c in TAPS_3x3x3], epilogue=EPI_BIAS)
+            dx1 = dx[..., :C1] if ctx.needs_input_grad[0] else None
+            dx2 = dx[..., C1:] if (x2 is not None and ctx.needs_input_grad[1]) else None
+        if ctx.needs_input_grad[2]:
+            dwp = torch.zeros_like(wp)
+            conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, ig, Cout, TAPS_3x3x3, bs1=_batch_stride_rows(x1),
+                       bs2=0 if x2 is None else _batch_stride_rows(x2))
+            dw = dwp.permute(1, 2, 0).reshape(Cout, Cin, 3, 3, 3)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = dy.reshape(-1, Cout).sum(dim=0)
+        return dx1, dx2, dw, db
+
+
+def conv3x3x3_rows(x1, x2, weight, bias):
+    """Conv3d(k=3, padding=1, stride=1) of the channel concat (x1 | x2) on channels-last rows [n,D,H,W,C] with autograd.
+    C1, C2 and Cout must be multiples of 32 (the GEMM K-step; the data gradient swaps the roles of Cin and Cout)."""
+    return _Conv3x3x3Rows.apply(x1, x2, weight, bias)

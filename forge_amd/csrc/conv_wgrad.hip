@@ -1,0 +1,199 @@
+// conv_wgrad.hip — weight gradient of the implicit-GEMM convolution on the fp32 matrix cores.
+//
+//   dW[t][co][ci] = sum_m dY[m][co] * X[row(m) + tap_t][ci]          (zero outside the grid)
+//
+// i.e. for every tap a GEMM  dW_t = dY^T (Cout x M)  @  X_t (M x Cin)  whose reduction dimension is the voxel index m.
+// Both operands are row-major [m][channels] in HBM = "k-major" for this GEMM, which is exactly what the 32x32x2 fp32 MFMA
+// wants from LDS without any transpose: lane l supplies A[i = l&31][k = l>>5], so a half-wave reads 32 CONSECUTIVE floats
+// of one LDS row (conflict-free ds_read_b32). Workgroup = 8 waves (4 along co x 2 along ci), tile 128(co) x 128(ci) for one
+// tap over one M-chunk, K-step = 32 voxels, register-staged buffer loads (out-of-range rows / taps -> 0), double-buffered
+// LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
+// taps x tiles alone is only ~100 workgroups). dW must be zero-filled by the caller.
+//
+// Replaces torch's conv3d weight-gradient (cuDNN/MIOpen) for the ConvGRU / fusion_conv / conv1 convolutions
+// (models/fusion.py:29-35,61-68; models/encoder.py:36-40) in training (scripts/kubric_trainer.py:56).
+#include "common.h"
+
+namespace forge {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16w;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4w;
+constexpr unsigned OOBW = 0x80000000u;
+
+__device__ __forceinline__ float4 buf_load16w(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    u32x4w v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+struct WgradArgs {
+    const float* dy; int ldy;                 // [M][ldy], Cout channels used
+    const float* x1; const float* x2;         // channel-concatenated inputs [rows][ld1], [rows][ld2]; x2 nullable
+    int C1, C2, ld1, ld2;
+    long long bs1r, bs2r, span1, span2, spany;
+    float* dw;                                // [ntaps][Cout][C1+C2], zero-filled, atomically accumulated
+    int n, D, H, W;                           // GEMM-row grid of dY (M = n D H W)
+    int is, Di, Hi, Wi;                       // input voxel = (z is + dz, ...)
+    int Cout, ntaps, mchunk;                  // rows per M-chunk (multiple of 32)
+    signed char tap[64][4];
+};
+
+constexpr int WT = 128, WK = 32;              // tile 128 x 128, K-step 32 voxels
+
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][2][WK][WT]: A (dY) and B (X) images, row = voxel, col = channel
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                        // wave tile 32 (co) x 64 (ci)
+    const int l31 = lane & 31, half = lane >> 5;
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const int Cin = a.C1 + a.C2;
+    const int cot = (a.Cout + WT - 1) / WT, cit = (Cin + WT - 1) / WT;
+    const int nchunk = (int)((M + a.mchunk - 1) / a.mchunk);
+    unsigned bid = blockIdx.x;
+    const int chunk = bid % nchunk; bid /= nchunk;
+    const int ci_t = bid % cit; bid /= cit;
+    const int co_t = bid % cot; bid /= cot;
+    const int t = bid;                                              // tap
+    const long long mbeg = (long long)chunk * a.mchunk;
+    const long long mend = mbeg + a.mchunk < M ? mbeg + a.mchunk : M;
+    const int nsteps = (int)((mend - mbeg + WK - 1) / WK);
+    const int co0 = co_t * WT, ci0 = ci_t * WT;
+
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
+    const bool second = ci0 >= a.C1;                                 // this ci tile lives in x2
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a.x2 : a.x1), 0, (int)(second ? a.span2 : a.span1), 0x00020000);
+    const int ldx = second ? a.ld2 : a.ld1, cx0 = second ? ci0 - a.C1 : ci0, Cx = second ? a.C2 : a.C1;
+    const long long bsx = second ? a.bs2r : a.bs1r;
+    const int dz = a.tap[t][0], dy_ = a.tap[t][1], dx = a.tap[t][2];
+
+    // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = tid >> 5 (+16), chunk = tid & 31)
+    const int srow[2] = {tid >> 5, (tid >> 5) + 16};
+    const int sc4 = (tid & 31) << 2;
+    const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = cx0 + sc4 < Cx;
+    float4 ra[2], rb[2];
+    // voxel coordinates of the two staged rows, advanced by WK rows per K-step (no per-step divisions)
+    int rx_[2], ry_[2], rz_[2], rn_[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned v = (unsigned)(mbeg + srow[j]);
+        rx_[j] = (int)(v % (unsigned)a.W); v /= (unsigned)a.W;
+        ry_[j] = (int)(v % (unsigned)a.H); v /= (unsigned)a.H;
+        rz_[j] = (int)(v % (unsigned)a.D); v /= (unsigned)a.D;
+        rn_[j] = (int)v;
+    }
+    auto load_step = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long m = mbeg + (long long)s * WK + srow[j];
+            const bool mok = m < mend;
+            ra[j] = buf_load16w(ry, (mok && ycol_ok) ? (unsigned)((m * a.ldy + co0 + sc4) * 4) : OOBW);
+            const int x = rx_[j] * a.is + dx, y = ry_[j] * a.is + dy_, z = rz_[j] * a.is + dz;
+            const bool ok = mok && xcol_ok && (unsigned)z < (unsigned)a.Di && (unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi;
+            const long long e = rn_[j] * bsx + ((long long)z * a.Hi + y) * a.Wi + x;
+            rb[j] = buf_load16w(rx, ok ? (unsigned)((e * ldx + cx0 + sc4) * 4) : OOBW);
+            rx_[j] += WK;                                         // advance to the row of the next K-step
+            while (rx_[j] >= a.W) {
+                rx_[j] -= a.W;
+                if (++ry_[j] == a.H) { ry_[j] = 0; if (++rz_[j] == a.D) { rz_[j] = 0; ++rn_[j]; } }
+            }
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* sa = smem + buf * (2 * WK * WT);
+        float* sb = sa + WK * WT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(sa + srow[j] * WT + sc4) = ra[j];
+            *reinterpret_cast<float4*>(sb + srow[j] * WT + sc4) = rb[j];
+        }
+    };
+
+    f32x16w acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    if (nsteps > 0) {
+        load_step(0);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const bool more = s + 1 < nsteps;
+        if (more) load_step(s + 1);
+        const float* sa = smem + buf * (2 * WK * WT) + wm * 32 + l31;
+        const float* sb = smem + buf * (2 * WK * WT) + WK * WT + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < WK / 2; ++kk) {
+            const int row = 2 * kk + half;
+            const float fa = sa[row * WT];
+            const float fb0 = sb[row * WT], fb1 = sb[row * WT + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb1, acc[1], 0, 0, 0);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // D[i = co][j = ci]: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wn * 64 + j * 32 + l31;
+        if (ci >= Cin || (second ? ci - a.C1 >= a.C2 : ci >= a.C1)) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < a.Cout) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[j][r]);
+        }
+    }
+}
+
+}  // namespace forge
+
+using namespace forge;
+
+extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1, long long bs1, const float* x2, int C2, int ld2,
+                                long long bs2, float* dw, int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout,
+                                const int* taps, int ntaps, forge_stream_t stream) {
+    FORGE_REQUIRE(dy && x1 && dw && taps, FORGE_EINVAL, "forge_conv_wgrad: null pointer argument");
+    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= 64 && is >= 1 && Di > 0 && Hi > 0 && Wi > 0, FORGE_EINVAL,
+                  "forge_conv_wgrad: bad dims");
+    FORGE_REQUIRE(C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0 && ld1 >= C1 && ld1 % 4 == 0 &&
+                  (C2 == 0 || (ld2 >= C2 && ld2 % 4 == 0)), FORGE_ESHAPE, "forge_conv_wgrad: channel counts / row strides must be multiples of 4");
+    FORGE_REQUIRE((C2 == 0) == (x2 == nullptr), FORGE_EINVAL, "forge_conv_wgrad: x2/C2 mismatch");
+    FORGE_REQUIRE(C2 == 0 || C1 % WT == 0, FORGE_ESHAPE, "forge_conv_wgrad: with two inputs C1 must be a multiple of %d", WT);
+    WgradArgs a;
+    a.dy = dy; a.ldy = ldy; a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.dw = dw;
+    a.n = n; a.D = D; a.H = H; a.W = W; a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cout = Cout; a.ntaps = ntaps;
+    a.bs1r = bs1 > 0 ? bs1 : (long long)Di * Hi * Wi; a.bs2r = bs2 > 0 ? bs2 : (long long)Di * Hi * Wi;
+    const long long M = (long long)n * D * H * W;
+    a.spany = M * ldy * 4;
+    a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
+    a.span2 = x2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
+    FORGE_REQUIRE(a.spany < (1ll << 31) && a.span1 < (1ll << 31) && a.span2 < (1ll << 31), FORGE_ESHAPE,
+                  "forge_conv_wgrad: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch");
+    for (int t = 0; t < 64; ++t) {
+        for (int k = 0; k < 3; ++k) a.tap[t][k] = (signed char)(t < ntaps ? taps[t * 3 + k] : 0);
+        a.tap[t][3] = 0;
+    }
+    const int Cin = C1 + C2;
+    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + WT - 1) / WT);
+    // split the voxel (reduction) axis so that ~1024 workgroups exist; chunks are multiples of the K-step
+    long long nchunk = (1024 + tiles - 1) / tiles;
+    if (nchunk < 1) nchunk = 1;
+    long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
+    if (mchunk < 4 * WK) mchunk = 4 * WK;
+    a.mchunk = (int)mchunk;
+    nchunk = (M + mchunk - 1) / mchunk;
+    const long long grid = tiles * nchunk;
+    FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
+    const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 64 KiB
+    static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr_once;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+    FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+    return 0;
+}

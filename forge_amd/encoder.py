@@ -110,6 +110,11 @@ class Encoder3D(nn.Module):
         z_2d = self.feature_extraction(img)
         B, C, H, W = z_2d.shape
         z_3d = z_2d.view(-1, 64, 32, H, W)
+        if z_3d.is_cuda and z_3d.dtype == torch.float32:
+            # training: conv1 on the MFMA GEMM (forward, dgrad) + wgrad kernel; BN (batch stats) + LeakyReLU stay torch
+            rows = self._rows(z_3d)
+            y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
+            return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
         return self.conv1(z_3d)
 
     def get_density3D(self, z_3d):
@@ -126,6 +131,8 @@ class Encoder3D(nn.Module):
         """x [b,t,c,d,h,w] -> [b,c,d,h,w] (models/encoder.py:59-63)"""
         if hip_inference(self, x):
             return self.fusion_feature.fuse_hip(x)
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0:
+            return self.fusion_feature.fuse_autograd_hip(x)             # training / refinement: HIP convs with autograd
         return self.fusion_feature(x, [self.fusion_feature.fusion_conv(x.mean(dim=1))])
 
     # ---------------------------------------------------------------- fused HIP inference path

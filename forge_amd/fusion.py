@@ -111,6 +111,35 @@ class ConvGRU_3D(nn.Module):
             h, h2 = h2, h
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
+    # ---------------------------------------------------------------- HIP training / autograd path
+    @staticmethod
+    def _bn_rows(bn, rows, act=None):
+        """nn.BatchNorm3d / SyncBatchNorm module applied to channels-last rows [b,D,H,W,C] (batch statistics in train mode)."""
+        y = bn(rows.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+        y = y if y.is_contiguous() else y.contiguous()
+        return y if act is None else act(y)
+
+    def fuse_autograd_hip(self, x):
+        """Encoder3D.fuse with an autograd graph (model.train(), or eval-mode pose refinement): the six convolutions per GRU step
+        and fusion_conv run on the MFMA implicit-GEMM kernel (forward and data gradient) and the wgrad kernel; BatchNorm (batch
+        statistics / SyncBN), sigmoid, tanh and the lerp stay torch element-wise ops so that their autograd is torch's."""
+        assert self.n_layers == 1
+        b, t, C, D, H, W = x.shape
+        xr = x.permute(0, 1, 3, 4, 5, 2)
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        cell, fc = self.cells[0], self.fusion_conv
+        lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
+        h = self._bn_rows(fc[1], co.conv3x3x3_rows(xr.mean(dim=1), None, fc[0].weight, fc[0].bias), lrelu)
+        h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
+        hs = self.hidden_size
+        for ti in range(t):
+            xt = xr[:, ti]
+            g = co.conv3x3x3_rows(xt, h, cell.conv_gate.weight, cell.conv_gate.bias)
+            update, reset = torch.sigmoid(g[..., :hs]), torch.sigmoid(g[..., hs:])
+            cand = torch.tanh(co.conv3x3x3_rows(xt, (h * reset).contiguous(), cell.out_gate.weight, cell.out_gate.bias))
+            h = h * (1 - update) + cand * update
+        return self.fusion_norm(h.permute(0, 4, 1, 2, 3))
+
     def forward(self, x, hidden=None):
         """x [b,t,c,d,h,w] -> fusion_norm(h_T) [b,c',d,h,w]"""
         seq_len = x.shape[1]

@@ -149,6 +149,17 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
                      int epilogue, int lift, forge_stream_t stream);
 
+/* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
+ *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)
+ * dy [M][ldy] is the upstream gradient of the conv output on the (n,D,H,W) row grid; x1/x2, is, Di.. as in forge_conv_igemm.
+ * dw [ntaps][Cout][C1+C2] MUST be zero-filled: partial sums over voxel chunks are accumulated with fp32 atomics (the order of
+ * the additions, hence the last bits, is not deterministic). With two inputs C1 must be a multiple of 128.
+ * The data gradient needs no extra entry point: it is forge_conv_igemm on dy with negated taps and wp[t][ci][co] (transposed).
+ */
+int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1, long long bs1, const float* x2, int C2, int ld2,
+                     long long bs2, float* dw, int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout,
+                     const int* taps, int ntaps, forge_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a1  ResNet stem helpers (torchvision conv1/bn1/relu/maxpool behind models/encoder.py:71-73).
  * forge_im2col_nchw: img [N][C][H][W] -> patch rows out [N*Ho*Wo][Kpad], k = (ky*kw + kx)*C + c, zeros outside the image and

@@ -549,3 +549,52 @@ def test_render_360_vs_oracle(dev):
         assert (imgs[s].cpu() - ref[0]).abs().max().item() < 1e-4
         assert (masks[s].cpu() - ref[1]).abs().max().item() < 2e-5
         assert (depths[s].cpu() - ref[2]).abs().max().item() < 2e-5
+
+
+def test_conv3x3x3_rows_autograd_vs_torch(dev):
+    """forward, data gradient (same GEMM, negated taps, transposed weights) and the wgrad kernel vs torch autograd on CPU."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(17)
+    x1 = torch.randn(2, 32, 6, 7, 9, generator=g)
+    x2 = torch.randn(2, 128, 6, 7, 9, generator=g)
+    w = torch.randn(64, 160, 3, 3, 3, generator=g) / 60
+    b = torch.randn(64, generator=g)
+    gy = torch.randn(2, 64, 6, 7, 9, generator=g)
+    # wgrad needs C1 % 128 == 0 with two inputs -> put the 128-channel tensor first
+    a1, a2, aw, ab = x2.clone().requires_grad_(True), x1.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(torch.cat([a1, a2], 1), aw, ab, padding=1)
+    ref.backward(gy)
+    d1 = _rows(x2).to(dev).requires_grad_(True)
+    d2 = _rows(x1).to(dev).requires_grad_(True)
+    dw, db = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = co.conv3x3x3_rows(d1, d2, dw, db)
+    out.backward(_rows(gy).to(dev))
+    assert (out.detach().permute(0, 4, 1, 2, 3).cpu() - ref.detach()).abs().max().item() < 5e-5 * ref.abs().max().item()
+    for got, exp, name in ((d1.grad.permute(0, 4, 1, 2, 3).cpu(), a1.grad, "dx1"), (d2.grad.permute(0, 4, 1, 2, 3).cpu(), a2.grad, "dx2"),
+                           (dw.grad.cpu(), aw.grad, "dw"), (db.grad.cpu(), ab.grad, "db")):
+        assert (got - exp).abs().max().item() < 1e-4 * exp.abs().max().item(), name
+
+
+def test_fuse_autograd_hip_vs_oracle(dev):
+    """ConvGRU fusion in train mode (batch-stat BN) through the HIP convs: output and all parameter/input gradients vs autograd
+    through the oracle."""
+    from forge_amd.fusion import ConvGRU_3D
+    gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128)
+    pre = "encoder_3d.fusion_feature."
+    w = syn.seeded_state_dict({pre + k: v for k, v in gru.state_dict().items()}, 9)
+    gru.load_state_dict({k[len(pre):]: v for k, v in w.items()})
+    gru = gru.to(dev).train()
+    x = torch.randn(1, 2, 128, 6, 6, 6, generator=torch.Generator().manual_seed(4))
+    wr = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = fo.fuse(xr, wr, training=True)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5))
+    ref.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    got = gru.fuse_autograd_hip(xd)
+    got.backward(gy.to(dev))
+    assert (got.detach().cpu() - ref.detach()).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() < 2e-3 * xr.grad.abs().max().item()
+    for name, p_ in gru.named_parameters():
+        e = wr[pre + name].grad
+        assert (p_.grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-6), name

@@ -120,12 +120,12 @@ class Encoder3D(nn.Module):
     def get_density3D(self, z_3d):
         if hip_inference(self, z_3d):
             return self._heads_hip(z_3d)[1]
-        return self.density_head(z_3d)
+        return self.density_head(z_3d.contiguous())        # torch/MIOpen path: plain NCDHW (its NDHWC solvers are naive kernels)
 
     def get_render_features(self, x):
         if hip_inference(self, x):
             return self._heads_hip(x)[0]
-        return self.features_head(x)
+        return self.features_head(x.contiguous())
 
     def fuse(self, x):
         """x [b,t,c,d,h,w] -> [b,c,d,h,w] (models/encoder.py:59-63)"""

@@ -79,7 +79,7 @@ class VolRender(nn.Module):
         half = (0.5 * (W - 1) * vox, 0.5 * (H - 1) * vox, 0.5 * (D - 1) * vox)
         outs = ops.render_rays(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray,
                                self.min_depth, self.max_depth, half, want_depth=render_depth)
-        rendered_imgs = self._conv_rgb_hip(outs[0]) if hip_inference(self, outs[0]) else F.relu(self.conv_rgb(outs[0]))
+        rendered_imgs = self._conv_rgb_hip(outs[0]) if hip_inference(self, outs[0]) else F.relu(self.conv_rgb(outs[0].contiguous()))
         rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
         result = [rendered_imgs, rendered_silhouettes]
         if render_depth:

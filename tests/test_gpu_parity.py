@@ -595,6 +595,7 @@ def test_fuse_autograd_hip_vs_oracle(dev):
     got.backward(gy.to(dev))
     assert (got.detach().cpu() - ref.detach()).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
     assert (xd.grad.cpu() - xr.grad).abs().max().item() < 2e-3 * xr.grad.abs().max().item()
+    gscale = max(wr[pre + n_].grad.abs().max().item() for n_, _ in gru.named_parameters())
     for name, p_ in gru.named_parameters():
-        e = wr[pre + name].grad
-        assert (p_.grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-6), name
+        e = wr[pre + name].grad          # conv biases in front of a train-mode BN have an analytically zero gradient: absolute floor
+        assert (p_.grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-3 * gscale), name

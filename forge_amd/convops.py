@@ -186,3 +186,66 @@ def conv3x3x3_rows(x1, x2, weight, bias):
     """Conv3d(k=3, padding=1, stride=1) of the channel concat (x1 | x2) on channels-last rows [n,D,H,W,C] with autograd.
     C1, C2 and Cout must be multiples of 32 (the GEMM K-step; the data gradient swaps the roles of Cin and Cout)."""
     return _Conv3x3x3Rows.apply(x1, x2, weight, bias)
+
+
+def conv3x3x3_rows_any(x, weight, bias):
+    """conv3x3x3_rows for channel counts that are not multiples of 32 (the heads' 32->16, 32->8, 8->1 convolutions): weight and
+    input are zero-padded to the GEMM K-step with differentiable torch ops and the extra output channels are sliced away, so the
+    same forward / dgrad / wgrad kernels serve them (their FLOPs are negligible; what matters is that no MIOpen 3-D weight-gradient
+    solver — 65-110 ms each on these shapes — is involved)."""
+    Cout, Cin = weight.shape[:2]
+    Cop, Cip = -(-Cout // 32) * 32, -(-Cin // 32) * 32
+    if Cop != Cout or Cip != Cin:
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, Cip - Cin, 0, Cop - Cout))
+        if bias is not None:
+            bias = torch.nn.functional.pad(bias, (0, Cop - Cout))
+    if x.shape[-1] != Cip:
+        x = torch.nn.functional.pad(x, (0, Cip - x.shape[-1]))
+    y = _Conv3x3x3Rows.apply(x, None, weight, bias)
+    return y[..., :Cout] if Cop != Cout else y
+
+
+TAPS_CT_DGRAD = [(kz - 1, ky - 1, kx - 1) for kz in range(4) for ky in range(4) for kx in range(4)]
+
+
+class _ConvT3dK4S2P1Rows(torch.autograd.Function):
+    """nn.ConvTranspose3d(k=4, s=2, p=1) on channels-last rows. forward: 8 output-phase GEMMs of 8 taps; data gradient: ONE
+    stride-2 gather GEMM over the 64 kernel taps (dX[z] = sum_k dY[2z - 1 + k] W[:, :, k]); weight gradient: the wgrad kernel with
+    the roles swapped (reduction over input voxels, 'dy' operand = x, gathered operand = dY at 2z - 1 + k)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        n, D, H, W, Cin = x.shape
+        Cout = weight.shape[1]
+        out = torch.empty(n, 2 * D, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
+        for (pz, py, px), taps, wp in convT_phases(weight, 1, 3):
+            conv_igemm(x, Cin, Cin, None, 0, 0, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
+                       taps, out_grid=(2 * D, 2 * H, 2 * W), ostride=2, phase=(pz, py, px), epilogue=EPI_BIAS)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        n, D, H, W, Cin = x.shape
+        Cout = weight.shape[1]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().reshape(Cin, Cout, 64).permute(2, 0, 1).contiguous()         # [k][Cin][Cout]
+            dx = torch.empty_like(x)
+            conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (2 * D, 2 * H, 2 * W),
+                       Cin, Cin, TAPS_CT_DGRAD, istride=2, epilogue=EPI_BIAS)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros(64, Cin, Cout, dtype=torch.float32, device=x.device)             # [k][ci][co]
+            conv_wgrad(x, dy, Cout, None, 0, dwp, (n, D, H, W), (2 * D, 2 * H, 2 * W), Cin, TAPS_CT_DGRAD, istride=2)
+            dw = dwp.permute(1, 2, 0).reshape(Cin, Cout, 4, 4, 4)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, Cout).sum(dim=0)
+        return dx, dw, db
+
+
+def convT3d_k4s2p1_rows(x, weight, bias):
+    """ConvTranspose3d(Cin, Cout, 4, stride=2, padding=1) on rows [n,D,H,W,Cin] -> [n,2D,2H,2W,Cout]; Cin, Cout % 32 == 0."""
+    return _ConvT3dK4S2P1Rows.apply(x, weight, bias)

@@ -120,11 +120,15 @@ class Encoder3D(nn.Module):
     def get_density3D(self, z_3d):
         if hip_inference(self, z_3d):
             return self._heads_hip(z_3d)[1]
-        return self.density_head(z_3d.contiguous())        # torch/MIOpen path: plain NCDHW (its NDHWC solvers are naive kernels)
+        if z_3d.is_cuda and z_3d.dtype == torch.float32:
+            return self._head_autograd_hip(self.density_head, z_3d)
+        return self.density_head(z_3d.contiguous())
 
     def get_render_features(self, x):
         if hip_inference(self, x):
             return self._heads_hip(x)[0]
+        if x.is_cuda and x.dtype == torch.float32:
+            return self._head_autograd_hip(self.features_head, x)
         return self.features_head(x.contiguous())
 
     def fuse(self, x):
@@ -134,6 +138,27 @@ class Encoder3D(nn.Module):
         if x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0:
             return self.fusion_feature.fuse_autograd_hip(x)             # training / refinement: HIP convs with autograd
         return self.fusion_feature(x, [self.fusion_feature.fusion_conv(x.mean(dim=1))])
+
+    def _head_autograd_hip(self, head, z):
+        """A head (nn.Sequential of ConvTranspose3d / Conv3d / BatchNorm3d / LeakyReLU / ReLU, models/encoder.py:16-34) with an
+        autograd graph: every convolution forward, data gradient and weight gradient on the HIP GEMM / wgrad kernels, the
+        normalisations and activations as torch ops on the same channels-last rows."""
+        rows = self._rows(z)
+        for m in head:
+            if isinstance(m, nn.ConvTranspose3d):
+                rows = co.convT3d_k4s2p1_rows(rows, m.weight, m.bias)
+            elif isinstance(m, nn.Conv3d):
+                rows = co.conv3x3x3_rows_any(rows, m.weight, m.bias)
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                rows = m(rows.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
+                rows = rows if rows.is_contiguous() else rows.contiguous()
+            elif isinstance(m, nn.LeakyReLU):
+                rows = torch.nn.functional.leaky_relu(rows, m.negative_slope)
+            elif isinstance(m, nn.ReLU):
+                rows = torch.relu(rows)
+            else:
+                raise TypeError("unexpected layer in head: %r" % (m,))
+        return rows.permute(0, 4, 1, 2, 3)
 
     # ---------------------------------------------------------------- fused HIP inference path
     @staticmethod

@@ -599,3 +599,31 @@ def test_fuse_autograd_hip_vs_oracle(dev):
     for name, p_ in gru.named_parameters():
         e = wr[pre + name].grad          # conv biases in front of a train-mode BN have an analytically zero gradient: absolute floor
         assert (p_.grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-3 * gscale), name
+
+
+def test_heads_autograd_hip_vs_oracle(dev, golden):
+    """both heads in train mode (batch-stat BN) with HIP conv / conv-transpose forward, dgrad and wgrad vs autograd through the oracle."""
+    from forge_amd.encoder import Encoder3D
+    enc = Encoder3D(syn.kubric_config())
+    w = syn.seeded_state_dict({"encoder_3d." + k: v for k, v in enc.state_dict().items() if "feature_extraction" not in k}, 0)
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()}, strict=False)
+    enc = enc.to(dev).train()
+    z = torch.randn(2, 128, 4, 5, 3, generator=torch.Generator().manual_seed(9))
+    wr = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
+    zr = z.clone().requires_grad_(True)
+    rd, rf = fo.density_head(zr, wr, training=True), fo.render_features_head(zr, wr, training=True)
+    gd = torch.randn(rd.shape, generator=torch.Generator().manual_seed(1))
+    gf = torch.randn(rf.shape, generator=torch.Generator().manual_seed(2))
+    ((rd * gd).sum() + (rf * gf).sum()).backward()
+    zd = z.to(dev).requires_grad_(True)
+    d, f = enc.get_density3D(zd), enc.get_render_features(zd)
+    ((d * gd.to(dev)).sum() + (f * gf.to(dev)).sum()).backward()
+    assert (d.detach().cpu() - rd.detach()).abs().max().item() < 1e-4 * max(1.0, rd.abs().max().item())
+    assert (f.detach().cpu() - rf.detach()).abs().max().item() < 1e-4 * max(1.0, rf.abs().max().item())
+    assert (zd.grad.cpu() - zr.grad).abs().max().item() < 2e-3 * zr.grad.abs().max().item()
+    names = [n for n, _ in enc.named_parameters() if n.startswith(("density_head", "features_head"))]
+    gscale = max(wr["encoder_3d." + n].grad.abs().max().item() for n in names)
+    params = dict(enc.named_parameters())
+    for n in names:
+        e = wr["encoder_3d." + n].grad
+        assert (params[n].grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-3 * gscale), n

@@ -151,6 +151,76 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Narrow variant for Cout <= 32 and Cin <= 32 (the heads' 32->16 / 32->8 / 8->1 convolutions, channel-padded to 32 by the host
+// code): a 128x128 tile would execute 16x the useful matrix work. Here every WAVE is independent — no LDS, no barriers: it owns
+// a group of up to 4 taps and a chunk of voxels, and feeds the 32x32x2 MFMA straight from global memory (lane l loads
+// dY[row][l & 31] and X[row + tap][l & 31], i.e. each half-wave reads one coalesced 128-byte row per operand per MFMA; the dY
+// element is shared by the wave's taps). Partial 32x32 tiles are added to dW with fp32 atomics.
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs a, int tap_groups, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const long long nchunk = (M + rows_per_wave - 1) / rows_per_wave;
+    if (wave_id >= nchunk * tap_groups) return;
+    const int tg = (int)(wave_id % tap_groups);
+    const long long mbeg = (wave_id / tap_groups) * rows_per_wave;
+    const long long mend = mbeg + rows_per_wave < M ? mbeg + rows_per_wave : M;
+    const int t0 = tg * 4;
+    const int Cin = a.C1;                                          // single input, Cin <= 32
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, (int)a.span1, 0x00020000);
+    const bool yc = l31 < a.Cout, xc = l31 < Cin;
+
+    int tdz[4], tdy[4], tdx[4]; bool tok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tok[q] = t0 + q < a.ntaps;
+        const int t = tok[q] ? t0 + q : 0;
+        tdz[q] = a.tap[t][0]; tdy[q] = a.tap[t][1]; tdx[q] = a.tap[t][2];
+    }
+    // this lane's row walks mbeg + half, +2, +4, ...
+    unsigned v = (unsigned)(mbeg + half);
+    int cx = (int)(v % (unsigned)a.W); v /= (unsigned)a.W;
+    int cy = (int)(v % (unsigned)a.H); v /= (unsigned)a.H;
+    int cz = (int)(v % (unsigned)a.D); v /= (unsigned)a.D;
+    int cn = (int)v;
+
+    f32x16w acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    for (long long m = mbeg + half; m < mend + half; m += 2) {      // all 64 lanes iterate together (m - half is wave-uniform)
+        const bool mok = m < mend;
+        const float fa = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, (mok && yc) ? (unsigned)((m * a.ldy + l31) * 4) : OOBW, 0, 0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = cx * a.is + tdx[q], y = cy * a.is + tdy[q], z = cz * a.is + tdz[q];
+            const bool ok = mok && xc && tok[q] && (unsigned)z < (unsigned)a.Di && (unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi;
+            const long long e = cn * a.bs1r + ((long long)z * a.Hi + y) * a.Wi + x;
+            const float fb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ok ? (unsigned)((e * a.ld1 + l31) * 4) : OOBW, 0, 0));
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[q], 0, 0, 0);
+        }
+        cx += 2;
+        while (cx >= a.W) {
+            cx -= a.W;
+            if (++cy == a.H) { cy = 0; if (++cz == a.D) { cz = 0; ++cn; } }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!tok[q] || l31 >= Cin) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < a.Cout) atomic_add_f32(a.dw + ((long long)(t0 + q) * a.Cout + co) * Cin + l31, acc[q][r]);
+        }
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
@@ -180,6 +250,18 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         a.tap[t][3] = 0;
     }
     const int Cin = C1 + C2;
+    if (Cout <= 32 && Cin <= 32 && x2 == nullptr && W % 2 == 0) {
+        // narrow channels: independent waves, 4 taps each, fed straight from global memory
+        const int tap_groups = (ntaps + 3) / 4;
+        long long rows = (M * tap_groups + 4095) / 4096;            // ~4096 waves
+        rows = (rows + 1) / 2 * 2;
+        if (rows < 256) rows = 256;
+        a.mchunk = (int)rows;
+        const long long waves = ((M + rows - 1) / rows) * tap_groups;
+        hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, tap_groups, (int)rows);
+        FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+        return 0;
+    }
     const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + WT - 1) / WT);
     // split the voxel (reduction) axis so that ~1024 workgroups exist; chunks are multiples of the K-step
     long long nchunk = (1024 + tiles - 1) / tiles;

@@ -330,12 +330,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
             for (int k = 0; k < 8; ++k) {
                 if (t.w[k] != 0.f) {
                     const long long o = tap_off(t, k);
-                    float* df = dfeat + ((vbase + o) * C4 + cg) * 4;
-                    atomic_add_f32(df + 0, t.w[k] * gw.x);
-                    atomic_add_f32(df + 1, t.w[k] * gw.y);
-                    atomic_add_f32(df + 2, t.w[k] * gw.z);
-                    atomic_add_f32(df + 3, t.w[k] * gw.w);
-                    if (cg == 0) atomic_add_f32(ddens + vbase + o, t.w[k] * dLdd);
+                    if (wgt != 0.f) {            // empty space (d = 0) or a fully absorbed ray (T = 0): the feature gradient is exactly 0
+                        float* df = dfeat + ((vbase + o) * C4 + cg) * 4;
+                        atomic_add_f32(df + 0, t.w[k] * gw.x);
+                        atomic_add_f32(df + 1, t.w[k] * gw.y);
+                        atomic_add_f32(df + 2, t.w[k] * gw.z);
+                        atomic_add_f32(df + 3, t.w[k] * gw.w);
+                    }
+                    if (cg == 0 && dLdd != 0.f) atomic_add_f32(ddens + vbase + o, t.w[k] * dLdd);
                 }
             }
         }

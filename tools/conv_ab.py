@@ -36,7 +36,22 @@ def timeit(name, iters=10):
     return a.elapsed_time(b) / iters
 
 
-variants = os.environ.get("AB_VARIANTS", "0,1,2,3,4").split(",")
+# weight-gradient kernel on the same shapes
+for name, (Cout, C2, _) in shapes.items():
+    dy = torch.randn(M, Cout, device=dev)
+    dwp = torch.zeros(27, Cout, Cc + C2, device=dev)
+    f = lambda: co.conv_wgrad(dy, x, Cc, hbuf if C2 else None, C2, dwp, (B, D, D, D), (D, D, D), Cout, co.TAPS_3x3x3)
+    f()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        f()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    print("wgrad %-6s %.3f ms (%.1f TF)" % (name, ms, 2.0 * M * Cout * 27 * (Cc + C2) / ms / 1e9))
+
+variants = os.environ.get("AB_VARIANTS", "0").split(",")
 res = {}
 for rnd in range(4):
     for v in variants:

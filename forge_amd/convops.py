@@ -139,53 +139,96 @@ def _batch_stride_rows(x):
     return 0 if (n == 1 or x.stride(0) == D * H * W * C) else x.stride(0) // C
 
 
-class _Conv3x3x3Rows(torch.autograd.Function):
+class _ConvTapsRows(torch.autograd.Function):
+    """y[m] = bias + sum_t wp[t] @ cat(x1, x2)[voxel(m) * istride + taps[t]] on channels-last rows — the one autograd node behind
+    every convolution of the training path. `wp` [T][Cout][Cin] is the differentiable weight: callers build it from the module
+    parameter with differentiable torch ops (permute / reshape / pad), so autograd maps its gradient back to the parameter layout.
+      forward          forge_conv_igemm
+      d/dx  stride 1   forge_conv_igemm on dy with negated taps and transposed weights
+            stride 2   (2-D, D = 1) a transposed convolution: one phase GEMM per input-pixel parity over the taps of that parity
+      d/dwp            forge_conv_wgrad
+    """
+
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias):
-        n, D, H, W, C1 = x1.shape
+    def forward(ctx, x1, x2, wp, bias, taps, istride, out_spatial):
+        n, Di, Hi, Wi, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
-        Cout = weight.shape[0]
-        wp = pack_conv3d_weight(weight)
+        T, Cout, Cin = wp.shape
+        D, H, W = out_spatial
+        wpc = wp.detach().contiguous()
         out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x1.device)
         bs1 = _batch_stride_rows(x1)
         bs2 = 0 if x2 is None else _batch_stride_rows(x2)
-        conv_igemm(x1, C1, C1, x2, C2, C2, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
-                   TAPS_3x3x3, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
-        ctx.save_for_backward(x1, x2, wp)
-        ctx.has_bias = bias is not None
+        conv_igemm(x1, C1, C1, x2, C2, C2, wpc, bias, None, None, 1.0, None, None, None, out, None,
+                   (n, D, H, W), (Di, Hi, Wi), Cout, Cout, taps, istride=istride, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
+        ctx.save_for_backward(x1, x2, wpc)
+        ctx.meta = (tuple(taps), istride, (D, H, W), bias is not None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x1, x2, wp = ctx.saved_tensors
-        n, D, H, W, C1 = x1.shape
+        taps, istride, (D, H, W), has_bias = ctx.meta
+        n, Di, Hi, Wi, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
-        Cin, Cout = C1 + C2, wp.shape[1]
+        T, Cout, Cin = wp.shape
         dy = dy.contiguous()
-        grid, ig = (n, D, H, W), (D, H, W)
-        dx1 = dx2 = dw = db = None
+        dx1 = dx2 = dwp = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            # data gradient = the same implicit GEMM on dy with negated taps and transposed weights
-            wd = wp.transpose(1, 2).contiguous()
-            dx = torch.empty(n, D, H, W, Cin, dtype=torch.float32, device=dy.device)
-            conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, grid, ig, Cin, Cin,
-                       [(-a, -b, -c) for a, b, c in TAPS_3x3x3], epilogue=EPI_BIAS)
+            wd = wp.transpose(1, 2).contiguous()                                     # [T][Cin][Cout]
+            if istride == 1:
+                assert (D, H, W) == (Di, Hi, Wi)
+                dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
+                conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (D, H, W), Cin, Cin,
+                           [(-a, -b, -c) for a, b, c in taps], epilogue=EPI_BIAS)
+            else:
+                assert istride == 2 and D == 1 and Di == 1 and Hi == 2 * H and Wi == 2 * W and all(t[0] == 0 for t in taps)
+                dx = torch.zeros(n, 1, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
+                for ph_y in (0, 1):
+                    for ph_x in (0, 1):
+                        sel = [i for i, (_, ty, tx) in enumerate(taps) if (ty - ph_y) % 2 == 0 and (tx - ph_x) % 2 == 0]
+                        if not sel:
+                            continue                                                 # no tap reaches this pixel parity: gradient stays 0
+                        ptaps = [(0, (ph_y - taps[i][1]) // 2, (ph_x - taps[i][2]) // 2) for i in sel]
+                        conv_igemm(dy, Cout, Cout, None, 0, 0, wd[sel].contiguous(), None, None, None, 1.0, None, None, None, dx, None,
+                                   (n, 1, H, W), (1, H, W), Cin, Cin, ptaps, out_grid=(1, Hi, Wi), ostride=2, phase=(0, ph_y, ph_x),
+                                   epilogue=EPI_BIAS)
             dx1 = dx[..., :C1] if ctx.needs_input_grad[0] else None
             dx2 = dx[..., C1:] if (x2 is not None and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[2]:
             dwp = torch.zeros_like(wp)
-            conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, ig, Cout, TAPS_3x3x3, bs1=_batch_stride_rows(x1),
+            conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
                        bs2=0 if x2 is None else _batch_stride_rows(x2))
-            dw = dwp.permute(1, 2, 0).reshape(Cout, Cin, 3, 3, 3)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+        if has_bias and ctx.needs_input_grad[3]:
             db = dy.reshape(-1, Cout).sum(dim=0)
-        return dx1, dx2, dw, db
+        return dx1, dx2, dwp, db, None, None, None
+
+
+def conv_taps_rows(x1, x2, wp, bias, taps, istride=1, out_spatial=None):
+    if out_spatial is None:
+        out_spatial = tuple(x1.shape[1:4])
+    return _ConvTapsRows.apply(x1, x2, wp, bias, tuple(taps), int(istride), tuple(out_spatial))
+
+
+def _pack3d(weight):        # differentiable pack_conv3d_weight
+    co_, ci_ = weight.shape[:2]
+    return weight.reshape(co_, ci_, -1).permute(2, 0, 1)
 
 
 def conv3x3x3_rows(x1, x2, weight, bias):
     """Conv3d(k=3, padding=1, stride=1) of the channel concat (x1 | x2) on channels-last rows [n,D,H,W,C] with autograd.
     C1, C2 and Cout must be multiples of 32 (the GEMM K-step; the data gradient swaps the roles of Cin and Cout)."""
-    return _Conv3x3x3Rows.apply(x1, x2, weight, bias)
+    return conv_taps_rows(x1, x2, _pack3d(weight), bias, TAPS_3x3x3)
+
+
+def conv2d_rows(x, weight, bias, stride=1):
+    """Conv2d(k, stride, padding=k//2) on NHWC rows [N,H,W,C] with autograd (ResNet bottleneck convolutions in training)."""
+    co_, ci_, kh, kw = weight.shape
+    N, H, W, C = x.shape
+    taps = [(0, ky - kh // 2, kx - kw // 2) for ky in range(kh) for kx in range(kw)]
+    Ho, Wo = (H + 2 * (kh // 2) - kh) // stride + 1, (W + 2 * (kw // 2) - kw) // stride + 1
+    y = conv_taps_rows(x.reshape(N, 1, H, W, C), None, weight.reshape(co_, ci_, kh * kw).permute(2, 0, 1), bias, taps, stride, (1, Ho, Wo))
+    return y.reshape(N, Ho, Wo, co_)
 
 
 def conv3x3x3_rows_any(x, weight, bias):
@@ -201,7 +244,7 @@ def conv3x3x3_rows_any(x, weight, bias):
             bias = torch.nn.functional.pad(bias, (0, Cop - Cout))
     if x.shape[-1] != Cip:
         x = torch.nn.functional.pad(x, (0, Cip - x.shape[-1]))
-    y = _Conv3x3x3Rows.apply(x, None, weight, bias)
+    y = conv_taps_rows(x, None, _pack3d(weight), bias, TAPS_3x3x3)
     return y[..., :Cout] if Cop != Cout else y
 
 

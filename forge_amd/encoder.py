@@ -107,14 +107,17 @@ class Encoder3D(nn.Module):
         (channel c = c3d*32 + z, models/encoder.py:49)."""
         if hip_inference(self, img):
             return self._conv1_hip(self._trunk_hip(img))
+        if img.is_cuda and img.dtype == torch.float32:
+            # training / refinement: every convolution (trunk, conv1) forward + dgrad on the MFMA GEMM, wgrad on the wgrad kernels;
+            # BatchNorm (batch statistics / SyncBN) and activations are torch ops on the same channels-last tensors
+            z = self._trunk_autograd_hip(img)                              # [N,H,W,2048] NHWC rows
+            N, H, W, _ = z.shape
+            rows = z.reshape(N, H, W, 64, 32).permute(0, 4, 1, 2, 3).contiguous()     # view(-1,64,32,H,W) as rows [N,32,H,W,64]
+            y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
+            return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
         z_2d = self.feature_extraction(img)
         B, C, H, W = z_2d.shape
         z_3d = z_2d.view(-1, 64, 32, H, W)
-        if z_3d.is_cuda and z_3d.dtype == torch.float32:
-            # training: conv1 on the MFMA GEMM (forward, dgrad) + wgrad kernel; BN (batch stats) + LeakyReLU stay torch
-            rows = self._rows(z_3d)
-            y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
-            return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
         return self.conv1(z_3d)
 
     def get_density3D(self, z_3d):
@@ -138,6 +141,42 @@ class Encoder3D(nn.Module):
         if x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0:
             return self.fusion_feature.fuse_autograd_hip(x)             # training / refinement: HIP convs with autograd
         return self.fusion_feature(x, [self.fusion_feature.fusion_conv(x.mean(dim=1))])
+
+    @staticmethod
+    def _bn2d_rows(bn, rows, relu=True):
+        y = bn(rows.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        y = y if y.is_contiguous() else y.contiguous()
+        return torch.relu(y) if relu else y
+
+    def _trunk_autograd_hip(self, img):
+        """ResNet-50 trunk with an autograd graph on the HIP kernels. Stem: patch gather + one-tap GEMM (the image needs no
+        gradient), max-pool by torch; bottlenecks: 1x1 / 3x3 (stride 1 or 2) / 1x1 convolutions through convops.conv2d_rows."""
+        from . import _lib
+        fe = self.feature_extraction
+        conv0, bn0, pool = fe[0], fe[1], fe[3]
+        N, Ci, Hi, Wi = img.shape
+        kh, kw = conv0.kernel_size
+        s0, p0 = conv0.stride[0], conv0.padding[0]
+        Kp = ((kh * kw * Ci + 31) // 32) * 32
+        Hc, Wc = (Hi + 2 * p0 - kh) // s0 + 1, (Wi + 2 * p0 - kw) // s0 + 1
+        patches = torch.empty(N, 1, Hc, Wc, Kp, dtype=torch.float32, device=img.device)
+        _lib.check(_lib.lib().forge_im2col_nchw(_lib.ptr(img.detach().contiguous()), _lib.ptr(patches), N, Ci, Hi, Wi, kh, kw, s0, p0, Kp,
+                                                _lib.current_stream()), "forge_im2col_nchw")
+        w0 = torch.nn.functional.pad(conv0.weight.permute(0, 2, 3, 1).reshape(conv0.out_channels, -1), (0, Kp - kh * kw * Ci))[None]
+        x = co.conv_taps_rows(patches, None, w0, None, [(0, 0, 0)]).reshape(N, Hc, Wc, conv0.out_channels)
+        x = self._bn2d_rows(bn0, x)
+        x = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        for li in (4, 5, 6, 7):
+            for blk in fe[li]:
+                idn = x
+                out = self._bn2d_rows(blk.bn1, co.conv2d_rows(x, blk.conv1.weight, None))
+                out = self._bn2d_rows(blk.bn2, co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0]))
+                out = self._bn2d_rows(blk.bn3, co.conv2d_rows(out, blk.conv3.weight, None), relu=False)
+                if blk.downsample is not None:
+                    idn = self._bn2d_rows(blk.downsample[1], co.conv2d_rows(x, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0]),
+                                          relu=False)
+                x = torch.relu(out + idn)
+        return x
 
     def _head_autograd_hip(self, head, z):
         """A head (nn.Sequential of ConvTranspose3d / Conv3d / BatchNorm3d / LeakyReLU / ReLU, models/encoder.py:16-34) with an

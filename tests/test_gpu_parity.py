@@ -627,3 +627,47 @@ def test_heads_autograd_hip_vs_oracle(dev, golden):
     for n in names:
         e = wr["encoder_3d." + n].grad
         assert (params[n].grad.cpu() - e).abs().max().item() < 3e-3 * max(e.abs().max().item(), 1e-3 * gscale), n
+
+
+def test_conv2d_rows_strided_autograd_vs_torch(dev):
+    """2-D conv autograd on rows incl. the stride-2 data gradient (transposed conv by pixel parity) and strided wgrad."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(23)
+    for k, stride, Cin, Cout in ((3, 2, 64, 96), (1, 2, 64, 128), (3, 1, 32, 64), (1, 1, 96, 32)):
+        x = torch.randn(2, Cin, 12, 16, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xa, wa, None, stride=stride, padding=k // 2)
+        gy = torch.randn(ref.shape, generator=g)
+        ref.backward(gy)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+        wd = w.to(dev).requires_grad_(True)
+        out = co.conv2d_rows(xd, wd, None, stride=stride)
+        out.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+        tag = "k%d s%d" % (k, stride)
+        assert (out.detach().permute(0, 3, 1, 2).cpu() - ref.detach()).abs().max().item() < 5e-5 * ref.abs().max().item(), tag
+        assert (xd.grad.permute(0, 3, 1, 2).cpu() - xa.grad).abs().max().item() < 1e-4 * xa.grad.abs().max().item(), tag
+        assert (wd.grad.cpu() - wa.grad).abs().max().item() < 1e-4 * wa.grad.abs().max().item(), tag
+
+
+def test_get_feat3D_train_hip_vs_oracle(dev):
+    """Encoder (ResNet trunk + lift + conv1) in TRAIN mode through the HIP convs: output and a few gradients vs the oracle autograd."""
+    from forge_amd.encoder import Encoder3D
+    enc = Encoder3D(syn.kubric_config())
+    w = syn.seeded_state_dict({"encoder_3d." + k: v for k, v in enc.state_dict().items()}, 0)
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()})
+    enc = enc.to(dev).train()
+    img = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(31))
+    wr = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
+    ref = fo.get_feat3D(img, wr, training=True)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(32))
+    ref.backward(gy)
+    got = enc.get_feat3D(img.to(dev))
+    got.backward(gy.to(dev))
+    assert (got.detach().cpu() - ref.detach()).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
+    params = dict(enc.named_parameters())
+    for n in ("conv1.0.weight", "feature_extraction.7.2.conv3.weight", "feature_extraction.6.0.conv2.weight", "feature_extraction.5.0.downsample.0.weight",
+              "feature_extraction.4.0.conv1.weight", "feature_extraction.0.weight", "feature_extraction.7.0.bn2.weight"):
+        e = wr["encoder_3d." + n].grad
+        rel = (params[n].grad.cpu() - e).abs().max().item() / max(e.abs().max().item(), 1e-12)
+        assert rel < 2e-2, (n, rel)          # 53 layers of train-mode BN amplify fp32 reordering noise

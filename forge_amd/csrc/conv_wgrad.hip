@@ -263,11 +263,12 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         return 0;
     }
     const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + WT - 1) / WT);
-    // split the voxel (reduction) axis so that ~1024 workgroups exist; chunks are multiples of the K-step
+    // split the voxel (reduction) axis so that ~1024 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
+    // workgroup ends with 16 K fp32 atomics for its 128x128 tile, which must stay small next to its MFMA work
     long long nchunk = (1024 + tiles - 1) / tiles;
+    if (nchunk > M / 1024) nchunk = M / 1024;
     if (nchunk < 1) nchunk = 1;
     long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
-    if (mchunk < 4 * WK) mchunk = 4 * WK;
     a.mchunk = (int)mchunk;
     nchunk = (M + mchunk - 1) / mchunk;
     const long long grid = tiles * nchunk;

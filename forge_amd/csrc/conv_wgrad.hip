@@ -5,7 +5,7 @@
 // i.e. for every tap a GEMM  dW_t = dY^T (Cout x M)  @  X_t (M x Cin)  whose reduction dimension is the voxel index m.
 // Both operands are row-major [m][channels] in HBM = "k-major" for this GEMM, which is exactly what the 32x32x2 fp32 MFMA
 // wants from LDS without any transpose: lane l supplies A[i = l&31][k = l>>5], so a half-wave reads 32 CONSECUTIVE floats
-// of one LDS row (conflict-free ds_read_b32). Workgroup = 8 waves (4 along co x 2 along ci), tile 128(co) x 128(ci) for one
+// of one LDS row (conflict-free ds_read_b32). Workgroup = 4 waves (2 x 2, wave tile 64 x 64 with even/odd channel interleave: one 8-byte LDS read feeds two MFMAs), tile 128(co) x 128(ci) for one
 // tap over one M-chunk, K-step = 32 voxels, register-staged buffer loads (out-of-range rows / taps -> 0), double-buffered
 // LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
 // taps x tiles alone is only ~100 workgroups). dW must be zero-filled by the caller.
@@ -13,6 +13,7 @@
 // Replaces torch's conv3d weight-gradient (cuDNN/MIOpen) for the ConvGRU / fusion_conv / conv1 convolutions
 // (models/fusion.py:29-35,61-68; models/encoder.py:36-40) in training (scripts/kubric_trainer.py:56).
 #include "common.h"
+#include <cstdlib>
 
 namespace forge {
 
@@ -41,10 +42,10 @@ struct WgradArgs {
 
 constexpr int WT = 128, WK = 32;              // tile 128 x 128, K-step 32 voxels
 
-__global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][2][WK][WT]: A (dY) and B (X) images, row = voxel, col = channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                        // wave tile 32 (co) x 64 (ci)
+    const int wm = wave >> 1, wn = wave & 1;                        // 4 waves as 2 x 2, wave tile 64 (co) x 64 (ci)
     const int l31 = lane & 31, half = lane >> 5;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int Cin = a.C1 + a.C2;
@@ -67,35 +68,41 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
     const long long bsx = second ? a.bs2r : a.bs1r;
     const int dz = a.tap[t][0], dy_ = a.tap[t][1], dx = a.tap[t][2];
 
-    // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = tid >> 5 (+16), chunk = tid & 31)
-    const int srow[2] = {tid >> 5, (tid >> 5) + 16};
+    // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = (tid >> 5) + 8 j, chunk = tid & 31)
     const int sc4 = (tid & 31) << 2;
     const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = cx0 + sc4 < Cx;
-    float4 ra[2], rb[2];
-    // voxel coordinates of the two staged rows, advanced by WK rows per K-step (no per-step divisions)
-    int rx_[2], ry_[2], rz_[2], rn_[2];
+    float4 ra[4], rb[4];
+    // voxel coordinates of the staged rows, advanced by WK rows per K-step (no per-step divisions)
+    int rx_[4], ry_[4], rz_[4], rn_[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        unsigned v = (unsigned)(mbeg + srow[j]);
+    for (int j = 0; j < 4; ++j) {
+        unsigned v = (unsigned)(mbeg + (tid >> 5) + 8 * j);
         rx_[j] = (int)(v % (unsigned)a.W); v /= (unsigned)a.W;
         ry_[j] = (int)(v % (unsigned)a.H); v /= (unsigned)a.H;
         rz_[j] = (int)(v % (unsigned)a.D); v /= (unsigned)a.D;
         rn_[j] = (int)v;
     }
+    // loop-invariant scalars pulled out of the kernarg struct once (re-loading them inside the K-loop costs a scalar-memory
+    // round trip + an lgkmcnt(0) wait — which also drains the LDS queue — per use)
+    const unsigned ldy_u = (unsigned)a.ldy, ldx_u = (unsigned)ldx, bsx_u = (unsigned)bsx, mbeg_u = (unsigned)mbeg, mend_u = (unsigned)mend;
+    const unsigned ycol_off = (unsigned)(co0 + sc4), xcol_off = (unsigned)(cx0 + sc4);
+    const int is_ = a.is, Wg = a.W, Hg = a.H, Dg = a.D, Wi_ = a.Wi, Hi_ = a.Hi, Di_ = a.Di;
+    const int trow = tid >> 5;
     auto load_step = [&](int s) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long long m = mbeg + (long long)s * WK + srow[j];
-            const bool mok = m < mend;
-            ra[j] = buf_load16w(ry, (mok && ycol_ok) ? (unsigned)((m * a.ldy + co0 + sc4) * 4) : OOBW);
-            const int x = rx_[j] * a.is + dx, y = ry_[j] * a.is + dy_, z = rz_[j] * a.is + dz;
-            const bool ok = mok && xcol_ok && (unsigned)z < (unsigned)a.Di && (unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi;
-            const long long e = rn_[j] * bsx + ((long long)z * a.Hi + y) * a.Wi + x;
-            rb[j] = buf_load16w(rx, ok ? (unsigned)((e * ldx + cx0 + sc4) * 4) : OOBW);
+        for (int j = 0; j < 4; ++j) {
+            // 32-bit offsets: every operand span is < 2 GiB (checked on the host side)
+            const unsigned m = mbeg_u + (unsigned)(s * WK + trow + 8 * j);
+            const bool mok = m < mend_u;
+            ra[j] = buf_load16w(ry, (mok && ycol_ok) ? (m * ldy_u + ycol_off) * 4u : OOBW);
+            const int x = rx_[j] * is_ + dx, y = ry_[j] * is_ + dy_, z = rz_[j] * is_ + dz;
+            const bool ok = mok && xcol_ok && (unsigned)z < (unsigned)Di_ && (unsigned)y < (unsigned)Hi_ && (unsigned)x < (unsigned)Wi_;
+            const unsigned e = (unsigned)rn_[j] * bsx_u + (unsigned)((z * Hi_ + y) * Wi_ + x);
+            rb[j] = buf_load16w(rx, ok ? (e * ldx_u + xcol_off) * 4u : OOBW);
             rx_[j] += WK;                                         // advance to the row of the next K-step
-            while (rx_[j] >= a.W) {
-                rx_[j] -= a.W;
-                if (++ry_[j] == a.H) { ry_[j] = 0; if (++rz_[j] == a.D) { rz_[j] = 0; ++rn_[j]; } }
+            while (rx_[j] >= Wg) {
+                rx_[j] -= Wg;
+                if (++ry_[j] == Hg) { ry_[j] = 0; if (++rz_[j] == Dg) { rz_[j] = 0; ++rn_[j]; } }
             }
         }
     };
@@ -103,17 +110,21 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
         float* sa = smem + buf * (2 * WK * WT);
         float* sb = sa + WK * WT;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(sa + srow[j] * WT + sc4) = ra[j];
-            *reinterpret_cast<float4*>(sb + srow[j] * WT + sc4) = rb[j];
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(sa + ((tid >> 5) + 8 * j) * WT + sc4) = ra[j];
+            *reinterpret_cast<float4*>(sb + ((tid >> 5) + 8 * j) * WT + sc4) = rb[j];
         }
     };
 
-    f32x16w acc[2];
+    // accumulators: [co parity][ci parity]; MFMA row i <-> co = co0 + wm*64 + 2 i + pco, col j <-> ci = ci0 + wn*64 + 2 j + pci:
+    // one 8-byte LDS read per lane then feeds TWO MFMA operands (even / odd channel), halving the LDS instruction count.
+    f32x16w acc[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
 
     if (nsteps > 0) {
         load_step(0);
@@ -124,33 +135,36 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const WgradArgs a) {
         const int buf = s & 1;
         const bool more = s + 1 < nsteps;
         if (more) load_step(s + 1);
-        const float* sa = smem + buf * (2 * WK * WT) + wm * 32 + l31;
-        const float* sb = smem + buf * (2 * WK * WT) + WK * WT + wn * 64 + l31;
+        const float* sa = smem + buf * (2 * WK * WT) + wm * 64 + 2 * l31;
+        const float* sb = smem + buf * (2 * WK * WT) + WK * WT + wn * 64 + 2 * l31;
 #pragma unroll
         for (int kk = 0; kk < WK / 2; ++kk) {
             const int row = 2 * kk + half;
-            const float fa = sa[row * WT];
-            const float fb0 = sb[row * WT], fb1 = sb[row * WT + 32];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb1, acc[1], 0, 0, 0);
+            const float2 fa = *reinterpret_cast<const float2*>(sa + row * WT);
+            const float2 fb = *reinterpret_cast<const float2*>(sb + row * WT);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[1][1], 0, 0, 0);
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
     }
 
-    // D[i = co][j = ci]: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // D[i][j]: col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ci = ci0 + wn * 64 + j * 32 + l31;
+    for (int q = 0; q < 2; ++q) {
+        const int ci = ci0 + wn * 64 + 2 * l31 + q;
         if (ci >= Cin || (second ? ci - a.C1 >= a.C2 : ci >= a.C1)) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < a.Cout) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[j][r]);
-        }
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + p;
+                if (co < a.Cout) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[p][q][r]);
+            }
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // Narrow variant for Cout <= 32 and Cin <= 32 (the heads' 32->16 / 32->8 / 8->1 convolutions, channel-padded to 32 by the host
@@ -263,9 +277,11 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         return 0;
     }
     const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + WT - 1) / WT);
-    // split the voxel (reduction) axis so that ~1024 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
+    // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
     // workgroup ends with 16 K fp32 atomics for its 128x128 tile, which must stay small next to its MFMA work
-    long long nchunk = (1024 + tiles - 1) / tiles;
+    long long target = 4096;      // many short workgroups: 512 are resident at a time, a coarse split leaves a mostly empty last round
+    if (const char* e = getenv("FORGE_WGRAD_BLOCKS")) target = atoll(e);
+    long long nchunk = (target + tiles - 1) / tiles;
     if (nchunk > M / 1024) nchunk = M / 1024;
     if (nchunk < 1) nchunk = 1;
     long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
@@ -276,7 +292,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
     const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 64 KiB
     static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr_once;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
     FORGE_LAUNCH_CHECK("forge_conv_wgrad");
     return 0;
 }

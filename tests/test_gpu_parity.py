@@ -671,3 +671,24 @@ def test_get_feat3D_train_hip_vs_oracle(dev):
         e = wr["encoder_3d." + n].grad
         rel = (params[n].grad.cpu() - e).abs().max().item() / max(e.abs().max().item(), 1e-12)
         assert rel < 2e-2, (n, rel)          # 53 layers of train-mode BN amplify fp32 reordering noise
+
+
+def test_forge_two_scenes_10_views_vs_oracle(dev):
+    """b = 2 scenes, 5 input + 5 novel cameras each (the FORGE 10-view layout, models/model.py:117-143): batch strides in the GRU,
+    per-scene view ordering, view->volume indexing with b > 1."""
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(w)
+    model = model.to(dev).eval()
+    sample = syn.make_sample(2, 10, 256, 1.5, seed=11)
+    with torch.no_grad():
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+        oi, om = fo.forward_hot_path(sample["images"][:, :5], sample["cam_poses_cv2_canonicalized"][:, :5],
+                                     sample["cam_extrinsics_cv2_canonicalized"][:, :5], sample["K_cv2"][:, :5], w, cfg,
+                                     order_by_distance=True, render_extrinsics=sample["cam_extrinsics_cv2_canonicalized"],
+                                     render_K=sample["K_cv2"])
+    assert imgs.shape == (20, 3, 256, 256) and masks.shape == (20, 1, 256, 256)
+    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
+    assert (masks.cpu() - om).abs().max().item() < 5e-4

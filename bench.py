@@ -132,7 +132,6 @@ def time_kernel(fn, iters=20, warm=3):
 
 def kernel_rooflines(dev, B):
     """Hand-written kernels at the bench shapes: ALGORITHMIC bytes per launch / avg duration."""
-    from forge_amd import ops
     lib = _lib.lib()
     st = _lib.current_stream()
     out = {}

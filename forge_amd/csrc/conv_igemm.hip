@@ -78,7 +78,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-template <int BM, int BN, int NW, int MT = 1, bool PRIO = false>
+template <int BM, int BN, int NW, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WM = BM / (32 * MT), WN = NW / WM; // NW waves as WM(M) x WN(N); wave tile (32 MT) x (BN / WN)
     constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off(wm * (32 * MT) + i * 32 + l31, 2 * g + half));
 #pragma unroll
             for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const float4*>(sb + lds_off(wn * (BN / WN) + j * 32 + l31, 2 * g + half));
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -212,7 +211,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
@@ -501,21 +499,6 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         (void)attr_once; /* set once per process: safe under stream capture */                                             \
         hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
     } while (0)
-#define FORGE_LAUNCH_CONV_X(BMv, BNv, NWv, MTv, PRv)                                                                       \
-    do {                                                                                                                   \
-        const long long grid = nblk(BMv, BNv);                                                                             \
-        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
-        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv, MTv, PRv>,  \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        (void)attr_once;                                                                                                   \
-        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv, MTv, PRv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a); \
-    } while (0)
-        const char* var = getenv("FORGE_CONV_VARIANT");     // experiments on the big tile only
-        if (tile == 'A' && var && *var == '1') { FORGE_LAUNCH_CONV_X(128, 128, 8, 1, true); }
-        else if (tile == 'A' && var && *var == '2') { FORGE_LAUNCH_CONV_X(256, 128, 8, 2, false); }
-        else if (tile == 'A' && var && *var == '3') { FORGE_LAUNCH_CONV_X(256, 128, 8, 2, true); }
-        else if (tile == 'A' && var && *var == '4') { FORGE_LAUNCH_CONV_X(128, 128, 4, 2, false); }
-        else
         switch (tile) {
             case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
             case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
@@ -523,7 +506,6 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
             default: FORGE_LAUNCH_CONV(64, 64, 4); break;
         }
 #undef FORGE_LAUNCH_CONV
-#undef FORGE_LAUNCH_CONV_X
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

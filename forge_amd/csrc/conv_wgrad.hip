@@ -13,7 +13,6 @@
 // Replaces torch's conv3d weight-gradient (cuDNN/MIOpen) for the ConvGRU / fusion_conv / conv1 convolutions
 // (models/fusion.py:29-35,61-68; models/encoder.py:36-40) in training (scripts/kubric_trainer.py:56).
 #include "common.h"
-#include <cstdlib>
 
 namespace forge {
 
@@ -280,7 +279,6 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
     // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
     // workgroup ends with 16 K fp32 atomics for its 128x128 tile, which must stay small next to its MFMA work
     long long target = 4096;      // many short workgroups: 512 are resident at a time, a coarse split leaves a mostly empty last round
-    if (const char* e = getenv("FORGE_WGRAD_BLOCKS")) target = atoll(e);
     long long nchunk = (target + tiles - 1) / tiles;
     if (nchunk > M / 1024) nchunk = M / 1024;
     if (nchunk < 1) nchunk = 1;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""A/B of conv_igemm tile variants on the ConvGRU shapes, interleaved rounds in ONE process (FORGE_CONV_VARIANT is read per launch)."""
+"""conv_igemm tiles (FORGE_CONV_TILE=A|B|C|D, read per launch) and the wgrad kernel on the ConvGRU shapes, interleaved rounds in ONE
+process. (The setprio / 256x128 / 4-wave variants measured with this tool in round 1 were removed again: DESIGN.md tuning log.)"""
 import os
 import sys
 
@@ -51,12 +52,11 @@ for name, (Cout, C2, _) in shapes.items():
     ms = a.elapsed_time(b) / 5
     print("wgrad %-6s %.3f ms (%.1f TF)" % (name, ms, 2.0 * M * Cout * 27 * (Cc + C2) / ms / 1e9))
 
-variants = os.environ.get("AB_VARIANTS", "0").split(",")
+variants = os.environ.get("AB_TILES", "A,B,D").split(",")
 res = {}
 for rnd in range(4):
     for v in variants:
-        os.environ["FORGE_CONV_VARIANT"] = v
-        os.environ["FORGE_CONV_TILE"] = "A"
+        os.environ["FORGE_CONV_TILE"] = v
         for name in shapes:
             if rnd == 0:
                 run(name)
@@ -65,4 +65,4 @@ for (v, name), ts in sorted(res.items()):
     Cout, C2, _ = shapes[name]
     fl = 2.0 * M * Cout * 27 * (Cc + C2)
     best, med = min(ts[1:]), sorted(ts[1:])[len(ts[1:]) // 2]
-    print("variant %s %-6s min %.3f ms (%.1f TF)  median %.3f ms (%.1f TF)" % (v, name, best, fl / best / 1e9, med, fl / med / 1e9))
+    print("tile %s %-6s min %.3f ms (%.1f TF)  median %.3f ms (%.1f TF)" % (v, name, best, fl / best / 1e9, med, fl / med / 1e9))

@@ -711,7 +711,7 @@ def test_forge_joint_mode_forward_backward(dev):
     loss = torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, sample["fg_probabilities"][0].to(dev)) \
         + torch.nn.functional.mse_loss(pose["pred"], pose["gt"]) + 0.1 * torch.nn.functional.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))
     loss.backward()
-    for name in ("pose_head.4.weight", "encoder_traj.out.3.weight", "encoder_traj_2d.out.3.weight", "encoder_3d.conv1.0.weight",
+    for name in ("pose_head.4.weight", "encoder_traj.pose_head_1.3.weight", "encoder_traj_2d.conv.9.weight", "encoder_3d.conv1.0.weight",
                  "encoder_3d.fusion_feature.cells.0.out_gate.weight", "encoder_3d.feature_extraction.4.0.conv1.weight"):
         g = dict(model.named_parameters())[name].grad
         assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0, name

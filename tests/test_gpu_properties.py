@@ -1,0 +1,113 @@
+"""GPU (-m gpu): size-independent properties of the HIP kernels at BASELINE.json's FULL sizes (where the CPU oracle would take
+minutes): linearity, pass-through, adjointness of every backward kernel against its forward (<J v, w> == <v, J^T w>)."""
+import pytest
+import torch
+
+from forge_amd import convops as co, ops, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _dot(a, b):
+    return (a.double() * b.double()).sum().item()
+
+
+def _cams(V, img, dev):
+    _, extr, _ = syn.orbit_cameras(10, 1.5, 15.0)
+    E = extr[:V]
+    K = syn.intrinsics(img) / 2.0
+    return torch.cat([E[:, :3, :3].reshape(V, 9), E[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1), K[0, 2].expand(V, 1),
+                      K[1, 2].expand(V, 1)], dim=1).contiguous().to(dev)
+
+
+@pytest.mark.parametrize("D,C", [(64, 128), (128, 16)])
+def test_rotate_full_size_linearity_passthrough_adjoint(dev, D, C):
+    """configs 2-4: 128-channel 64^3 feature grids / 128^3 grids (models/rotate.py:115-120)."""
+    g = torch.Generator(device="cpu").manual_seed(D)
+    n = 3
+    poses, _, _ = syn.orbit_cameras(n, 1.5, 12.0)
+    T = poses[0:1] @ torch.inverse(poses)
+    e = 0.5 * (D - 1) / D
+    xf = torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(n, 12).to(dev)
+    mode = torch.tensor([0, 1, 1], dtype=torch.int32, device=dev)
+    mk = lambda: torch.randn(n, D, D, D, C, generator=g).permute(0, 4, 1, 2, 3).to(dev)
+    a, b = mk(), mk()
+    Ra, Rb = ops.rotate_warp(a, xf, mode), ops.rotate_warp(b, xf, mode)
+    assert torch.equal(Ra[0], a[0])                                                    # view 0 passes through bit-exactly
+    lin = ops.rotate_warp(a + 2.0 * b, xf, mode)
+    assert (lin - (Ra + 2.0 * Rb)).abs().max().item() < 1e-4
+    # adjointness of forge_rotate_bwd: <R a, w> == <a, R^T w>
+    w = mk()
+    a_ = a.clone().requires_grad_(True)
+    (ops.rotate_warp(a_, xf, mode) * w).sum().backward()
+    lhs, rhs = _dot(Ra, w), _dot(a, a_.grad)
+    assert abs(lhs - rhs) < 1e-5 * max(abs(lhs), 1.0)
+
+
+def test_render_full_size_linearity_and_adjoint(dev):
+    """config 4/5: 128^3 render grid, 128^2 rays x 64 samples x 4 views sharing one volume."""
+    D, C, V, Hr, S = 128, 16, 4, 128, 64
+    feat, dens = syn.blob_volumes(1, D, C, seed=3)
+    feat, dens = feat.to(dev), dens.to(dev)
+    feat2 = torch.randn_like(feat)
+    cam = _cams(V, 256, dev)
+    v2v = torch.zeros(V, dtype=torch.int32, device=dev)
+    h = [0.5 * (D - 1) / D] * 3
+    r = lambda f, d: ops.render_rays(f, d, cam, v2v, Hr, Hr, S, 0.5, 2.0, h, True)
+    f1, o1, z1 = r(feat, dens)
+    f2, o2, z2 = r(feat2, dens)
+    f3, o3, z3 = r(feat + 3.0 * feat2, dens)
+    assert torch.equal(o1, o2) and torch.equal(z1, z2)                                 # opacity / depth do not depend on the features
+    assert (f3 - (f1 + 3.0 * f2)).abs().max().item() < 1e-4 * max(1.0, f3.abs().max().item())
+    assert o1.max().item() <= 1.0 + 1e-5 or dens.max().item() > 1.0                    # unclamped densities may overshoot
+    zero = r(feat, torch.zeros_like(dens))
+    assert zero[0].abs().max().item() == 0.0 and zero[1].abs().max().item() == 0.0     # empty volume -> exact zeros
+    # adjointness of forge_render_bwd w.r.t. the (linear) feature path: <J f, w> == <f, J^T w>
+    w = torch.randn_like(f1)
+    f_ = feat.clone().requires_grad_(True)
+    (r(f_, dens)[0] * w).sum().backward()
+    lhs, rhs = _dot(f1, w), _dot(feat, f_.grad)
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_conv_full_size_adjoints(dev):
+    """The ConvGRU gates convolution at full size (M = 32^3, 128+128 -> 256 channels): forward vs data gradient vs weight
+    gradient are mutually adjoint — <conv(x;W), y> == <x, dgrad(y;W)> == <W, wgrad(x,y)>."""
+    g = torch.Generator().manual_seed(1)
+    D = 32
+    x1 = torch.randn(1, D, D, D, 128, generator=g).to(dev).requires_grad_(True)
+    x2 = torch.randn(1, D, D, D, 128, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(256, 256, 3, 3, 3, generator=g) * 0.02).to(dev).requires_grad_(True)
+    y = torch.randn(1, D, D, D, 256, generator=g).to(dev)
+    out = co.conv3x3x3_rows(x1, x2, w, None)
+    (out * y).sum().backward()
+    lhs = _dot(out.detach(), y)
+    assert abs(lhs - (_dot(x1.detach(), x1.grad) + _dot(x2.detach(), x2.grad))) < 2e-5 * max(abs(lhs), 1.0)
+    assert abs(lhs - _dot(w.detach(), w.grad)) < 2e-5 * max(abs(lhs), 1.0)
+    # the fused inference epilogue (bias + identity affine, slope 1) equals the raw conv
+    wp = co.pack_conv3d_weight(w.detach())
+    fused = torch.empty_like(out)
+    one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    co.conv_igemm(x1.detach(), 128, 128, x2.detach(), 128, 128, wp, zero, one, zero, 1.0, None, None, None, fused, None, (1, D, D, D), (D, D, D),
+                  256, 256, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+    assert torch.equal(fused, out.detach())
+
+
+def test_graph_replay_is_deterministic(dev):
+    """forward kernels are bit-deterministic run to run (no atomics on the inference path)."""
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+    s = {k: v.to(dev) for k, v in syn.make_sample(1, 5, 256, 1.5, seed=3).items()}
+    with torch.no_grad():
+        a = [t.clone() for t in model(s, syn.SyntheticDataset(1.5), dev)]
+        b = [t.clone() for t in model(s, syn.SyntheticDataset(1.5), dev)]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

@@ -50,7 +50,9 @@ def kubric_config(img_size=256, volume_size=1.0, n_pts_per_ray=64, min_depth=0.5
                     "scale_rotate": 0.01, "scale_translate": 0.01, "backbone": "resnet"},
         "render": {"n_pts_per_ray": n_pts_per_ray, "volume_size": volume_size, "min_depth": min_depth,
                    "max_depth": max_depth, "camera_z": camera_z, "k_size": 5},
-        "train": {"use_gt_pose": use_gt_pose, "canonicalize": True, "parameter": parameter},
+        "train": {"use_gt_pose": use_gt_pose, "canonicalize": True, "parameter": parameter, "lr": 0.0008, "accumulation_step": 1,
+                  "adjust_iter_num": [17500, 26000, 34000, 50000]},
+        "loss": {"recon_rgb": 5.0, "recon_mask": 1.0, "perceptual_img": 0.0, "regu_origin_proj": 0.0},
     })
 
 

@@ -1,0 +1,95 @@
+"""Row f1 — loss assembly and the optimisation step around the model, mirroring the reference's
+scripts/kubric_compute_loss.py (:9-42 `compute_reconstruction_loss`, :121-172 `compute_all_loss_nvs`),
+scripts/kubric_trainer.py (:21-59: clip-norm 10 (Kubric) / 5 (OmniObject3D), gradient accumulation, optimizer step) and
+utils/train_utils.py (:149-164 `adjust_lr`). Same names, argument order and return tuples, so the reference's trainer can call
+them; the reference's own functions also work unchanged on the forge_amd models (they only call `model(sample, dataset, device)`).
+
+Difference: the per-term `.item()` calls of the reference (4-8 device synchronisations per iteration) are replaced by ONE
+device->host copy of the stacked loss terms.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _publish(losses, terms):
+    """one D2H copy for all logged scalars"""
+    if terms:
+        vals = torch.stack([v.detach() for v in terms.values()]).cpu().tolist()
+        losses.update(dict(zip(terms.keys(), vals)))
+    return losses
+
+
+def compute_reconstruction_loss(config, epoch, sample, dataset, model, losses, device, perceptual_loss=None):
+    """GT-pose training (kubric_train_pose_3D.py): model returns 2t views per scene = [3v/2v cross views | all-view fusion]."""
+    rendered_imgs, rendered_masks = model(sample, dataset, device)
+    clips = sample["images"].to(device)
+    masks = sample["fg_probabilities"].to(device)
+    b, t, c, h, w = clips.shape
+    target_imgs, target_masks = clips.reshape(b * t, c, h, w), masks.reshape(b * t, 1, h, w)
+    rendered_imgs = rendered_imgs.reshape(b, 2 * t, c, h, w)
+    rendered_masks = rendered_masks.reshape(b, 2 * t, 1, h, w)
+    terms = {
+        "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
+        "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
+        "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
+        "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
+    }
+    if config.loss.perceptual_img > 0:
+        tgt = target_imgs.reshape(b, t, c, h, w).repeat(1, 2, 1, 1, 1).reshape(b * 2 * t, c, h, w)
+        terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
+    loss = sum(terms.values())
+    return loss, _publish(losses, terms), rendered_imgs, rendered_masks
+
+
+def compute_all_loss_nvs(config, epoch, sample, dataset, model, losses, device, perceptual_loss=None):
+    """Joint training (kubric_train_joint.py): 5 input + novel views, pose / translation MSE, optional origin regulariser."""
+    rendered_imgs, rendered_masks, origin_proj, pose = model(sample, dataset, device)
+    clips, clips_nvs = sample["images"][:, :5].to(device), sample["images"][:, 5:].to(device)
+    masks, masks_nvs = sample["fg_probabilities"][:, :5].to(device), sample["fg_probabilities"][:, 5:].to(device)
+    b, t, c, h, w = clips.shape
+    t_all = t + clips_nvs.shape[1]
+    rendered_imgs = rendered_imgs.reshape(b, t_all, c, h, w)
+    rendered_masks = rendered_masks.reshape(b, t_all, 1, h, w)
+    terms = {
+        "recon_img": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t], clips),
+        "recon_mask": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t], masks),
+        "recon_img_nvs": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:], clips_nvs),
+        "recon_mask_nvs": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:], masks_nvs),
+        "pose": F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]),
+        "trans": F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]),
+    }
+    if config.loss.perceptual_img > 0:
+        tgt = torch.cat([clips, clips_nvs], dim=1).reshape(b * t_all, c, h, w)
+        terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
+    if getattr(config.loss, "regu_origin_proj", 0) > 0:
+        terms["regu_origin"] = config.loss.regu_origin_proj * F.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))
+    loss = sum(terms.values())
+    return loss, _publish(losses, terms), rendered_imgs, rendered_masks
+
+
+def adjust_lr(config, optimizer, iter_num, adjust_iter_num):
+    """utils/train_utils.py:149-164: lr = base * 0.5^k at the k-th milestone (OmniObject3D: linear warm-up over 500 iterations)."""
+    lr = None
+    if config.dataset.name == "omniobject3d":
+        lr = config.train.lr * iter_num / 500
+    for k, it in enumerate(adjust_iter_num[:4]):
+        if iter_num == it:
+            lr = config.train.lr * 0.5 ** (k + 1)
+    if lr is not None:
+        for group in optimizer.param_groups:
+            group["lr"] = lr
+    return lr
+
+
+def train_step(config, sample, dataset, model, optimizer, device, loss_func=compute_reconstruction_loss, epoch=0, batch_idx=0,
+               perceptual_loss=None):
+    """One iteration of scripts/kubric_trainer.py:47-59 (without the logging): loss, backward, clip, optimizer step."""
+    max_norm = 5.0 if config.dataset.name == "omniobject3d" else 10.0
+    accumulation = getattr(config.train, "accumulation_step", 1)
+    loss, losses, imgs, masks = loss_func(config, epoch, sample, dataset, model, {}, device, perceptual_loss)
+    (loss / accumulation).backward()
+    if (batch_idx + 1) % accumulation == 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm, norm_type=2.0)
+        optimizer.step()
+        optimizer.zero_grad()
+    return loss.detach(), losses

@@ -146,3 +146,14 @@ def test_look_at_view_transform_kat_and_shim():
     R, T = nvs.nvs_cameras(1.5)
     assert R.shape == (28, 3, 3) and torch.allclose(T.norm(dim=1), torch.full((28,), 1.5), atol=1e-5)
     assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(28, 3, 3), atol=1e-5)
+
+
+def test_adjust_lr_schedule():
+    """utils/train_utils.py:149-164 + config/kubric/gt_pose.yaml:41,54"""
+    from forge_amd import train
+    cfg = syn.kubric_config()
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=cfg.train.lr)
+    for k, it in enumerate(cfg.train.adjust_iter_num):
+        assert train.adjust_lr(cfg, opt, it, cfg.train.adjust_iter_num) == pytest.approx(cfg.train.lr * 0.5 ** (k + 1))
+        assert opt.param_groups[0]["lr"] == pytest.approx(cfg.train.lr * 0.5 ** (k + 1))
+    assert train.adjust_lr(cfg, opt, 123, cfg.train.adjust_iter_num) is None

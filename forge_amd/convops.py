@@ -100,6 +100,18 @@ class PackCache:
         return self.val
 
 
+_SPLITK_WS = {}
+SPLITK_WS_BYTES = 128 << 20
+
+
+def _splitk_workspace(device):
+    """Per-device scratch for forge_conv_igemm's split-K mode (allocated once, outside any graph capture by the warm-up passes)."""
+    ws = _SPLITK_WS.get(device)
+    if ws is None:
+        ws = _SPLITK_WS[device] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
                bs1=0, bs2=0, lift=0):
@@ -113,7 +125,8 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
     _lib.check(_lib.lib().forge_conv_igemm(
         p(in1), C1, ld1, int(bs1), p(in2), C2, ld2, int(bs2), p(wp), p(bias), p(scale), p(shift), float(slope), p(residual), p(aux_h), p(aux_z),
         p(out), p(out2), n, D, H, W, istride, Di, Hi, Wi, Cout, ldo, _taps_array(taps), len(taps), ostride,
-        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.current_stream()), "forge_conv_igemm")
+        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), p(_splitk_workspace(out.device)), SPLITK_WS_BYTES,
+        _lib.current_stream()), "forge_conv_igemm")
     return out
 
 

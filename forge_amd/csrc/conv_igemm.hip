@@ -57,6 +57,7 @@ struct ConvArgs {
     int os, pz, py, px, Do, Ho, Wo;        // output voxel = (z os + pz, y os + py, x os + px) in an (Do,Ho,Wo) grid
     int epi;
     int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
+    float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
 
@@ -93,12 +94,16 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int ntile_n = (a.Cout + BN - 1) / BN;
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = (int)(bid_all % (unsigned)a.ksplit);           // K-slice of this workgroup (split-K for small M x N problems)
+    const unsigned bid = bid_all / (unsigned)a.ksplit;
     const long long m0 = (long long)(bid / ntile_n) * BM;
     const int n0 = (bid % ntile_n) * BN;
     const int Cin = a.C1 + a.C2;
     const int kchunks = Cin / BK;
-    const int nsteps = a.ntaps * kchunks;
+    const int nsteps_all = a.ntaps * kchunks;
+    const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
+    const int nsteps = s_end - s_begin;
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
@@ -174,9 +179,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    int t = 0, kc = 0;
-    prep_tap(0);
-    load_step(0, 0);
+    int t = s_begin / kchunks, kc = s_begin - t * kchunks;
+    prep_tap(t);
+    load_step(t, kc);
     store_step(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
@@ -275,6 +280,21 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
     };
+    if (a.ksplit > 1) {                                             // raw partial sums; conv_splitk_epilogue_kernel finishes the job
+        float* wsl = a.ws + (long long)ks * M * a.Cout;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (col < a.Cout && m < M) wsl[m * a.Cout + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     switch (a.epi) {
         case EPI_BIAS: epilogue(std::integral_constant<int, EPI_BIAS>{}); break;
         case EPI_AFFINE_ACT: epilogue(std::integral_constant<int, EPI_AFFINE_ACT>{}); break;
@@ -283,6 +303,49 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
+
+
+// Second half of a split-K launch: out = epilogue(sum_ks ws[ks][m][col]). One thread per 4 output channels; deterministic
+// (fixed summation order), memory-bound (ksplit x M x Cout floats read once).
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs a) {
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const int C4 = a.Cout >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * C4) return;
+    const long long m = idx / C4;
+    const int col = (int)(idx - m * C4) << 2;
+    float4 v = *reinterpret_cast<const float4*>(a.ws + m * a.Cout + col);
+    for (int k = 1; k < a.ksplit; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(a.ws + ((long long)k * M + m) * a.Cout + col);
+        v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    }
+    long long orow = m;
+    if ((a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W)) {
+        long long q = m;
+        const int x = (int)(q % a.W); q /= a.W;
+        const int y = (int)(q % a.H); q /= a.H;
+        const int z = (int)(q % a.D); q /= a.D;
+        orow = ((q * a.Do + (z * a.os + a.pz)) * a.Ho + (y * a.os + a.py)) * a.Wo + (x * a.os + a.px);
+    }
+    float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int cc = col + c;
+        float t = r[c] + (a.bias ? a.bias[cc] : 0.f);
+        if (a.epi == EPI_AFFINE_ACT) {
+            t = fmaf(t, a.scale[cc], a.shift[cc]);
+            if (a.residual) t += a.residual[orow * a.ldr + cc];
+            t = t > 0.f ? t : t * a.slope;
+        }
+        if (a.lift > 0) {
+            const int Cl = a.Cout / a.lift, zc = cc / Cl, c2 = cc - zc * Cl;
+            const long long HW = (long long)a.H * a.W, nn = m / HW, hw = m - nn * HW;
+            a.out[((nn * a.lift + zc) * HW + hw) * Cl + c2] = t;
+        } else {
+            a.out[orow * a.ldo + cc] = t;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Narrow-N variant for Cout <= 16 (render-feature / density convs of the heads, conv_rgb): a 128-wide
@@ -443,7 +506,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const float* aux_h, const float* aux_z, float* out, float* out2,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, int lift, forge_stream_t stream) {
+                                int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
@@ -466,7 +529,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
     a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
-                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     for (int t = 0; t < MAX_TAPS; ++t) {
@@ -489,9 +552,23 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         if (Cout > 64 && nblk(128, 128) < 512) tile = nblk(64, 128) >= 512 ? 'B' : 'D';
         if (Cout <= 64 && nblk(128, 64) < 512) tile = 'D';
         if (const char* f = getenv("FORGE_CONV_TILE")) { if (*f >= 'A' && *f <= 'D' && (Cout > 64 || *f == 'C' || *f == 'D')) tile = *f; }
+        // split-K: when even the smallest tile leaves the chip under-filled (ResNet at small batch: M = 5120), slice the
+        // tap x channel reduction across workgroups; partial tiles go to the caller's workspace and a light second kernel
+        // sums them in a fixed order (deterministic) and applies the epilogue
+        {
+            const long long nb = tile == 'A' ? nblk(128, 128) : tile == 'B' ? nblk(64, 128) : tile == 'C' ? nblk(128, 64) : nblk(64, 64);
+            const int nsteps = ntaps * ((C1 + C2) / BK);
+            if (splitk_ws && nb < 512 && nsteps >= 16 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0) {
+                long long k = (1024 + nb - 1) / nb;
+                if (k > 8) k = 8;
+                if (k > nsteps / 8) k = nsteps / 8;
+                while (k > 1 && k * M * Cout * 4 > splitk_ws_bytes) --k;
+                if (k > 1) { a.ksplit = (int)k; a.ws = splitk_ws; }
+            }
+        }
 #define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
     do {                                                                                                                   \
-        const long long grid = nblk(BMv, BNv);                                                                             \
+        const long long grid = nblk(BMv, BNv) * a.ksplit;                                                                  \
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
         const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
         static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv>,            \
@@ -506,6 +583,10 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
             default: FORGE_LAUNCH_CONV(64, 64, 4); break;
         }
 #undef FORGE_LAUNCH_CONV
+        if (a.ksplit > 1) {
+            const long long total = M * (Cout / 4);
+            hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+        }
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
     return 0;

@@ -140,6 +140,10 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *   lift > 0 (epilogue 1, 2-D conv i.e. D = 1): fuses the 2D->3D feature lift of models/encoder.py:49 into the store —
  *            GEMM column j = z*(Cout/lift) + c of row (n, h, w) is written to out[n][z][h][w][c] (a channels-last
  *            (n, lift, H, W) volume with Cout/lift channels). The caller orders the weight rows accordingly.
+ *   splitk_ws (nullable, splitk_ws_bytes): scratch for split-K. When the M x Cout tile grid alone cannot fill the chip
+ *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
+ *            per tile; raw partial tiles go to splitk_ws[slice][M][Cout] and a second kernel sums them in a fixed order and
+ *            applies the epilogue (epilogues 0 and 1 only). NULL disables it. Results are deterministic either way.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
                      const float* wp,
@@ -147,7 +151,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const float* aux_h, const float* aux_z, float* out, float* out2,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, int lift, forge_stream_t stream);
+                     int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
 
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
  *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)

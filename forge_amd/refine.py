@@ -1,0 +1,81 @@
+"""Row f2 — test-time pose optimisation (kubric_eval.py:412-530 `do_refinement`, demo.py:115-188 `refine_pose`): thousands of
+forward+backward passes through rotate -> fuse -> heads -> render w.r.t. the 7-D relative poses (quaternion + translation) of the
+non-reference views, features frozen. This is the reference's largest wall-clock consumer (5000 iterations per instance by default).
+
+Every kernel of the loop is a hand-written HIP kernel: the pose gradient flows through forge_render_bwd (camera gradients),
+forge_rotate_bwd (affine gradients) and the data-gradient GEMMs of the ConvGRU / heads; weight gradients are switched off.
+Same optimiser as the reference (Adam, lr 1e-3 rotation / 5e-4 translation, ExponentialLR with gamma = 1), same loss
+(recon_rgb * MSE(rgb) + recon_mask * MSE(mask)); the per-iteration host-side pose metric (`.cpu()` every iteration in the
+reference, kubric_eval.py:508-517) is evaluated only every `log_every` iterations.
+"""
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import geo_utils
+from .model import chose_selected, sequence_from_distance
+
+
+def _render_views(model, config, dataset, features, pose7, K, device):
+    b, t = features.shape[:2]
+    D = features.shape[3]
+    rel = model.encoder_traj.toSE3(pose7)                                              # [b(t-1),4,4]
+    can_p = dataset.get_canonical_pose_cv2(device=device)
+    can_e = dataset.get_canonical_extrinsics_cv2(device=device)
+    poses = (can_p.unsqueeze(0) @ rel)
+    extr = torch.inverse(poses).reshape(b, t - 1, 4, 4)
+    poses = torch.cat([can_p.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), poses.reshape(b, t - 1, 4, 4)], dim=1)
+    extr = torch.cat([can_e.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), extr], dim=1)
+    ft = model.rotate(voxels=features, camPoses_cv2=poses, grid_size=D)
+    ft = chose_selected(ft, sequence_from_distance(poses[:, :, :3, 3]))
+    fused = model.encoder_3d.fuse(ft)
+    dens = model.encoder_3d.get_density3D(fused)
+    feat = model.encoder_3d.get_render_features(fused)
+    cams = {"R": extr.reshape(b * t, 4, 4)[:, :3, :3], "T": extr.reshape(b * t, 4, 4)[:, :3, 3], "K": K.reshape(b * t, 3, 3)}
+    v2v = torch.arange(b, device=device, dtype=torch.int32).repeat_interleave(t)
+    imgs, masks, depths, origin = model.render(cams, feat, dens, return_origin_proj=True, render_depth=True, view2vol=v2v)
+    return imgs, masks, depths, origin, poses
+
+
+def refine_poses(model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, iter_num=500, log_every=0):
+    """features [b,t,C,D,H,W] (detached encoder output), poses_cam [b(t-1),7] initial (quat, trans), target_imgs [b*t,3,H,W],
+    target_masks [b*t,1,H,W], K [b,t,3,3]. Returns (refined poses [b(t-1),7], list of losses, seconds per iteration)."""
+    model.eval()
+    frozen = [p for p in model.parameters() if p.requires_grad]
+    for p in frozen:                                   # no weight gradients: only the poses are optimised
+        p.requires_grad_(False)
+    try:
+        features = features.detach().to(device)
+        rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
+        trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
+        lr = 0.001
+        opt = torch.optim.Adam([{"params": rot, "lr": lr}, {"params": trans, "lr": lr / 2.0}], lr=lr)
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, 1.0)
+        w_rgb, w_mask = config.loss.recon_rgb, config.loss.recon_mask
+        history = []
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for it in range(iter_num + 1):
+            pose7 = torch.cat([F.normalize(rot), trans], dim=1)
+            imgs, masks, _, _, _ = _render_views(model, config, dataset, features, pose7, K.to(device), device)
+            loss = w_rgb * F.mse_loss(imgs, target_imgs) + w_mask * F.mse_loss(masks, target_masks)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            sched.step()
+            if log_every and it % log_every == 0:
+                history.append(loss.item())
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / (iter_num + 1)
+        return torch.cat([F.normalize(rot), trans], dim=1).detach(), history, dt
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+
+
+def pose_errors(pred7, gt44):
+    """rotation error (deg, quaternion angle as utils/eval_utils.py:14-33) and translation error (L2) per pose"""
+    gq = geo_utils.mat2quat(gt44)
+    d = (F.normalize(pred7[:, :4]) * F.normalize(gq[:, :4])).sum(dim=1).abs().clamp(max=1.0)
+    return torch.rad2deg(2 * torch.acos(d)), (pred7[:, 4:] - gq[:, 4:]).norm(dim=1)

@@ -64,3 +64,50 @@ def test_world1_is_a_noop():
     assert fd.all_reduce_scalars([1.5, 2.0], "cpu") == [1.5, 2.0]
     assert fd.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     assert fd.psnr_from_sse(1.0, 100.0) == pytest.approx(20.0)
+
+
+def _ray_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import forge_oracle as fo
+    from forge_amd import dist as fd, synthetic as syn
+    fd.init(backend="gloo")
+    feat, dens = syn.blob_volumes(1, 12, 4, seed=2)
+    _, extr, _ = syn.orbit_cameras(3, 1.5, 10.0)
+    Kh = fo.halve_intrinsics(syn.intrinsics(32)[None].repeat(3, 1, 1))
+    cam = torch.cat([extr[:, :3, :3].reshape(3, 9), extr[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1)
+    v2v = torch.zeros(3, dtype=torch.int32)
+    h = fo.grid_half_extent(12, 1.0)
+
+    def oracle_fn(f, d, c, v2v_, Hr, Wr, S, zmin, zmax, half, want_depth):      # CPU stand-in with the ops.render_rays signature
+        K = torch.zeros(c.shape[0], 3, 3)
+        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 2] = c[:, 12], c[:, 13], c[:, 14], c[:, 15], 1.0
+        r = fo.render_rays(f[v2v_.long()], d[v2v_.long()], c[:, :9].reshape(-1, 3, 3), c[:, 9:12], K, Hr, Wr, S, zmin, zmax, 1.0, want_depth)
+        C = f.shape[1]
+        outs = [r[..., :C].permute(0, 3, 1, 2), r[..., C:C + 1].permute(0, 3, 1, 2)]
+        if want_depth:
+            outs.append(r[..., C + 1:].permute(0, 3, 1, 2))
+        return tuple(outs)
+    got = fd.render_rays_sharded(feat, dens, cam, v2v, 16, 16, 24, 0.5, 2.0, (h, h, h), True, render_fn=oracle_fn)
+    ref = oracle_fn(feat, dens, cam, v2v, 16, 16, 24, 0.5, 2.0, (h, h, h), True)
+    q.put((rank, [float((a - b).abs().max()) for a, b in zip(got, ref)], [tuple(a.shape) for a in got]))
+    torch.distributed.destroy_process_group()
+
+
+def test_ray_sharded_render_world2():
+    """config-5 style per-ray sharding: two ranks each march half of the image rows (principal point shifted by the band origin),
+    all_gather the bands, and both end up with exactly the full-image result."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ray_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, errs, shapes in res:
+        assert shapes == [(3, 4, 16, 16), (3, 1, 16, 16), (3, 1, 16, 16)]
+        assert max(errs) < 1e-6

@@ -293,6 +293,20 @@ def main():
     dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
     views = world * B * V_OUT * args.steps
 
+    # ---- the same steps with the sample handed over as (pinned) HOST buffers, as a DataLoader would: PCIe-inclusive rate (never `value`)
+    pcie_views_per_s = None
+    if rank == 0 and world == 1:
+        host = {k: v.pin_memory() for k, v in sample_cpu.items()}
+        feed = (lambda: graphed(host)) if not args.no_graph else None
+        if feed is not None:
+            feed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                feed()
+            torch.cuda.synchronize()
+            pcie_views_per_s = B * V_OUT * args.steps / (time.perf_counter() - t1)
+
     # ---- per-stage HIP-event split of one more step (outside the timed region)
     rec, undo = stage_timers(model)
     for _ in range(3):
@@ -347,6 +361,7 @@ def main():
                        "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
             "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "gflop_per_step_algorithmic": B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB),
+            "views_per_s_with_host_to_device_copy": pcie_views_per_s,
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, ref = cpu_baseline(sample_cpu, weights, cfg)

@@ -6,6 +6,7 @@ sharded across ranks and only scalar metrics (losses / SSE / counts / time) are 
 Gradient all-reduce in training is torch DDP's bucketed RCCL all-reduce, unchanged.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -24,8 +25,13 @@ def init(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            if backend == "nccl" and torch.cuda.device_count() < world:
+                # more ranks than GPUs (a multi-rank dry run on a 1-GPU box): RCCL refuses two ranks on one device, gloo does not
+                print("forge_amd.dist: %d ranks on %d GPU(s) - falling back to gloo, ranks share devices"
+                      % (world, torch.cuda.device_count()), file=sys.stderr)
+                backend = "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return rank, local_rank, world
 

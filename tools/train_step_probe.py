@@ -46,3 +46,52 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print("train step b=%d: %.1f ms/step, %.1f rendered views/s (fwd+bwd+Adam), loss %.5f, peak mem %.1f GB"
       % (b, dt * 1e3, b * 10 / dt, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
+
+if os.environ.get("TRAIN_PROFILE"):
+    # per-launch HIP-event timing of every conv GEMM / wgrad launch of one step, grouped by shape
+    from forge_amd import convops as co
+    rec = []
+
+    def timed(kind, fn, label_of):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            rec.append((kind,) + label_of(*a, **k) + (e0, e1))
+            return r
+        return wrapper
+
+    def lab_igemm(in1, C1, ld1, in2, C2, ld2, wp, *rest, **k):
+        grid, in_grid, Cout = rest[9], rest[10], rest[11]
+        M = grid[0] * grid[1] * grid[2] * grid[3]
+        return (M, Cout, C1 + C2, wp.shape[0], k.get("istride", 1), k.get("ostride", 1))
+
+    def lab_wgrad(dy, x1, C1, x2, C2, dwp, grid, in_grid, Cout, taps, istride=1, **k):
+        M = grid[0] * grid[1] * grid[2] * grid[3]
+        return (M, Cout, C1 + C2, len(taps), istride, 1)
+
+    co.conv_igemm = timed("igemm", co.conv_igemm, lab_igemm)
+    co.conv_wgrad = timed("wgrad", co.conv_wgrad, lab_wgrad)
+    import forge_amd.encoder as _e, forge_amd.fusion as _f, forge_amd.volume_render as _v
+    for mod in (_e, _f, _v):
+        for name in ("conv_igemm", "conv_wgrad"):
+            if hasattr(mod, name):
+                setattr(mod, name, getattr(co, name))
+    step()
+    torch.cuda.synchronize()
+    agg = {}
+    for kind, M, N, K, T, is_, os_, e0, e1 in rec:
+        key = (kind, M, N, K, T, is_, os_)
+        ms = e0.elapsed_time(e1)
+        a = agg.setdefault(key, [0, 0.0])
+        a[0] += 1
+        a[1] += ms
+    tot = {"igemm": 0.0, "wgrad": 0.0}
+    print("%-6s %8s %5s %5s %4s %2s %2s %5s %9s %8s" % ("kind", "M", "N", "Cin", "taps", "is", "os", "calls", "ms total", "TF"))
+    for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        kind, M, N, K, T, is_, os_ = key
+        tf = 2.0 * M * N * K * T * n / (ms * 1e-3) / 1e12
+        tot[kind] += ms
+        print("%-6s %8d %5d %5d %4d %2d %2d %5d %9.3f %8.1f" % (kind, M, N, K, T, is_, os_, n, ms, tf))
+    print("totals (event-timed, eager, incl. launch gaps):", tot)

@@ -112,6 +112,18 @@ def _splitk_workspace(device):
     return ws
 
 
+TILE_NAMES = {"A": "128, 128, 8", "B": "64, 128, 8", "C": "128, 64, 8", "D": "64, 64, 4", "E": "128, 32, 4"}
+
+
+def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo):
+    """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only)."""
+    import ctypes
+    tile, ks = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(epilogue), int(ldo), SPLITK_WS_BYTES,
+                                                ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
+    return chr(tile.value), ks.value
+
+
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
                bs1=0, bs2=0, lift=0):

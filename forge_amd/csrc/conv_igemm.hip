@@ -23,6 +23,7 @@
 // The K order inside a 32-chunk is permuted identically for A and B: a lane's 16-byte read
 // supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of MFMA j.
 #include "common.h"
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -498,9 +499,75 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Launch plan: tile shape and split-K factor from a makespan model of the 256-CU chip (times in us).
+//   tiles      A 128x128 / 8 waves   B 64x128 / 8   C 128x64 / 8   D 64x64 / 4   E 128x32 / 4 (Cout <= 32)
+//   tile_us    = BM x BN x K-steps / (8000 x eff): CU-time of one tile with the CU's resident workgroups saturating the MFMA
+//                pipes; eff = measured rate of each tile on M = 131072 problems relative to tile A (130 TF)
+//   makespan   = full waves of 256 x occupancy workgroups, then the remainder with r = ceil(rem / 256) workgroups per CU running at
+//                g(r)/g(occ) of the saturated rate (a lone workgroup cannot overlap its own barriers: g(1) = 0.8); floored by the
+//                operand/result traffic at 4 TB/s (short-K 1x1 convs are traffic-bound; narrow N tiles re-read A); plus a
+//                prologue/epilogue term per round, larger for tile A whose 2 resident workgroups overlap it worst
+//   split-K    slices K across workgroups when the chip is under-filled (M = 5120: ResNet, one scene); costs the reduction kernel
+// Constants fitted on tools/conv_plan_sweep.py (52 shapes x 30 plans, 1 and 4 scenes): chosen plans are within 0.2 % of the
+// per-shape best in total. FORGE_CONV_TILE=A..E / FORGE_CONV_KSPLIT=n override the model (that tool).
+struct ConvPlan { char tile; int ksplit; };
+
+static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes) {
+    struct Tile { char id; int bm, bn, occ; double eff, ov; };
+    static const Tile tiles[5] = {{'A', 128, 128, 2, 1.000, 4.0}, {'B', 64, 128, 3, 0.983, 1.0}, {'C', 128, 64, 3, 0.969, 1.0},
+                                  {'D', 64, 64, 5, 0.980, 1.0}, {'E', 128, 32, 4, 0.915, 1.0}};
+    static const int splits[6] = {1, 2, 3, 4, 6, 8};
+    auto g = [](long long o) { return o <= 1 ? 0.8 : o == 2 ? 0.85 : o == 3 ? 0.96 : 1.0; };
+    const int nsteps = ntaps * (Cin / BK);
+    const double K = (double)ntaps * Cin;
+    ConvPlan best{'D', 1};
+    double best_us = 1e300;
+    const char* ft = getenv("FORGE_CONV_TILE");
+    const char* fk = getenv("FORGE_CONV_KSPLIT");
+    for (const Tile& t : tiles) {
+        if (ft && *ft != t.id) continue;
+        if (!ft && t.id == 'E' && Cout > 32) continue;
+        const long long ntn = (Cout + t.bn - 1) / t.bn;
+        const long long nb = ((M + t.bm - 1) / t.bm) * ntn;
+        for (int k : splits) {
+            if (fk && atoi(fk) != k) continue;
+            if (k > 1 && (!can_split || nsteps / k < 8 || (long long)k * M * Cout * 4 > ws_bytes)) continue;
+            const long long wgs = nb * k, slots = 256LL * t.occ;
+            const long long full = wgs / slots, rem = wgs - full * slots;
+            const double tile_us = (double)t.bm * t.bn * ((nsteps + k - 1) / k) / (8000.0 * t.eff);
+            double us = (double)full * t.occ * tile_us;
+            long long rounds = full;
+            if (rem > 0) {
+                const long long r = (rem + 255) / 256;
+                us += (double)r * tile_us * g(t.occ) / g(r);
+                ++rounds;
+            }
+            const double traffic_us = ((double)M * K * 4.0 * ntn + (double)Cout * K * 4.0 + (double)M * Cout * 4.0) / 4.0e6;
+            if (us < traffic_us) us = traffic_us;
+            us += (double)(rounds + 1) * t.ov * sqrt((double)t.bm * t.bn / 16384.0);
+            if (k > 1) us += 3.0 + (double)(k + 1) * M * Cout * 4.0 / 2.0e6;
+            if (us < best_us) { best_us = us; best = ConvPlan{t.id, k}; }
+        }
+    }
+    return best;
+}
+
 }  // namespace forge
 
 using namespace forge;
+
+extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int epilogue, int ldo, long long splitk_ws_bytes,
+                                     int* tile, int* ksplit) {
+    FORGE_REQUIRE(tile && ksplit && M > 0 && Cout > 0 && Cin > 0 && ntaps > 0, FORGE_EINVAL, "forge_conv_igemm_plan: bad argument");
+    if (Cout <= 16) { *tile = 'N'; *ksplit = 1; return 0; }                         // conv_igemm_n16_kernel
+    const ConvPlan pl = plan_conv(M, Cout, Cin, ntaps,
+                                  splitk_ws_bytes > 0 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
+                                  splitk_ws_bytes);
+    *tile = pl.tile; *ksplit = pl.ksplit;
+    return 0;
+}
 
 // Generic entry; see include/forge_hip.h for the contract.
 extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
@@ -547,28 +614,12 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
     } else {
-        // Tile choice: the chip wants >= 2 workgroups per CU (512); take the largest tile that still gives that many,
-        // else the smallest one. FORGE_CONV_TILE=A|B|C|D forces a variant (experiments).
-        //   A 128x128 / 8 waves   B 64x128 / 8 waves   C 128x64 / 8 waves   D 64x64 / 4 waves
+        const ConvPlan pl = plan_conv(M, Cout, C1 + C2, ntaps,
+                                      splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
+                                      splitk_ws_bytes);
+        const char tile = pl.tile;
+        if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-        char tile = Cout > 64 ? 'A' : 'C';
-        if (Cout > 64 && nblk(128, 128) < 512) tile = nblk(64, 128) >= 512 ? 'B' : 'D';
-        if (Cout <= 64 && nblk(128, 64) < 512) tile = 'D';
-        if (const char* f = getenv("FORGE_CONV_TILE")) { if (*f >= 'A' && *f <= 'D' && (Cout > 64 || *f == 'C' || *f == 'D')) tile = *f; }
-        // split-K: when even the smallest tile leaves the chip under-filled (ResNet at small batch: M = 5120), slice the
-        // tap x channel reduction across workgroups; partial tiles go to the caller's workspace and a light second kernel
-        // sums them in a fixed order (deterministic) and applies the epilogue
-        {
-            const long long nb = tile == 'A' ? nblk(128, 128) : tile == 'B' ? nblk(64, 128) : tile == 'C' ? nblk(128, 64) : nblk(64, 64);
-            const int nsteps = ntaps * ((C1 + C2) / BK);
-            if (splitk_ws && nb < 512 && nsteps >= 16 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0) {
-                long long k = (1024 + nb - 1) / nb;
-                if (k > 8) k = 8;
-                if (k > nsteps / 8) k = nsteps / 8;
-                while (k > 1 && k * M * Cout * 4 > splitk_ws_bytes) --k;
-                if (k > 1) { a.ksplit = (int)k; a.ws = splitk_ws; }
-            }
-        }
 #define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
     do {                                                                                                                   \
         const long long grid = nblk(BMv, BNv) * a.ksplit;                                                                  \
@@ -583,6 +634,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
             case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
             case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
             case 'C': FORGE_LAUNCH_CONV(128, 64, 8); break;
+            case 'E': FORGE_LAUNCH_CONV(128, 32, 4); break;
             default: FORGE_LAUNCH_CONV(64, 64, 4); break;
         }
 #undef FORGE_LAUNCH_CONV

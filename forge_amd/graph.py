@@ -30,7 +30,9 @@ class GraphedForward:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        # thread_local: only calls made by THIS thread are checked against the capture; the RCCL watchdog thread of a live
+        # process group may keep polling its events while we capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = model(self.static_in, dataset, device)
 
     def __call__(self, sample=None):

@@ -153,6 +153,13 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
                      int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
 
+/* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
+ * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
+ * *ksplit the number of K-slices (1 = no split-K). Pure host arithmetic (a makespan model of the 256-CU chip), no launch; lets a
+ * caller size the split-K workspace (ksplit * M * Cout floats) and lets profilers attribute launches to kernel instantiations. */
+int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int epilogue, int ldo, long long splitk_ws_bytes,
+                          int* tile, int* ksplit);
+
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
  *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)
  * dy [M][ldy] is the upstream gradient of the conv output on the (n,D,H,W) row grid; x1/x2, is, Di.. as in forge_conv_igemm.

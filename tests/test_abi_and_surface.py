@@ -157,3 +157,18 @@ def test_adjust_lr_schedule():
         assert train.adjust_lr(cfg, opt, it, cfg.train.adjust_iter_num) == pytest.approx(cfg.train.lr * 0.5 ** (k + 1))
         assert opt.param_groups[0]["lr"] == pytest.approx(cfg.train.lr * 0.5 ** (k + 1))
     assert train.adjust_lr(cfg, opt, 123, cfg.train.adjust_iter_num) is None
+
+
+def test_conv_plan_is_host_arithmetic_and_sane():
+    """forge_conv_igemm_plan runs without a GPU: plans for the step's shapes (csrc/conv_igemm.hip: plan_conv)."""
+    from forge_amd import convops as co
+    assert co.conv_plan(32768, 256, 256, 27, co.EPI_GRU_GATES, 128) == ("A", 1)          # ConvGRU gates: 512 tiles = 2 per CU
+    assert co.conv_plan(262144, 16, 32, 27, co.EPI_AFFINE_ACT, 16)[0] == "N"             # Cout <= 16 kernel
+    assert co.conv_plan(786432, 32, 32, 27, co.EPI_BIAS, 32) == ("E", 1)                 # 32-channel tile
+    t, k = co.conv_plan(5120, 512, 512, 9, co.EPI_AFFINE_ACT, 512)                       # ResNet layer4 3x3 at one scene: split-K
+    assert k > 1 and t in "ABCD"
+    assert co.conv_plan(5120, 512, 512, 9, co.EPI_GRU_OUT, 512)[1] == 1                  # GRU epilogues cannot be split
+    for M in (1, 63, 5120, 20480, 131072):
+        for N in (17, 32, 64, 96, 2048):
+            t, k = co.conv_plan(M, N, 64, 1, co.EPI_BIAS, N)
+            assert t in "ABCDE" and k == 1                                               # 2 K-steps: never split

@@ -321,6 +321,36 @@ def test_conv_igemm_concat_affine_residual(dev):
     assert (out.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max().item() < 5e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("tile", list("ABCDE"))
+def test_conv_igemm_every_tile_and_splitk(dev, tile, monkeypatch):
+    """every workgroup tile x split-K factor of the launch plan (forced through the experiment overrides) on a ragged problem
+    (M = 630 rows, Cout = 96: partial tiles in both directions) with the folded-BN + residual + LeakyReLU epilogue."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(7)
+    Cin, Cout, dims = 64, 96, (5, 7, 9)
+    x = torch.randn(2, Cin, *dims, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5
+    b, sc, sh = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(2, Cout, *dims, generator=g)
+    bc = lambda v: v[None, :, None, None, None]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(x, w, b, padding=1) * bc(sc) + bc(sh) + res, 0.01)
+    xd, wd, rd = _rows(x).to(dev), co.pack_conv3d_weight(w).to(dev), _rows(res).to(dev)
+    M = 2 * dims[0] * dims[1] * dims[2]
+    seen = 0
+    for k in (1, 2, 3, 4, 6):
+        monkeypatch.setenv("FORGE_CONV_TILE", tile)
+        monkeypatch.setenv("FORGE_CONV_KSPLIT", str(k))
+        if co.conv_plan(M, Cout, Cin, 27, co.EPI_AFFINE_ACT, Cout) != (tile, k):
+            continue
+        seen += 1
+        out = torch.full((2, *dims, Cout), float("nan"), device=dev)
+        co.conv_igemm(xd, Cin, Cin, None, 0, 0, wd, b.to(dev), sc.to(dev), sh.to(dev), 0.01, rd, None, None, out, None,
+                      (2, *dims), dims, Cout, Cout, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+        err = (out.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max().item()
+        assert err < 5e-5 * ref.abs().max().item(), (tile, k, err)
+    assert seen >= 4
+
+
 def test_conv_igemm_strided2d_and_transpose_phases(dev):
     from forge_amd import convops as co
     g = torch.Generator().manual_seed(2)

@@ -41,14 +41,19 @@ struct WgradArgs {
 
 constexpr int WT = 128, WK = 32;              // tile 128 x 128, K-step 32 voxels
 
+// CIW = width of the Cin tile: 128 (4 waves as 2 x 2, wave tile 64 co x 64 ci, even/odd interleave on both operands), or for
+// narrow inputs 64 / 32 (4 waves as 4 x 1, wave tile 32 co x CIW ci) so that a Cin <= 64 problem (conv1: 64, the transpose conv
+// of the heads: 32) does not execute a mostly empty 128-wide tile.
+template <int CIW>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int P = CIW == 128 ? 2 : 1, Q = CIW == 32 ? 1 : 2;    // accumulators per wave: P co-parities x Q ci-parities
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][2][WK][WT]: A (dY) and B (X) images, row = voxel, col = channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                        // 4 waves as 2 x 2, wave tile 64 (co) x 64 (ci)
+    const int wm = CIW == 128 ? wave >> 1 : wave, wn = CIW == 128 ? wave & 1 : 0;
     const int l31 = lane & 31, half = lane >> 5;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int Cin = a.C1 + a.C2;
-    const int cot = (a.Cout + WT - 1) / WT, cit = (Cin + WT - 1) / WT;
+    const int cot = (a.Cout + WT - 1) / WT, cit = (Cin + CIW - 1) / CIW;
     const int nchunk = (int)((M + a.mchunk - 1) / a.mchunk);
     unsigned bid = blockIdx.x;
     const int chunk = bid % nchunk; bid /= nchunk;
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const long long mbeg = (long long)chunk * a.mchunk;
     const long long mend = mbeg + a.mchunk < M ? mbeg + a.mchunk : M;
     const int nsteps = (int)((mend - mbeg + WK - 1) / WK);
-    const int co0 = co_t * WT, ci0 = ci_t * WT;
+    const int co0 = co_t * WT, ci0 = ci_t * CIW;
 
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
     const bool second = ci0 >= a.C1;                                 // this ci tile lives in x2
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = (tid >> 5) + 8 j, chunk = tid & 31)
     const int sc4 = (tid & 31) << 2;
-    const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = cx0 + sc4 < Cx;
+    const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = sc4 < CIW && cx0 + sc4 < Cx;
     float4 ra[4], rb[4];
     // voxel coordinates of the staged rows, advanced by WK rows per K-step (no per-step divisions)
     int rx_[4], ry_[4], rz_[4], rn_[4];
@@ -117,11 +122,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     // accumulators: [co parity][ci parity]; MFMA row i <-> co = co0 + wm*64 + 2 i + pco, col j <-> ci = ci0 + wn*64 + 2 j + pci:
     // one 8-byte LDS read per lane then feeds TWO MFMA operands (even / odd channel), halving the LDS instruction count.
-    f32x16w acc[2][2];
+    f32x16w acc[P][Q];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < Q; ++q)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
 
@@ -134,17 +139,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         const int buf = s & 1;
         const bool more = s + 1 < nsteps;
         if (more) load_step(s + 1);
-        const float* sa = smem + buf * (2 * WK * WT) + wm * 64 + 2 * l31;
-        const float* sb = smem + buf * (2 * WK * WT) + WK * WT + wn * 64 + 2 * l31;
+        const float* sa = smem + buf * (2 * WK * WT) + (P == 2 ? wm * 64 + 2 * l31 : wm * 32 + l31);
+        const float* sb = smem + buf * (2 * WK * WT) + WK * WT + (Q == 2 ? wn * 64 + 2 * l31 : l31);
 #pragma unroll
         for (int kk = 0; kk < WK / 2; ++kk) {
             const int row = 2 * kk + half;
-            const float2 fa = *reinterpret_cast<const float2*>(sa + row * WT);
-            const float2 fb = *reinterpret_cast<const float2*>(sb + row * WT);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc[1][1], 0, 0, 0);
+            float fa[2], fb[2];
+            if constexpr (P == 2) { const float2 v = *reinterpret_cast<const float2*>(sa + row * WT); fa[0] = v.x; fa[1] = v.y; }
+            else fa[0] = fa[1] = sa[row * WT];
+            if constexpr (Q == 2) { const float2 v = *reinterpret_cast<const float2*>(sb + row * WT); fb[0] = v.x; fb[1] = v.y; }
+            else fb[0] = fb[1] = sb[row * WT];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p], fb[q], acc[p][q], 0, 0, 0);
         }
         if (more) store_step(buf ^ 1);
         __syncthreads();
@@ -152,14 +160,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     // D[i][j]: col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int ci = ci0 + wn * 64 + 2 * l31 + q;
+    for (int q = 0; q < Q; ++q) {
+        const int ci = ci0 + (Q == 2 ? wn * 64 + 2 * l31 + q : l31);
         if (ci >= Cin || (second ? ci - a.C1 >= a.C2 : ci >= a.C1)) continue;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * half) + p;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = co0 + (P == 2 ? wm * 64 + 2 * i + p : wm * 32 + i);
                 if (co < a.Cout) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[p][q][r]);
             }
     }
@@ -275,22 +284,38 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         FORGE_LAUNCH_CHECK("forge_conv_wgrad");
         return 0;
     }
-    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + WT - 1) / WT);
+    const int ciw = (x2 == nullptr && Cin <= 32) ? 32 : (x2 == nullptr && Cin <= 64) ? 64 : WT;
+    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + ciw - 1) / ciw);
     // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
-    // workgroup ends with 16 K fp32 atomics for its 128x128 tile, which must stay small next to its MFMA work
+    // workgroup ends with up to 16 K fp32 atomics for its tile, which must stay small next to its MFMA work. When that leaves the
+    // chip under-filled (ResNet at one scene: M = 5120, a handful of tiles) the floor drops to 8 K-steps: those launches are
+    // latency-bound and more, shorter workgroups are what shortens them.
     long long target = 4096;      // many short workgroups: 512 are resident at a time, a coarse split leaves a mostly empty last round
     long long nchunk = (target + tiles - 1) / tiles;
     if (nchunk > M / 1024) nchunk = M / 1024;
     if (nchunk < 1) nchunk = 1;
+    if (tiles * nchunk < 512) {
+        nchunk = (512 + tiles - 1) / tiles;
+        if (nchunk > M / 256) nchunk = M / 256;
+        if (nchunk < 1) nchunk = 1;
+    }
     long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
     a.mchunk = (int)mchunk;
     nchunk = (M + mchunk - 1) / mchunk;
     const long long grid = tiles * nchunk;
     FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
     const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 64 KiB
-    static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr_once;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+#define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
+    do {                                                                                                                             \
+        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel<CIWv>,                               \
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+        (void)attr_once;                                                                                                             \
+        hipLaunchKernelGGL(conv_wgrad_kernel<CIWv>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);                  \
+    } while (0)
+    if (ciw == 32) FORGE_LAUNCH_WGRAD(32);
+    else if (ciw == 64) FORGE_LAUNCH_WGRAD(64);
+    else FORGE_LAUNCH_WGRAD(128);
+#undef FORGE_LAUNCH_WGRAD
     FORGE_LAUNCH_CHECK("forge_conv_wgrad");
     return 0;
 }

@@ -1,0 +1,99 @@
+"""GPU (-m gpu): the data-parallel TRAINING path (kubric_train_pose_3D.py:119-130): the model wrapped in torch
+DistributedDataParallel, one scene per rank, gradients all-reduced in buckets. Two ranks share the single GPU of the test box, so
+the process group is gloo (RCCL refuses two ranks on one device; the bucketing / hook logic of DDP is backend-independent); the
+averaged gradients must equal those of ONE process that sees both scenes as a batch of 2."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["encoder_3d.fusion_feature.cells.0.conv_gate.weight", "encoder_3d.conv1.0.weight", "encoder_3d.density_head.6.weight",
+        "encoder_3d.features_head.0.weight", "encoder_3d.feature_extraction.0.weight", "render.conv_rgb.6.weight",
+        "encoder_3d.fusion_feature.fusion_norm.bias"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dev):
+    from forge_amd import synthetic as syn
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).train()
+    for m in model.modules():                       # running statistics: per-rank batch statistics would differ from the batch-of-2 run
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    return cfg, model
+
+
+def _loss(model, sample, dev):
+    from forge_amd import synthetic as syn
+    imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+    b = sample["images"].shape[0]
+    tgt_i = sample["images"].repeat(1, 2, 1, 1, 1).reshape(b * 10, 3, 256, 256)
+    tgt_m = sample["fg_probabilities"].repeat(1, 2, 1, 1, 1).reshape(b * 10, 1, 256, 256)
+    return 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, tgt_m)
+
+
+def _sample(seeds, dev):
+    from forge_amd import synthetic as syn
+    parts = [syn.make_sample(1, 5, 256, 1.5, seed=s) for s in seeds]
+    return {k: torch.cat([p[k] for p in parts], dim=0).to(dev) for k in parts[0]}
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from forge_amd import dist as fd
+    fd.init()                                       # 2 ranks on 1 GPU -> gloo, both on cuda:0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _, model = _build(dev)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
+    loss = _loss(ddp, _sample([100 + rank], dev), dev)
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    out = {k: named[k].grad.detach().cpu().numpy() for k in KEYS}      # numpy: pickled by value (tensors travel as fds of a process that may be gone)
+    q.put((rank, float(loss.detach()), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_equal_one_process_batch_of_two():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # every rank holds the same (averaged) gradients
+    for k in KEYS:
+        assert (res[0][2][k] == res[1][2][k]).all(), k
+    # one process, both scenes as a batch of 2: mean loss over 2 scenes -> the same averaged gradients
+    dev = torch.device("cuda:0")
+    _, model = _build(dev)
+    loss = _loss(model, _sample([100, 101], dev), dev)
+    loss.backward()
+    assert abs(float(loss.detach()) - 0.5 * (res[0][1] + res[1][1])) < 1e-5 * max(1.0, abs(float(loss.detach())))
+    named = dict(model.named_parameters())
+    for k in KEYS:
+        ref = named[k].grad.detach().cpu()
+        err = (torch.from_numpy(res[0][2][k]) - ref).abs().max().item()
+        assert err < 2e-4 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())

@@ -9,7 +9,7 @@ last_state_list, torch.stack of every h) is not reproduced — only the returned
 import torch
 import torch.nn as nn
 
-from . import convops as co
+from . import _lib, convops as co
 
 
 def hip_inference(module, x):
@@ -17,6 +17,80 @@ def hip_inference(module, x):
     and no autograd graph. Training keeps the stock torch ops for the dense convs (their backward kernels are
     the next row to be hand-written), the HIP rotate/render ops have their own backward kernels."""
     return x.is_cuda and x.dtype == torch.float32 and not module.training and not torch.is_grad_enabled()
+
+
+class _GRUCellRows(torch.autograd.Function):
+    """One ConvGRU step (models/fusion.py:29-35) on channels-last rows with an autograd graph. Both convolutions run on the MFMA
+    implicit-GEMM kernel (bias epilogue), data / weight gradients on the same GEMM / the wgrad kernel, and each element-wise half of
+    the cell is one HIP kernel per direction (csrc/gru.hip) instead of ~23 generic tensor ops per step.
+      x [b,D,H,W,C] (a view with a batch stride is fine), h [b,D,H,W,C] dense, wg [27][2C][2C], wo [27][C][2C] packed weights."""
+
+    @staticmethod
+    def forward(ctx, x, h, wg, bg, wo, bo):
+        b, D, H, W, C = h.shape
+        M = b * D * H * W
+        dev = h.device
+        h = h.contiguous()
+        wgc, woc = wg.detach().contiguous(), wo.detach().contiguous()
+        bsx = co._batch_stride_rows(x)
+        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
+        g = new(2 * C)
+        co.conv_igemm(x, C, C, h, C, C, wgc, bg, None, None, 1.0, None, None, None, g, None, grid, ig, 2 * C, 2 * C, taps, epilogue=co.EPI_BIAS, bs1=bsx)
+        z, r, hr = new(C), new(C), new(C)
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        _lib.check(L.forge_gru_gates_fwd(p(g), p(h), p(z), p(r), p(hr), M, C, st()), "forge_gru_gates_fwd")
+        cand = new(C)
+        co.conv_igemm(x, C, C, hr, C, C, woc, bo, None, None, 1.0, None, None, None, cand, None, grid, ig, C, C, taps, epilogue=co.EPI_BIAS, bs1=bsx)
+        hn = new(C)
+        _lib.check(L.forge_gru_state_fwd(p(cand), p(h), p(z), p(hn), M, C, st()), "forge_gru_state_fwd")     # cand <- tanh(conv)
+        ctx.save_for_backward(x, h, z, r, hr, cand, wgc, woc)
+        ctx.has_bias = (bg is not None, bo is not None)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        x, h, z, r, hr, cand, wg, wo = ctx.saved_tensors
+        b, D, H, W, C = h.shape
+        M = b * D * H * W
+        dev = h.device
+        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        ntaps = [(-a, -b_, -c) for a, b_, c in taps]
+        bsx = co._batch_stride_rows(x)
+        new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        dhn = dhn.contiguous()
+        dh, dz, dc = new(C), new(C), new(C)
+        _lib.check(L.forge_gru_state_bwd(p(dhn), p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
+        # candidate conv: c = conv([x | h r], wo)
+        dxh = new(2 * C)                                                                   # (dx | d(h r))
+        co.conv_igemm(dc, C, C, None, 0, 0, wo.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh, None, grid, ig,
+                      2 * C, 2 * C, ntaps, epilogue=co.EPI_BIAS)
+        dwo = dbo = dwg = dbg = None
+        if ctx.needs_input_grad[4]:
+            dwo = torch.zeros_like(wo)
+            co.conv_wgrad(dc, x, C, hr, C, dwo, grid, ig, C, list(taps), bs1=bsx)
+        if ctx.has_bias[1] and ctx.needs_input_grad[5]:
+            dbo = dc.reshape(M, C).sum(dim=0)
+        # gates: g = conv([x | h], wg); z = sigmoid(g[:C]), r = sigmoid(g[C:]), hr = h r
+        dg = new(2 * C)
+        _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), M, C, st()), "forge_gru_gates_bwd")
+        dxh2 = new(2 * C)
+        co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, wg.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh2, None, grid, ig,
+                      2 * C, 2 * C, ntaps, epilogue=co.EPI_BIAS)
+        if ctx.needs_input_grad[2]:
+            dwg = torch.zeros_like(wg)
+            co.conv_wgrad(dg, x, C, h, C, dwg, grid, ig, 2 * C, list(taps), bs1=bsx)
+        if ctx.has_bias[0] and ctx.needs_input_grad[3]:
+            dbg = dg.reshape(M, 2 * C).sum(dim=0)
+        dx = (dxh[..., :C] + dxh2[..., :C]) if ctx.needs_input_grad[0] else None
+        dh_total = (dh + dxh2[..., C:]) if ctx.needs_input_grad[1] else None
+        return dx, dh_total, dwg, dbg, dwo, dbo
+
+
+def gru_cell_rows(x, h, gate_weight, gate_bias, out_weight, out_bias):
+    """ConvGRUCell_3D.forward on rows [b,D,H,W,C] with autograd; weights are the module's Conv3d parameters."""
+    return _GRUCellRows.apply(x, h, co._pack3d(gate_weight), gate_bias, co._pack3d(out_weight), out_bias)
 
 
 class ConvGRUCell_3D(nn.Module):
@@ -121,8 +195,9 @@ class ConvGRU_3D(nn.Module):
 
     def fuse_autograd_hip(self, x):
         """Encoder3D.fuse with an autograd graph (model.train(), or eval-mode pose refinement): the six convolutions per GRU step
-        and fusion_conv run on the MFMA implicit-GEMM kernel (forward and data gradient) and the wgrad kernel; BatchNorm (batch
-        statistics / SyncBN), sigmoid, tanh and the lerp stay torch element-wise ops so that their autograd is torch's."""
+        and fusion_conv run on the MFMA implicit-GEMM kernel (forward and data gradient) and the wgrad kernel, the cell's sigmoid /
+        tanh / lerp halves on the element-wise kernels of csrc/gru.hip (_GRUCellRows); BatchNorm (batch statistics / SyncBN) stays
+        a torch module so that SyncBatchNorm conversion keeps working."""
         assert self.n_layers == 1
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
@@ -131,13 +206,8 @@ class ConvGRU_3D(nn.Module):
         lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
         h = self._bn_rows(fc[1], co.conv3x3x3_rows(xr.mean(dim=1), None, fc[0].weight, fc[0].bias), lrelu)
         h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
-        hs = self.hidden_size
         for ti in range(t):
-            xt = xr[:, ti]
-            g = co.conv3x3x3_rows(xt, h, cell.conv_gate.weight, cell.conv_gate.bias)
-            update, reset = torch.sigmoid(g[..., :hs]), torch.sigmoid(g[..., hs:])
-            cand = torch.tanh(co.conv3x3x3_rows(xt, (h * reset).contiguous(), cell.out_gate.weight, cell.out_gate.bias))
-            h = h * (1 - update) + cand * update
+            h = gru_cell_rows(xr[:, ti], h, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias)
         return self.fusion_norm(h.permute(0, 4, 1, 2, 3))
 
     def forward(self, x, hidden=None):

@@ -172,6 +172,22 @@ int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1,
                      const int* taps, int ntaps, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a4 (training)  element-wise halves of the ConvGRU cell, models/fusion.py:29-35 under autograd. Inference fuses them into
+ * forge_conv_igemm's GRU epilogues; with an autograd graph the two convolutions run with the bias epilogue and each half of the
+ * cell is one kernel per direction. All arrays are channels-last rows [M][C] fp32, C % 4 == 0, g / dg are [M][2C] (update | reset).
+ *   gates fwd: z = sigmoid(g[:, :C]), r = sigmoid(g[:, C:]), hr = h * r
+ *   state fwd: cand = tanh(c) (written over c), hn = h (1 - z) + cand z
+ *   state bwd: dh = dhn (1 - z), dz = dhn (cand - h), dc = dhn z (1 - cand^2)
+ *   gates bwd: dg = (dz z (1 - z) | dhr h r (1 - r)), dh += dhr r      (dhr rows may be strided: ld_dhr floats)
+ */
+int forge_gru_gates_fwd(const float* g, const float* h, float* z, float* r, float* hr, long long M, int C, forge_stream_t stream);
+int forge_gru_state_fwd(float* c_cand, const float* h, const float* z, float* hn, long long M, int C, forge_stream_t stream);
+int forge_gru_state_bwd(const float* dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
+                        long long M, int C, forge_stream_t stream);
+int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
+                        float* dg, float* dh, long long M, int C, forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a1  ResNet stem helpers (torchvision conv1/bn1/relu/maxpool behind models/encoder.py:71-73).
  * forge_im2col_nchw: img [N][C][H][W] -> patch rows out [N*Ho*Wo][Kpad], k = (ky*kw + kx)*C + c, zeros outside the image and
  *   for k >= kh*kw*C; Ho = (H + 2 pad - kh)/stride + 1. The 7x7/s2 stem conv then runs as forge_conv_igemm with one tap and

@@ -6,8 +6,8 @@
 // Both operands are row-major [m][channels] in HBM = "k-major" for this GEMM, which is exactly what the 32x32x2 fp32 MFMA
 // wants from LDS without any transpose: lane l supplies A[i = l&31][k = l>>5], so a half-wave reads 32 CONSECUTIVE floats
 // of one LDS row (conflict-free ds_read_b32). Workgroup = 4 waves (2 x 2, wave tile 64 x 64 with even/odd channel interleave: one 8-byte LDS read feeds two MFMAs), tile 128(co) x 128(ci) for one
-// tap over one M-chunk, K-step = 32 voxels, register-staged buffer loads (out-of-range rows / taps -> 0), double-buffered
-// LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
+// tap over one M-chunk, K-step = 16 voxels (32 KiB of LDS, 112 VGPRs: 4 workgroups per CU; with 32-voxel steps and 2 workgroups per
+// CU the same kernel ran 7-16 % slower), register-staged buffer loads (out-of-range rows / taps -> 0), double-buffered LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
 // taps x tiles alone is only ~100 workgroups). dW must be zero-filled by the caller.
 //
 // Replaces torch's conv3d weight-gradient (cuDNN/MIOpen) for the ConvGRU / fusion_conv / conv1 convolutions
@@ -39,7 +39,7 @@ struct WgradArgs {
     signed char tap[64][4];
 };
 
-constexpr int WT = 128, WK = 32;              // tile 128 x 128, K-step 32 voxels
+constexpr int WT = 128, WK = 16, WJ = WK / 8;  // tile 128 x 128, K-step 16 voxels (32 KiB of LDS: 4 workgroups per CU)
 
 // CIW = width of the Cin tile: 128 (4 waves as 2 x 2, wave tile 64 co x 64 ci, even/odd interleave on both operands), or for
 // narrow inputs 64 / 32 (4 waves as 4 x 1, wave tile 32 co x CIW ci) so that a Cin <= 64 problem (conv1: 64, the transpose conv
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = (tid >> 5) + 8 j, chunk = tid & 31)
     const int sc4 = (tid & 31) << 2;
     const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = sc4 < CIW && cx0 + sc4 < Cx;
-    float4 ra[4], rb[4];
+    float4 ra[WJ], rb[WJ];
     // voxel coordinates of the staged rows, advanced by WK rows per K-step (no per-step divisions)
-    int rx_[4], ry_[4], rz_[4], rn_[4];
+    int rx_[WJ], ry_[WJ], rz_[WJ], rn_[WJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < WJ; ++j) {
         unsigned v = (unsigned)(mbeg + (tid >> 5) + 8 * j);
         rx_[j] = (int)(v % (unsigned)a.W); v /= (unsigned)a.W;
         ry_[j] = (int)(v % (unsigned)a.H); v /= (unsigned)a.H;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int trow = tid >> 5;
     auto load_step = [&](int s) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WJ; ++j) {
             // 32-bit offsets: every operand span is < 2 GiB (checked on the host side)
             const unsigned m = mbeg_u + (unsigned)(s * WK + trow + 8 * j);
             const bool mok = m < mend_u;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         float* sa = smem + buf * (2 * WK * WT);
         float* sb = sa + WK * WT;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WJ; ++j) {
             *reinterpret_cast<float4*>(sa + ((tid >> 5) + 8 * j) * WT + sc4) = ra[j];
             *reinterpret_cast<float4*>(sb + ((tid >> 5) + 8 * j) * WT + sc4) = rb[j];
         }
@@ -304,7 +304,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
     nchunk = (M + mchunk - 1) / mchunk;
     const long long grid = tiles * nchunk;
     FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
-    const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 64 KiB
+    const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 32 KiB
 #define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
     do {                                                                                                                             \
         static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel<CIWv>,                               \

@@ -103,8 +103,10 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
     dst[e] = acc;
 }
 
-// Backward: scatter-add of the upstream gradient through the same 8 taps (hardware fp32 atomics,
-// resolved in L2), optional gradient w.r.t. the 3x4 affine (pose refinement).
+// Gradient w.r.t. the 3x4 affine (pose refinement): per OUTPUT voxel, the upstream gradient dotted with the 8 source taps
+// and chained through the trilinear weights; block reduction + 12 atomics per workgroup. (With dvox != NULL it also scatter-adds
+// the volume gradient with fp32 atomics - the pre-gather formulation, kept for A/B measurements; the entry point uses the gather
+// kernel below for dvox.)
 __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
                                                          const float* __restrict__ xf, const int* __restrict__ mode,
                                                          float* __restrict__ dvox, float* __restrict__ dxf,
@@ -119,13 +121,13 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
     float dA[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dA[i] = 0.f;
-    if (active && md == 0) {
+    if (active && md == 0 && dvox) {
         const float4 g = dout[(long long)n * per_vol + e];
         float* d = dvox + ((long long)n * per_vol + e) * 4;
         // mode-0 volumes receive exactly one contribution per element: plain accumulate is enough,
         // but dvox may alias nothing else, so a non-atomic RMW is safe.
         d[0] += g.x; d[1] += g.y; d[2] += g.z; d[3] += g.w;
-    } else if (active) {
+    } else if (active && md != 0) {
         const int c4 = (int)(e % C4);
         long long v = e / C4;
         const int x = (int)(v % W); v /= W;
@@ -151,11 +153,13 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
                 const float wx = dx ? t.wx1 : t.wx0, wy = dy ? t.wy1 : t.wy0, wz = dz ? t.wz1 : t.wz0;
                 const float w = wx * wy * wz;
                 const long long off = (long long)n * per_vol + zi * sD + yi * sH + xi * sW + c4;
-                float* d = dvox + off * 4;
-                atomic_add_f32(d + 0, w * g.x);
-                atomic_add_f32(d + 1, w * g.y);
-                atomic_add_f32(d + 2, w * g.z);
-                atomic_add_f32(d + 3, w * g.w);
+                if (dvox) {
+                    float* d = dvox + off * 4;
+                    atomic_add_f32(d + 0, w * g.x);
+                    atomic_add_f32(d + 1, w * g.y);
+                    atomic_add_f32(d + 2, w * g.z);
+                    atomic_add_f32(d + 3, w * g.w);
+                }
                 if (dxf) {
                     const float4 s = vox[off];
                     const float dot = s.x * g.x + s.y * g.y + s.z * g.z + s.w * g.w;
@@ -187,6 +191,79 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
             atomic_add_f32(dxf + n * 12 + threadIdx.x, s);
         }
     }
+}
+
+// Volume gradient as a GATHER (the adjoint of the warp without atomics): thread = (SOURCE voxel q, 4 channels). The warp maps an
+// output voxel x to the source pixel coordinate p(x) = P x + p0 (affine: normalisation, 3x4 transform, align_corners=False
+// un-normalisation), and q receives w(q, p(x)) dout[x] from every x with |p(x) - q| < 1 on all axes, i.e. from the integer points of
+// the box P^-1 (q - p0 + (-1, 1)^3): centre P^-1 (q - p0), half extents sum_b |P^-1_ab| (<= sqrt 3 for a rigid pose), ~8 hits among
+// <= 5^3 candidates. Each candidate is re-evaluated with the forward pass's own expressions (same taps, same weights), so the result is
+// the exact transpose of rotate_fwd_kernel; it is deterministic (fixed summation order) and dvox is written, not accumulated.
+__global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __restrict__ dout, const float* __restrict__ xf,
+                                                                const int* __restrict__ mode, float4* __restrict__ dvox,
+                                                                int C4, int D, int H, int W, long long per_vol, unsigned blocks_per_vol) {
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int n = bid / blocks_per_vol;
+    const long long e = (long long)(bid % blocks_per_vol) * 256 + threadIdx.x;
+    if (e >= per_vol) return;
+    const float4* g = dout + (long long)n * per_vol;
+    if (mode[n] == 0) {
+        dvox[(long long)n * per_vol + e] = g[e];
+        return;
+    }
+    const int c4 = (int)(e % C4);
+    long long v = e / C4;
+    const int qx = (int)(v % W); v /= W;
+    const int qy = (int)(v % H);
+    const int qz = (int)(v / H);
+    const float* A = xf + n * 12;
+    const float Nf[3] = {(float)W, (float)H, (float)D};
+    float P[3][3], p0[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) P[a][b] = A[a * 4 + b] * Nf[a] / (Nf[b] - 1.f);
+        p0[a] = ((A[a * 4 + 3] - A[a * 4] - A[a * 4 + 1] - A[a * 4 + 2] + 1.f) * Nf[a] - 1.f) * 0.5f;
+    }
+    const float c00 = P[1][1] * P[2][2] - P[1][2] * P[2][1], c01 = P[0][2] * P[2][1] - P[0][1] * P[2][2], c02 = P[0][1] * P[1][2] - P[0][2] * P[1][1];
+    const float c10 = P[1][2] * P[2][0] - P[1][0] * P[2][2], c11 = P[0][0] * P[2][2] - P[0][2] * P[2][0], c12 = P[0][2] * P[1][0] - P[0][0] * P[1][2];
+    const float c20 = P[1][0] * P[2][1] - P[1][1] * P[2][0], c21 = P[0][1] * P[2][0] - P[0][0] * P[2][1], c22 = P[0][0] * P[1][1] - P[0][1] * P[1][0];
+    const float det = P[0][0] * c00 + P[0][1] * c10 + P[0][2] * c20;
+    int lo[3] = {0, 0, 0}, hi[3] = {W - 1, H - 1, D - 1};           // singular transform: scan the whole grid (never a camera pose)
+    if (fabsf(det) > 1e-20f) {
+        const float id = 1.f / det;
+        const float I[3][3] = {{c00 * id, c01 * id, c02 * id}, {c10 * id, c11 * id, c12 * id}, {c20 * id, c21 * id, c22 * id}};
+        const float r[3] = {(float)qx - p0[0], (float)qy - p0[1], (float)qz - p0[2]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float cc = I[a][0] * r[0] + I[a][1] * r[1] + I[a][2] * r[2];
+            const float hh = fabsf(I[a][0]) + fabsf(I[a][1]) + fabsf(I[a][2]) + 0.02f + 1e-5f * fabsf(cc);
+            lo[a] = max((int)ceilf(fmaxf(cc - hh, -1.f)), 0);
+            hi[a] = min((int)floorf(fminf(cc + hh, Nf[a])), (int)Nf[a] - 1);
+        }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
+    for (int z = lo[2]; z <= hi[2]; ++z) {
+        const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+        for (int y = lo[1]; y <= hi[1]; ++y) {
+            const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
+            for (int x = lo[0]; x <= hi[0]; ++x) {
+                const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
+                const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
+                const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
+                const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
+                TriTaps t;
+                taps_ac_false(sx, sy, sz, W, H, D, t);
+                const unsigned ux = (unsigned)(qx - t.x0), uy = (unsigned)(qy - t.y0), uz = (unsigned)(qz - t.z0);
+                if (ux <= 1u && uy <= 1u && uz <= 1u) {
+                    const float w = (ux ? t.wx1 : t.wx0) * (uy ? t.wy1 : t.wy0) * (uz ? t.wz1 : t.wz0);
+                    acc = f4_fma(w, g[z * sD + y * sH + x * sW + c4], acc);
+                }
+            }
+        }
+    }
+    dvox[(long long)n * per_vol + e] = acc;
 }
 
 // poses [B][t][16] row-major camera poses -> xf [B*t][12], mode [B*t]: T = P_0 P_i^-1 (models/rotate.py:64-89, general
@@ -275,8 +352,11 @@ extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float
     const long long per_vol = (long long)D * H * W * C4;
     const unsigned bpv = (unsigned)((per_vol + 255) / 256);
     FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_bwd: grid too large");
-    hipLaunchKernelGGL(rotate_bwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dout, (const float4*)vox, xf, mode, dvox, dxf, C4, D, H, W, per_vol, bpv);
+    hipLaunchKernelGGL(rotate_bwd_gather_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dout, xf, mode, (float4*)dvox, C4, D, H, W, per_vol, bpv);
+    if (dxf)
+        hipLaunchKernelGGL(rotate_bwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)dout, (const float4*)vox, xf, mode, (float*)nullptr, dxf, C4, D, H, W, per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_bwd");
     return 0;
 }

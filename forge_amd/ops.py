@@ -55,7 +55,7 @@ class _RotateWarp(torch.autograd.Function):
         vox_cl, xf_c, mode = ctx.saved_tensors
         n, C, D, H, W = vox_cl.shape
         g_cl = to_channels_last_3d(g)
-        dvox = _zeros_like_cl(vox_cl)
+        dvox = _empty_like_cl(vox_cl)                      # written by the gather kernel
         dxf = torch.zeros_like(xf_c) if ctx.needs_input_grad[1] else None
         _lib.check(_lib.lib().forge_rotate_bwd(_lib.ptr(g_cl), _lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode),
                                                _lib.ptr(dvox), _lib.ptr(dxf), n, C, D, H, W, _lib.current_stream()),

@@ -65,8 +65,8 @@ int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, 
 
 /* Backward of forge_rotate_fwd w.r.t. the volumes (and optionally the affine).
  *   dout [n][D][H][W][C]   upstream gradient
- *   dvox [n][D][H][W][C]   MUST be zero-filled by the caller; receives scatter-added gradients
- *                          (mode 0 volumes: plain copy of dout)
+ *   dvox [n][D][H][W][C]   written (not accumulated): the exact transpose of the warp, computed as a gather per source voxel
+ *                          (deterministic, no atomics); mode 0 volumes: plain copy of dout
  *   dxf  [n][12]           nullable; MUST be zero-filled; d loss / d xf (pose refinement,
  *                          kubric_eval.py:469-503). Needs vox (nullable when dxf is NULL).
  */

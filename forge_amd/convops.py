@@ -256,12 +256,56 @@ def conv2d_rows(x, weight, bias, stride=1):
     return y.reshape(N, Ho, Wo, co_)
 
 
+class _ConvDirectRows(torch.autograd.Function):
+    """Stride-1 'same' convolution with tiny channel counts (Cin in {4, 8, 16}, Cout <= 4) on channels-last rows, all three directions
+    on the direct vector-ALU kernels (csrc/conv_direct.hip). wp [T][Cout][Cin] is the differentiable packed weight."""
+
+    @staticmethod
+    def forward(ctx, x, wp, bias, taps):
+        n, D, H, W, Cin = x.shape
+        T, Cout, _ = wp.shape
+        x = x.contiguous()
+        wpc = wp.detach().contiguous()
+        out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().forge_conv_direct_fwd(_lib.ptr(x), Cin, _lib.ptr(wpc), _lib.ptr(bias), _lib.ptr(out), Cout, n, D, H, W, Cin, Cout,
+                                                    _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_fwd")
+        ctx.save_for_backward(x, wpc)
+        ctx.meta = (tuple(taps), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp = ctx.saved_tensors
+        taps, has_bias = ctx.meta
+        n, D, H, W, Cin = x.shape
+        T, Cout, _ = wp.shape
+        dy = dy.contiguous()
+        dx = dwp = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(_lib.lib().forge_conv_direct_dgrad(_lib.ptr(dy), Cout, _lib.ptr(wp), _lib.ptr(dx), Cin, n, D, H, W, Cin, Cout,
+                                                          _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_dgrad")
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros_like(wp)
+            _lib.check(_lib.lib().forge_conv_direct_wgrad(_lib.ptr(dy), Cout, _lib.ptr(x), Cin, _lib.ptr(dwp), n, D, H, W, Cin, Cout,
+                                                          _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_wgrad")
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, Cout).sum(dim=0)
+        return dx, dwp, db, None
+
+
+def conv_direct_rows(x, wp, bias, taps):
+    return _ConvDirectRows.apply(x, wp, bias, tuple(taps))
+
+
 def conv3x3x3_rows_any(x, weight, bias):
-    """conv3x3x3_rows for channel counts that are not multiples of 32 (the heads' 32->16, 32->8, 8->1 convolutions): weight and
-    input are zero-padded to the GEMM K-step with differentiable torch ops and the extra output channels are sliced away, so the
-    same forward / dgrad / wgrad kernels serve them (their FLOPs are negligible; what matters is that no MIOpen 3-D weight-gradient
-    solver — 65-110 ms each on these shapes — is involved)."""
+    """conv3x3x3_rows for channel counts that are not multiples of 32 (the heads' 32->16, 32->8, 8->1 convolutions). Tiny layers
+    (Cin in {4, 8, 16}, Cout <= 4: the density head's 8->1) run on the direct kernels; the others are zero-padded to the GEMM K-step
+    with differentiable torch ops and the extra output channels are sliced away, so the same forward / dgrad / wgrad kernels serve
+    them (what matters is that no MIOpen 3-D weight-gradient solver - 65-110 ms each on these shapes - is involved)."""
     Cout, Cin = weight.shape[:2]
+    if Cin in (4, 8, 16) and Cout <= 4 and x.shape[-1] == Cin:
+        return conv_direct_rows(x, _pack3d(weight), bias, TAPS_3x3x3)
     Cop, Cip = -(-Cout // 32) * 32, -(-Cin // 32) * 32
     if Cop != Cout or Cip != Cin:
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, Cip - Cin, 0, Cop - Cout))

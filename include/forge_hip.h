@@ -172,6 +172,22 @@ int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1,
                      const int* taps, int ntaps, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a5 / a7  direct convolution for TINY channel counts (Cin in {4, 8, 16}, Cout in 1..4): the last convolutions of the density head
+ * (Conv3d(8, 1, 3), models/encoder.py:31) and of conv_rgb (Conv2d(8, 3, 5), models/volume_render.py:36). A matrix-core tile pads such
+ * a layer to 16 or 32 channels on both sides (up to 128x the useful FLOPs); these are streaming problems and run on the vector ALUs.
+ * Stride-1 "same" geometry on channels-last rows: in [M][ld_in], w [ntaps][Cout][Cin], taps (dz,dy,dx) inside the (n,D,H,W) grid.
+ *   fwd    out[m][co] = bias[co] + sum_t sum_ci w[t][co][ci] in[m + tap_t][ci]          (bias nullable)
+ *   dgrad  dx[m][ci]  = sum_t sum_co w[t][co][ci] dy[m - tap_t][co]
+ *   wgrad  dw[t][co][ci] += sum_m dy[m][co] x[m + tap_t][ci]                              (dw zero-filled by the caller; fp32 atomics)
+ */
+int forge_conv_direct_fwd(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
+                          int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream);
+int forge_conv_direct_dgrad(const float* dy, int ld_dy, const float* w, float* dx, int ld_dx,
+                            int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream);
+int forge_conv_direct_wgrad(const float* dy, int ld_dy, const float* x, int ld_x, float* dw,
+                            int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a4 (training)  element-wise halves of the ConvGRU cell, models/fusion.py:29-35 under autograd. Inference fuses them into
  * forge_conv_igemm's GRU epilogues; with an autograd graph the two convolutions run with the bias epilogue and each half of the
  * cell is one kernel per direction. All arrays are channels-last rows [M][C] fp32, C % 4 == 0, g / dg are [M][2C] (update | reset).

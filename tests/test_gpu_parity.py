@@ -351,6 +351,32 @@ def test_conv_igemm_every_tile_and_splitk(dev, tile, monkeypatch):
     assert seen >= 4
 
 
+@pytest.mark.parametrize("Cin,Cout,dims,k", [(8, 1, (6, 7, 9), 3), (8, 3, (1, 20, 17), 5), (16, 4, (3, 5, 4), 3), (4, 2, (2, 3, 70), 3)])
+def test_conv_direct_fwd_dgrad_wgrad_vs_torch(dev, Cin, Cout, dims, k):
+    """direct kernels for tiny channel counts (density head 8->1 3x3x3, conv_rgb 8->3 5x5) against torch's conv autograd on the CPU."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(Cin * 10 + Cout)
+    D, H, W = dims
+    x = torch.randn(2, Cin, D, H, W, generator=g, requires_grad=True)
+    kd = k if D > 1 else 1
+    w = (torch.randn(Cout, Cin, kd, k, k, generator=g) / (kd * k * k * Cin) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, requires_grad=True)
+    ref = torch.nn.functional.conv3d(x, w, b, padding=(kd // 2, k // 2, k // 2))
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    taps = [(a - kd // 2, bb - k // 2, c - k // 2) for a in range(kd) for bb in range(k) for c in range(k)]
+    xd = _rows(x.detach()).to(dev).requires_grad_(True)
+    wd = w.detach().to(dev).requires_grad_(True)
+    bd = b.detach().to(dev).requires_grad_(True)
+    out = co.conv_direct_rows(xd, wd.reshape(Cout, Cin, -1).permute(2, 0, 1), bd, taps)
+    out.backward(_rows(gy).to(dev))
+    tol = lambda t: 3e-5 * max(1.0, t.abs().max().item())
+    assert (out.detach().permute(0, 4, 1, 2, 3).cpu() - ref.detach()).abs().max().item() < tol(ref.detach())
+    assert (xd.grad.permute(0, 4, 1, 2, 3).cpu() - x.grad).abs().max().item() < tol(x.grad)
+    assert (wd.grad.cpu() - w.grad).abs().max().item() < 1e-4 * max(1.0, w.grad.abs().max().item())
+    assert (bd.grad.cpu() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
+
+
 def test_conv_igemm_strided2d_and_transpose_phases(dev):
     from forge_amd import convops as co
     g = torch.Generator().manual_seed(2)

@@ -201,7 +201,22 @@ class _ConvTapsRows(torch.autograd.Function):
         dx1 = dx2 = dwp = db = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wd = wp.transpose(1, 2).contiguous()                                     # [T][Cin][Cout]
-            if istride == 1:
+            if istride == 1 and Cout <= 16:
+                # narrow output (forward ran on the Cout <= 16 kernel): the data gradient has K = Cout <= 16 and N = Cin; run it on the
+                # same kernel in 16-column blocks of Cin (K padded to its 16-voxel step) instead of padding both sides to 32
+                assert (D, H, W) == (Di, Hi, Wi)
+                if Cout < 16:
+                    dyk = torch.nn.functional.pad(dy, (0, 16 - Cout))
+                    wd = torch.nn.functional.pad(wd, (0, 16 - Cout))
+                else:
+                    dyk = dy
+                dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
+                ntaps_ = [(-a, -b, -c) for a, b, c in taps]
+                for j in range(0, Cin, 16):
+                    nb = min(16, Cin - j)
+                    conv_igemm(dyk, 16, 16, None, 0, 0, wd[:, j:j + nb].contiguous(), None, None, None, 1.0, None, None, None, dx[..., j:], None,
+                               (n, D, H, W), (D, H, W), nb, Cin, ntaps_, epilogue=EPI_BIAS)
+            elif istride == 1:
                 assert (D, H, W) == (Di, Hi, Wi)
                 dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
                 conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (D, H, W), Cin, Cin,
@@ -300,12 +315,15 @@ def conv_direct_rows(x, wp, bias, taps):
 
 def conv3x3x3_rows_any(x, weight, bias):
     """conv3x3x3_rows for channel counts that are not multiples of 32 (the heads' 32->16, 32->8, 8->1 convolutions). Tiny layers
-    (Cin in {4, 8, 16}, Cout <= 4: the density head's 8->1) run on the direct kernels; the others are zero-padded to the GEMM K-step
+    (Cin in {4, 8, 16}, Cout <= 4: the density head's 8->1) run on the direct kernels, Cout <= 16 layers on the narrow-N GEMM kernel
+    (forward and, in 16-column blocks, data gradient); anything else is zero-padded to the GEMM K-step
     with differentiable torch ops and the extra output channels are sliced away, so the same forward / dgrad / wgrad kernels serve
     them (what matters is that no MIOpen 3-D weight-gradient solver - 65-110 ms each on these shapes - is involved)."""
     Cout, Cin = weight.shape[:2]
     if Cin in (4, 8, 16) and Cout <= 4 and x.shape[-1] == Cin:
         return conv_direct_rows(x, _pack3d(weight), bias, TAPS_3x3x3)
+    if Cout <= 16 and Cout % 4 == 0 and Cin % 16 == 0 and x.shape[-1] == Cin:
+        return conv_taps_rows(x.contiguous(), None, _pack3d(weight), bias, TAPS_3x3x3)          # Cout <= 16 kernel, no channel padding
     Cop, Cip = -(-Cout // 32) * 32, -(-Cin // 32) * 32
     if Cop != Cout or Cip != Cin:
         weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, 0, 0, Cip - Cin, 0, Cop - Cout))

@@ -243,6 +243,114 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs a
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Narrow variant with operand reuse across taps (stride-1 "same" convolutions with Cout, Cin <= 32 whose taps span <= 9 distinct
+// (dz, dy) lines and |dx| <= 2: the heads' 3x3x3 convolutions, conv_rgb's 5x5). conv_wgrad_small_kernel above loads one X element per
+// lane per MFMA (12.8 FLOP per byte of L1/L2 traffic -> 35 TF); but the 27 taps of a voxel segment read the same dY rows and almost
+// the same X rows. Here a workgroup stages, for a segment of 32 consecutive x-voxels of one (n, z, y) line, the dY rows and the X
+// halo - every needed (dz, dy) line, 32 + 2 rx voxels long - in LDS once (43 KB for 3x3x3 at 32 channels) and feeds all taps from
+// it: each wave owns every 4th tap (<= 7 accumulator tiles), one ds_read_b32 per operand per MFMA, conflict-free (a half-wave reads
+// 32 consecutive floats of one LDS row). Workgroups walk segments grid-stride with the next segment's global loads in flight under the
+// current segment's MFMAs, and add their partial 32x32 tiles to dW with fp32 atomics once at the end.
+constexpr int LSEG = 32, LMAXL = 9, LMAXR = 2, LROWS = LSEG + 2 * LMAXR, LTAPS = 7;
+
+struct LineTable { signed char dz[LMAXL], dy[LMAXL]; int nlines, rx; };
+
+__global__ __launch_bounds__(256) void conv_wgrad_lines_kernel(const WgradArgs a, const LineTable lt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // dYs [LSEG][32] | Xs [nlines][LSEG + 2 rx][32]
+    float* dYs = smem;
+    float* Xs = smem + LSEG * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int Cin = a.C1, xrows = LSEG + 2 * lt.rx;
+    const int nsx = (a.W + LSEG - 1) / LSEG;
+    const long long nseg = (long long)a.n * a.D * a.H * nsx;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, (int)a.span1, 0x00020000);
+    // staging geometry: one float4 (4 channels) per thread per pass; 8 threads per 32-channel row
+    const int c4 = (tid & 7) << 2, srow = tid >> 3;                 // 32 rows per pass
+    const int xchunks = lt.nlines * xrows;                           // X rows to stage
+    constexpr int XP = (LMAXL * LROWS + 31) / 32;                    // passes (upper bound 11)
+    float4 ry4, rx4[XP];
+    auto load_seg = [&](long long sg) {
+        long long q = sg;
+        const int sx = (int)(q % nsx); q /= nsx;
+        const int y = (int)(q % a.H); q /= a.H;
+        const int z = (int)(q % a.D); q /= a.D;
+        const int nn = (int)q, x0 = sx * LSEG;
+        {   // dY row srow of the segment
+            const int x = x0 + srow;
+            const long long m = (((long long)nn * a.D + z) * a.H + y) * a.W + x;
+            ry4 = buf_load16w(ry, (x < a.W && c4 < a.Cout) ? (unsigned)((m * a.ldy + c4) * 4) : OOBW);
+        }
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int r = srow + 32 * p;                             // staged X row: (line, xr)
+            unsigned off = OOBW;
+            if (r < xchunks && c4 < Cin) {
+                const int ln = r / xrows, xr = r - ln * xrows;
+                const int zi = z + lt.dz[ln], yi = y + lt.dy[ln], xi = x0 - lt.rx + xr;
+                if ((unsigned)zi < (unsigned)a.D && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+                    off = (unsigned)((((long long)nn * a.bs1r + ((long long)zi * a.H + yi) * a.W + xi) * a.ld1 + c4) * 4);
+            }
+            rx4[p] = buf_load16w(rx_, off);
+        }
+    };
+    auto store_seg = [&]() {
+        *reinterpret_cast<float4*>(dYs + srow * 32 + c4) = ry4;
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int r = srow + 32 * p;
+            if (r < xchunks) *reinterpret_cast<float4*>(Xs + r * 32 + c4) = rx4[p];
+        }
+    };
+    // this wave's taps: t = wave, wave + 4, ... (<= LTAPS); LDS row offset of each tap's first X row
+    int tb[LTAPS];
+    bool tok[LTAPS];
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j) {
+        const int t = wave + 4 * j;
+        tok[j] = t < a.ntaps;
+        const int tt = tok[j] ? t : 0;
+        tb[j] = (a.tap[tt][3] * xrows + a.tap[tt][2] + lt.rx) * 32;  // (line, dx + rx)
+    }
+    f32x16w acc[LTAPS];
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    long long sg = blockIdx.x;
+    if (sg < nseg) load_seg(sg);
+    for (; sg < nseg; sg += gridDim.x) {
+        __syncthreads();                                             // previous segment's MFMAs have read the LDS images
+        store_seg();
+        __syncthreads();
+        if (sg + gridDim.x < nseg) load_seg(sg + gridDim.x);         // in flight under this segment's MFMAs
+#pragma unroll 4
+        for (int k = 0; k < LSEG / 2; ++k) {
+            const int row = 2 * k + half;
+            const float fa = dYs[row * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < LTAPS; ++j) {
+                if (!tok[j]) continue;                               // wave-uniform
+                const float fb = Xs[tb[j] + row * 32 + l31];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j) {
+        if (!tok[j] || l31 >= Cin) continue;
+        const int t = wave + 4 * j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < a.Cout && acc[j][r] != 0.f) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + l31, acc[j][r]);
+        }
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
@@ -272,6 +380,40 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         a.tap[t][3] = 0;
     }
     const int Cin = C1 + C2;
+    if (Cout <= 32 && Cin <= 32 && x2 == nullptr && is == 1 && Di == D && Hi == H && Wi == W && ntaps <= 4 * LTAPS) {
+        // taps grouped by (dz, dy) line; usable when <= 9 lines and |dx| <= 2
+        LineTable lt;
+        lt.nlines = 0; lt.rx = 0;
+        bool ok = true;
+        for (int t = 0; t < ntaps && ok; ++t) {
+            const int dz = taps[t * 3], dy_ = taps[t * 3 + 1], dx = taps[t * 3 + 2];
+            if (dx > LMAXR || dx < -LMAXR) { ok = false; break; }
+            if (dx > lt.rx) lt.rx = dx;
+            if (-dx > lt.rx) lt.rx = -dx;
+            int ln = -1;
+            for (int i = 0; i < lt.nlines; ++i)
+                if (lt.dz[i] == dz && lt.dy[i] == dy_) ln = i;
+            if (ln < 0) {
+                if (lt.nlines == LMAXL) { ok = false; break; }
+                ln = lt.nlines++;
+                lt.dz[ln] = (signed char)dz; lt.dy[ln] = (signed char)dy_;
+            }
+            a.tap[t][3] = (signed char)ln;
+        }
+        if (ok) {
+            const long long nseg = (long long)n * D * H * ((W + LSEG - 1) / LSEG);
+            const size_t lds = (size_t)(LSEG * 32 + lt.nlines * (LSEG + 2 * lt.rx) * 32) * sizeof(float);
+            static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                    (int)((LSEG * 32 + LMAXL * LROWS * 32) * sizeof(float)));
+            (void)attr_once;
+            const long long grid = nseg < 512 ? nseg : 512;          // 2 workgroups per CU (244 VGPRs), each walking its share of the segments
+            a.mchunk = 0;
+            hipLaunchKernelGGL(conv_wgrad_lines_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, lt);
+            FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+            return 0;
+        }
+        for (int t = 0; t < ntaps; ++t) a.tap[t][3] = 0;
+    }
     if (Cout <= 32 && Cin <= 32 && x2 == nullptr && W % 2 == 0) {
         // narrow channels: independent waves, 4 taps each, fed straight from global memory
         const int tap_groups = (ntaps + 3) / 4;

@@ -335,47 +335,73 @@ def conv3x3x3_rows_any(x, weight, bias):
     return y[..., :Cout] if Cop != Cout else y
 
 
-TAPS_CT_DGRAD = [(kz - 1, ky - 1, kx - 1) for kz in range(4) for ky in range(4) for kx in range(4)]
-
-
-class _ConvT3dK4S2P1Rows(torch.autograd.Function):
-    """nn.ConvTranspose3d(k=4, s=2, p=1) on channels-last rows. forward: 8 output-phase GEMMs of 8 taps; data gradient: ONE
-    stride-2 gather GEMM over the 64 kernel taps (dX[z] = sum_k dY[2z - 1 + k] W[:, :, k]); weight gradient: the wgrad kernel with
-    the roles swapped (reduction over input voxels, 'dy' operand = x, gathered operand = dY at 2z - 1 + k)."""
+class _ConvTS2Rows(torch.autograd.Function):
+    """nn.ConvTranspose{2,3}d(kernel k, stride 2, padding pad) on channels-last rows [n,D,H,W,Cin] (2-D: D = 1).
+    forward: 2^nd output-phase GEMMs; data gradient: ONE stride-2 gather GEMM over the k^nd kernel taps
+    (dX[z] = sum_k dY[2z - pad + k] W[:, :, k]); weight gradient: the wgrad kernel with the roles swapped (reduction over input voxels,
+    'dy' operand = x, gathered operand = dY at 2z - pad + k)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, pad, nd):
         n, D, H, W, Cin = x.shape
-        Cout = weight.shape[1]
-        out = torch.empty(n, 2 * D, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
-        for (pz, py, px), taps, wp in convT_phases(weight, 1, 3):
+        Cout, k = weight.shape[1], weight.shape[-1]
+        Do = 2 * D if nd == 3 else 1
+        out = torch.empty(n, Do, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
+        for (pz, py, px), taps, wp in convT_phases(weight, pad, nd):
             conv_igemm(x, Cin, Cin, None, 0, 0, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
-                       taps, out_grid=(2 * D, 2 * H, 2 * W), ostride=2, phase=(pz, py, px), epilogue=EPI_BIAS)
+                       taps, out_grid=(Do, 2 * H, 2 * W), ostride=2, phase=(pz, py, px), epilogue=EPI_BIAS)
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.meta = (bias is not None, pad, nd, k)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        has_bias, pad, nd, k = ctx.meta
         n, D, H, W, Cin = x.shape
         Cout = weight.shape[1]
+        Do = 2 * D if nd == 3 else 1
+        kk = k ** nd
+        taps = [(kz - pad if nd == 3 else 0, ky - pad, kx - pad) for kz in (range(k) if nd == 3 else (0,)) for ky in range(k) for kx in range(k)]
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wd = weight.detach().reshape(Cin, Cout, 64).permute(2, 0, 1).contiguous()         # [k][Cin][Cout]
+            wd = weight.detach().reshape(Cin, Cout, kk).permute(2, 0, 1).contiguous()         # [k][Cin][Cout]
             dx = torch.empty_like(x)
-            conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (2 * D, 2 * H, 2 * W),
-                       Cin, Cin, TAPS_CT_DGRAD, istride=2, epilogue=EPI_BIAS)
+            conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (Do, 2 * H, 2 * W),
+                       Cin, Cin, taps, istride=2, epilogue=EPI_BIAS)
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(64, Cin, Cout, dtype=torch.float32, device=x.device)             # [k][ci][co]
-            conv_wgrad(x, dy, Cout, None, 0, dwp, (n, D, H, W), (2 * D, 2 * H, 2 * W), Cin, TAPS_CT_DGRAD, istride=2)
-            dw = dwp.permute(1, 2, 0).reshape(Cin, Cout, 4, 4, 4)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dwp = torch.zeros(kk, Cin, Cout, dtype=torch.float32, device=x.device)             # [k][ci][co]
+            conv_wgrad(x, dy, Cout, None, 0, dwp, (n, D, H, W), (Do, 2 * H, 2 * W), Cin, taps, istride=2)
+            dw = dwp.permute(1, 2, 0).reshape(weight.shape)
+        if has_bias and ctx.needs_input_grad[2]:
             db = dy.reshape(-1, Cout).sum(dim=0)
-        return dx, dw, db
+        return dx, dw, db, None, None
+
+
+def convT_s2_rows(x, weight, bias, pad, nd):
+    """ConvTranspose{2,3}d(Cin, Cout, k, stride=2, padding=pad) on rows [n,D,H,W,Cin] -> [n,(2)D,2H,2W,Cout] with autograd; Cin and
+    Cout multiples of 32, or both <= 16 and multiples of 16 (narrow-N kernel)."""
+    return _ConvTS2Rows.apply(x, weight, bias, int(pad), int(nd))
 
 
 def convT3d_k4s2p1_rows(x, weight, bias):
     """ConvTranspose3d(Cin, Cout, 4, stride=2, padding=1) on rows [n,D,H,W,Cin] -> [n,2D,2H,2W,Cout]; Cin, Cout % 32 == 0."""
-    return _ConvT3dK4S2P1Rows.apply(x, weight, bias)
+    return convT_s2_rows(x, weight, bias, 1, 3)
+
+
+def conv2d_rows_any(x, weight, bias):
+    """Conv2d(k, stride 1, padding k//2) on NHWC rows [N,H,W,Cin] with autograd for the narrow layers of conv_rgb: tiny layers
+    (Cin in {4, 8, 16}, Cout <= 4) on the direct kernels, Cout <= 16 with Cin % 16 == 0 on the narrow-N GEMM kernel."""
+    co_, ci_, kh, kw = weight.shape
+    N, H, W, C = x.shape
+    taps = [(0, ky - kh // 2, kx - kw // 2) for ky in range(kh) for kx in range(kw)]
+    wp = weight.reshape(co_, ci_, kh * kw).permute(2, 0, 1)
+    x5 = x.reshape(N, 1, H, W, C)
+    if ci_ in (4, 8, 16) and co_ <= 4:
+        y = conv_direct_rows(x5, wp, bias, taps)
+    elif co_ <= 16 and co_ % 4 == 0 and ci_ % 16 == 0:
+        y = conv_taps_rows(x5.contiguous(), None, wp, bias, taps)
+    else:
+        raise ValueError("conv2d_rows_any: Cin=%d Cout=%d is not a narrow layer; use conv2d_rows" % (ci_, co_))
+    return y.reshape(N, H, W, co_)

@@ -104,12 +104,11 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
 }
 
 // Gradient w.r.t. the 3x4 affine (pose refinement): per OUTPUT voxel, the upstream gradient dotted with the 8 source taps
-// and chained through the trilinear weights; block reduction + 12 atomics per workgroup. (With dvox != NULL it also scatter-adds
-// the volume gradient with fp32 atomics - the pre-gather formulation, kept for A/B measurements; the entry point uses the gather
-// kernel below for dvox.)
-__global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
+// and chained through the trilinear weights; block reduction + 12 atomics per workgroup. (The volume gradient is the gather
+// kernel below; its first version scatter-added 8 x C fp32 atomics per voxel from here.)
+__global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
                                                          const float* __restrict__ xf, const int* __restrict__ mode,
-                                                         float* __restrict__ dvox, float* __restrict__ dxf,
+                                                         float* __restrict__ dxf,
                                                          int C4, int D, int H, int W, long long per_vol,
                                                          unsigned blocks_per_vol) {
     __shared__ float red[12][4];   // per-wave partials of d xf
@@ -121,13 +120,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
     float dA[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) dA[i] = 0.f;
-    if (active && md == 0 && dvox) {
-        const float4 g = dout[(long long)n * per_vol + e];
-        float* d = dvox + ((long long)n * per_vol + e) * 4;
-        // mode-0 volumes receive exactly one contribution per element: plain accumulate is enough,
-        // but dvox may alias nothing else, so a non-atomic RMW is safe.
-        d[0] += g.x; d[1] += g.y; d[2] += g.z; d[3] += g.w;
-    } else if (active && md != 0) {
+    if (active && md != 0) {                       // mode-0 volumes are copied, not warped: no dependence on the affine
         const int c4 = (int)(e % C4);
         long long v = e / C4;
         const int x = (int)(v % W); v /= W;
@@ -151,32 +144,20 @@ __global__ __launch_bounds__(256) void rotate_bwd_kernel(const float4* __restric
             const int xi = t.x0 + dx, yi = t.y0 + dy, zi = t.z0 + dz;
             if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H && (unsigned)zi < (unsigned)D) {
                 const float wx = dx ? t.wx1 : t.wx0, wy = dy ? t.wy1 : t.wy0, wz = dz ? t.wz1 : t.wz0;
-                const float w = wx * wy * wz;
-                const long long off = (long long)n * per_vol + zi * sD + yi * sH + xi * sW + c4;
-                if (dvox) {
-                    float* d = dvox + off * 4;
-                    atomic_add_f32(d + 0, w * g.x);
-                    atomic_add_f32(d + 1, w * g.y);
-                    atomic_add_f32(d + 2, w * g.z);
-                    atomic_add_f32(d + 3, w * g.w);
-                }
-                if (dxf) {
-                    const float4 s = vox[off];
-                    const float dot = s.x * g.x + s.y * g.y + s.z * g.z + s.w * g.w;
-                    gsx += (dx ? 1.f : -1.f) * wy * wz * dot;
-                    gsy += (dy ? 1.f : -1.f) * wx * wz * dot;
-                    gsz += (dz ? 1.f : -1.f) * wx * wy * dot;
-                }
+                const float4 s = vox[(long long)n * per_vol + zi * sD + yi * sH + xi * sW + c4];
+                const float dot = s.x * g.x + s.y * g.y + s.z * g.z + s.w * g.w;
+                gsx += (dx ? 1.f : -1.f) * wy * wz * dot;
+                gsy += (dy ? 1.f : -1.f) * wx * wz * dot;
+                gsz += (dz ? 1.f : -1.f) * wx * wy * dot;
             }
         }
-        if (dxf) {   // d pixel / d s = N/2 per axis (align_corners=False)
-            gsx *= 0.5f * (float)W; gsy *= 0.5f * (float)H; gsz *= 0.5f * (float)D;
-            dA[0] = gsx * gx; dA[1] = gsx * gy; dA[2] = gsx * gz; dA[3] = gsx;
-            dA[4] = gsy * gx; dA[5] = gsy * gy; dA[6] = gsy * gz; dA[7] = gsy;
-            dA[8] = gsz * gx; dA[9] = gsz * gy; dA[10] = gsz * gz; dA[11] = gsz;
-        }
+        // d pixel / d s = N/2 per axis (align_corners=False)
+        gsx *= 0.5f * (float)W; gsy *= 0.5f * (float)H; gsz *= 0.5f * (float)D;
+        dA[0] = gsx * gx; dA[1] = gsx * gy; dA[2] = gsx * gz; dA[3] = gsx;
+        dA[4] = gsy * gx; dA[5] = gsy * gy; dA[6] = gsy * gz; dA[7] = gsy;
+        dA[8] = gsz * gx; dA[9] = gsz * gy; dA[10] = gsz * gz; dA[11] = gsz;
     }
-    if (dxf && md != 0) {   // md is workgroup-uniform: whole-block reduction then 12 atomics
+    if (md != 0) {   // md is workgroup-uniform: whole-block reduction then 12 atomics
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -355,8 +336,8 @@ extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float
     hipLaunchKernelGGL(rotate_bwd_gather_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dout, xf, mode, (float4*)dvox, C4, D, H, W, per_vol, bpv);
     if (dxf)
-        hipLaunchKernelGGL(rotate_bwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)dout, (const float4*)vox, xf, mode, (float*)nullptr, dxf, C4, D, H, W, per_vol, bpv);
+        hipLaunchKernelGGL(rotate_bwd_affine_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)dout, (const float4*)vox, xf, mode, dxf, C4, D, H, W, per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_bwd");
     return 0;
 }

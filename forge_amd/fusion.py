@@ -14,8 +14,8 @@ from . import _lib, convops as co
 
 def hip_inference(module, x):
     """The fused HIP convolution path is taken for inference: eval-mode BN (folded into the GEMM epilogue)
-    and no autograd graph. Training keeps the stock torch ops for the dense convs (their backward kernels are
-    the next row to be hand-written), the HIP rotate/render ops have their own backward kernels."""
+    and no autograd graph. With an autograd graph (training, pose refinement) the same GEMM kernel runs with the plain bias epilogue,
+    data / weight gradients on the GEMM / wgrad kernels, and BatchNorm stays a torch module (batch statistics, SyncBN)."""
     return x.is_cuda and x.dtype == torch.float32 and not module.training and not torch.is_grad_enabled()
 
 

@@ -25,7 +25,7 @@ class GraphedForward:
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.no_grad(), torch.cuda.stream(side):
-            for _ in range(warmup):                       # weight packing, MIOpen find, allocator warm-up
+            for _ in range(warmup):                       # weight packing, allocator warm-up
                 model(self.static_in, dataset, device)
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)

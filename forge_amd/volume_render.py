@@ -79,7 +79,12 @@ class VolRender(nn.Module):
         half = (0.5 * (W - 1) * vox, 0.5 * (H - 1) * vox, 0.5 * (D - 1) * vox)
         outs = ops.render_rays(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray,
                                self.min_depth, self.max_depth, half, want_depth=render_depth)
-        rendered_imgs = self._conv_rgb_hip(outs[0]) if hip_inference(self, outs[0]) else F.relu(self.conv_rgb(outs[0].contiguous()))
+        if hip_inference(self, outs[0]):
+            rendered_imgs = self._conv_rgb_hip(outs[0])
+        elif outs[0].is_cuda:
+            rendered_imgs = self._conv_rgb_autograd_hip(outs[0])
+        else:
+            rendered_imgs = F.relu(self.conv_rgb(outs[0].contiguous()))
         rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
         result = [rendered_imgs, rendered_silhouettes]
         if render_depth:
@@ -123,6 +128,24 @@ class VolRender(nn.Module):
         rgb = torch.empty(V, H2, W2, 3, dtype=torch.float32, device=dev)
         co.conv_igemm(mid, 16, 16, None, 0, 0, p["w6"], p["b6"], p["one"], p["zero"], 0.0, None, None, None, rgb, None,
                       g2, ig2, 3, 3, p["taps6"], epilogue=co.EPI_AFFINE_ACT)
+        return rgb.permute(0, 3, 1, 2)
+
+    def _conv_rgb_autograd_hip(self, x):
+        """conv_rgb + ReLU with an autograd graph (training / pose refinement): the transposed convolution and Conv2d(16, 8, k) on the
+        narrow-N GEMM kernel (forward, data gradient) and the narrow weight-gradient kernels, Conv2d(8, 3, k) on the direct
+        kernels; BatchNorm2d (batch statistics / SyncBN) and the activations stay torch ops on the same NHWC memory."""
+        cr = self.conv_rgb
+        rows = x.permute(0, 2, 3, 1)
+        rows = rows if rows.is_contiguous() else rows.contiguous()
+        V, Hr, Wr, C = rows.shape
+
+        def bn_act(bn, r):                                           # r [V,H,W,C] -> BatchNorm2d on the NCHW view, LeakyReLU
+            y = bn(r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            return F.leaky_relu(y if y.is_contiguous() else y.contiguous(), 0.01)
+
+        up = co.convT_s2_rows(rows.reshape(V, 1, Hr, Wr, C), cr[0].weight, cr[0].bias, self.pad_size, 2).reshape(V, 2 * Hr, 2 * Wr, -1)
+        mid = bn_act(cr[4], co.conv2d_rows_any(bn_act(cr[1], up), cr[3].weight, cr[3].bias))
+        rgb = torch.relu(co.conv2d_rows_any(mid, cr[6].weight, cr[6].bias))
         return rgb.permute(0, 3, 1, 2)
 
     def proj_origin(self, camera_params, device):

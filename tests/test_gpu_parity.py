@@ -377,6 +377,37 @@ def test_conv_direct_fwd_dgrad_wgrad_vs_torch(dev, Cin, Cout, dims, k):
     assert (bd.grad.cpu() - b.grad).abs().max().item() < 1e-4 * max(1.0, b.grad.abs().max().item())
 
 
+def test_conv_rgb_autograd_hip_vs_torch(dev):
+    """a7 with an autograd graph (models/volume_render.py:29-37,73): forward, input gradient and every parameter gradient of the HIP
+    path (narrow-N GEMM / narrow wgrad / direct kernels) against torch's own conv autograd on the CPU, BatchNorm in train mode."""
+    import copy
+    from forge_amd import synthetic as syn
+    from forge_amd.volume_render import VolRender
+    torch.manual_seed(3)
+    ref = VolRender(syn.kubric_config()).train()
+    with torch.no_grad():
+        for prm in ref.conv_rgb.parameters():
+            prm.add_(0.05 * torch.randn_like(prm))
+    hip = copy.deepcopy(ref).to(dev)
+    x = torch.randn(3, 16, 24, 40)
+    gy = torch.randn(3, 3, 48, 80)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(ref.conv_rgb(xr))
+    yr.backward(gy)
+    xh = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yh = hip._conv_rgb_autograd_hip(xh)
+    yh.backward(gy.to(dev))
+    rel = lambda a, b: (a.cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+    assert rel(yh.detach(), yr.detach()) < 1e-4
+    assert rel(xh.grad, xr.grad) < 2e-4
+    gscale = max(pr.grad.abs().max().item() for pr in ref.conv_rgb.parameters())
+    for (k, ph), (_, pr) in zip(hip.conv_rgb.named_parameters(), ref.conv_rgb.named_parameters()):
+        # (a conv bias in front of a train-mode BatchNorm has an analytically zero gradient: absolute floor from the overall scale)
+        assert (ph.grad.cpu() - pr.grad).abs().max().item() < 5e-4 * max(pr.grad.abs().max().item(), 1e-2 * gscale), k
+    for bh, br in zip(hip.conv_rgb.buffers(), ref.conv_rgb.buffers()):          # BatchNorm running statistics were updated identically
+        assert rel(bh.float(), br.float()) < 1e-4
+
+
 def test_conv_igemm_strided2d_and_transpose_phases(dev):
     from forge_amd import convops as co
     g = torch.Generator().manual_seed(2)

@@ -36,26 +36,55 @@ __device__ __forceinline__ void taps_ac_false(float sx, float sy, float sz, int 
     t.wz1 = pz - fz; t.wz0 = (fz + 1.f) - pz;
 }
 
+// Voxel traversal order: linear index -> (x, y, z). Plain x-fastest order makes a workgroup's neighbours in time (same XCD, same
+// L2) a full x-row / z-slice of the OUTPUT, whose SOURCE footprint under a rotation is a tilted slab spanning tens of z-slices
+// (44 MB at 64^3 x 128 ch for 20 degrees) - every source row is then re-fetched from HBM for each of its y/z taps. Walking the output
+// in 16^3-voxel cubes (8^3 tiles in 2x2x2 groups) keeps the footprint of the ~256 workgroups in flight on an XCD inside its 4 MiB L2.
+__device__ __forceinline__ void voxel_of(unsigned v, int W, int H, int D, int& x, int& y, int& z) {
+    if (((W | H | D) & 15) == 0) {
+        // 8^3 tiles, themselves grouped 2 x 2 x 2: 4096 consecutive voxels = one 16^3 cube (2 MB of source at 128 channels)
+        const unsigned w = v & 511u, sub = (v >> 9) & 7u;
+        unsigned t = v >> 12;
+        const unsigned nsx = (unsigned)W >> 4, nsy = (unsigned)H >> 4;
+        const unsigned sx = t % nsx; t /= nsx;
+        const unsigned sy = t % nsy;
+        const unsigned sz = t / nsy;
+        x = (int)((sx << 4) | ((sub & 1u) << 3) | (w & 7u));
+        y = (int)((sy << 4) | (((sub >> 1) & 1u) << 3) | ((w >> 3) & 7u));
+        z = (int)((sz << 4) | ((sub >> 2) << 3) | (w >> 6));
+    } else {
+        x = (int)(v % (unsigned)W); v /= (unsigned)W;
+        y = (int)(v % (unsigned)H);
+        z = (int)(v / (unsigned)H);
+    }
+}
+
+// NQ = 16-byte channel groups per thread (c4, c4 + C4/NQ, ...): the tap / weight arithmetic (~150 VALU instructions with IEEE
+// divisions in ATen's order) is the same for every channel of a voxel, and with one group per thread the kernel is VALU-issue
+// bound, not HBM-bound (3.1 TB/s at 64^3 x 128 ch); two groups per thread halve that cost per byte. All index math is 32-bit
+// (a volume holds < 2^31 float4 elements; checked on the host side).
+template <int NQ>
 __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restrict__ vox, const float* __restrict__ xf,
                                                          const int* __restrict__ mode, float4* __restrict__ out,
-                                                         int C4, int D, int H, int W, long long per_vol /* D*H*W*C4 */,
+                                                         int C4, int D, int H, int W, unsigned per_vol /* D*H*W*C4 */,
                                                          unsigned blocks_per_vol) {
     // grid = n * blocks_per_vol; a workgroup never straddles two volumes
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / blocks_per_vol;
-    const long long e = (long long)(bid % blocks_per_vol) * 256 + threadIdx.x;   // element (voxel, c4) in volume
-    if (e >= per_vol) return;
-    const float4* src = vox + (long long)n * per_vol;
-    float4* dst = out + (long long)n * per_vol;
+    const unsigned n = bid / blocks_per_vol;
+    const unsigned CQ = (unsigned)C4 / NQ;                           // threads per voxel
+    const unsigned t = (bid % blocks_per_vol) * 256u + threadIdx.x;  // (voxel in tile order, channel group)
+    if (t >= per_vol / NQ) return;
+    const float4* src = vox + (size_t)n * per_vol;
+    float4* dst = out + (size_t)n * per_vol;
+    const unsigned c4 = t % CQ;
+    int x, y, z;
+    voxel_of(t / CQ, W, H, D, x, y, z);
+    const unsigned e = (((unsigned)z * H + y) * W + x) * C4 + c4;
     if (mode[n] == 0) {            // view 0: pass-through (models/rotate.py:141)
-        dst[e] = src[e];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dst[e + q * CQ] = src[e + q * CQ];
         return;
     }
-    const int c4 = (int)(e % C4);
-    long long v = e / C4;
-    const int x = (int)(v % W); v /= W;
-    const int y = (int)(v % H);
-    const int z = (int)(v / H);
     const float* A = xf + n * 12;  // uniform per workgroup -> scalar loads
     const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
     const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
@@ -63,44 +92,46 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
     const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
     const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
     const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
-    TriTaps t;
-    taps_ac_false(sx, sy, sz, W, H, D, t);
+    TriTaps tp;
+    taps_ac_false(sx, sy, sz, W, H, D, tp);
 
-    const bool vx0 = (unsigned)t.x0 < (unsigned)W, vx1 = (unsigned)(t.x0 + 1) < (unsigned)W;
-    const bool vy0 = (unsigned)t.y0 < (unsigned)H, vy1 = (unsigned)(t.y0 + 1) < (unsigned)H;
-    const bool vz0 = (unsigned)t.z0 < (unsigned)D, vz1 = (unsigned)(t.z0 + 1) < (unsigned)D;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vx0 = (unsigned)tp.x0 < (unsigned)W, vx1 = (unsigned)(tp.x0 + 1) < (unsigned)W;
+    const bool vy0 = (unsigned)tp.y0 < (unsigned)H, vy1 = (unsigned)(tp.y0 + 1) < (unsigned)H;
+    const bool vz0 = (unsigned)tp.z0 < (unsigned)D, vz1 = (unsigned)(tp.z0 + 1) < (unsigned)D;
     if (!((vx0 | vx1) & (vy0 | vy1) & (vz0 | vz1))) {   // fully outside: zeros padding
-        dst[e] = acc;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dst[e + q * CQ] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    // clamped indices + zeroed weights: every load is in-bounds and unconditional (8 in flight)
-    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
-    const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
-    const int za = min(max(t.z0, 0), D - 1), zb = min(max(t.z0 + 1, 0), D - 1);
-    const float wxa = vx0 ? t.wx0 : 0.f, wxb = vx1 ? t.wx1 : 0.f;
-    const float wya = vy0 ? t.wy0 : 0.f, wyb = vy1 ? t.wy1 : 0.f;
-    const float wza = vz0 ? t.wz0 : 0.f, wzb = vz1 ? t.wz1 : 0.f;
-    const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
-    const float4* p = src + c4;
-    const float4 v000 = p[za * sD + ya * sH + xa * sW];
-    const float4 v001 = p[za * sD + ya * sH + xb * sW];
-    const float4 v010 = p[za * sD + yb * sH + xa * sW];
-    const float4 v011 = p[za * sD + yb * sH + xb * sW];
-    const float4 v100 = p[zb * sD + ya * sH + xa * sW];
-    const float4 v101 = p[zb * sD + ya * sH + xb * sW];
-    const float4 v110 = p[zb * sD + yb * sH + xa * sW];
-    const float4 v111 = p[zb * sD + yb * sH + xb * sW];
+    // clamped indices + zeroed weights: every load is in-bounds and unconditional (8 NQ in flight)
+    const unsigned xa = (unsigned)min(max(tp.x0, 0), W - 1), xb = (unsigned)min(max(tp.x0 + 1, 0), W - 1);
+    const unsigned ya = (unsigned)min(max(tp.y0, 0), H - 1), yb = (unsigned)min(max(tp.y0 + 1, 0), H - 1);
+    const unsigned za = (unsigned)min(max(tp.z0, 0), D - 1), zb = (unsigned)min(max(tp.z0 + 1, 0), D - 1);
+    const float wxa = vx0 ? tp.wx0 : 0.f, wxb = vx1 ? tp.wx1 : 0.f;
+    const float wya = vy0 ? tp.wy0 : 0.f, wyb = vy1 ? tp.wy1 : 0.f;
+    const float wza = vz0 ? tp.wz0 : 0.f, wzb = vz1 ? tp.wz1 : 0.f;
+    const unsigned sW = (unsigned)C4, sH = (unsigned)W * C4, sD = (unsigned)H * W * C4;
+    const unsigned o000 = za * sD + ya * sH + xa * sW + c4, o001 = za * sD + ya * sH + xb * sW + c4;
+    const unsigned o010 = za * sD + yb * sH + xa * sW + c4, o011 = za * sD + yb * sH + xb * sW + c4;
+    const unsigned o100 = zb * sD + ya * sH + xa * sW + c4, o101 = zb * sD + ya * sH + xb * sW + c4;
+    const unsigned o110 = zb * sD + yb * sH + xa * sW + c4, o111 = zb * sD + yb * sH + xb * sW + c4;
+    float4 v[NQ][8];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4* p = src + q * CQ;
+        v[q][0] = p[o000]; v[q][1] = p[o001]; v[q][2] = p[o010]; v[q][3] = p[o011];
+        v[q][4] = p[o100]; v[q][5] = p[o101]; v[q][6] = p[o110]; v[q][7] = p[o111];
+    }
     // ATen accumulation order: tnw, tne, tsw, tse, bnw, bne, bsw, bse (t = z0, n = y0, w = x0)
-    acc = f4_fma(wxa * wya * wza, v000, acc);
-    acc = f4_fma(wxb * wya * wza, v001, acc);
-    acc = f4_fma(wxa * wyb * wza, v010, acc);
-    acc = f4_fma(wxb * wyb * wza, v011, acc);
-    acc = f4_fma(wxa * wya * wzb, v100, acc);
-    acc = f4_fma(wxb * wya * wzb, v101, acc);
-    acc = f4_fma(wxa * wyb * wzb, v110, acc);
-    acc = f4_fma(wxb * wyb * wzb, v111, acc);
-    dst[e] = acc;
+    const float w8[8] = {wxa * wya * wza, wxb * wya * wza, wxa * wyb * wza, wxb * wyb * wza,
+                         wxa * wya * wzb, wxb * wya * wzb, wxa * wyb * wzb, wxb * wyb * wzb};
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = f4_fma(w8[k], v[q][k], acc);
+        dst[e + q * CQ] = acc;
+    }
 }
 
 // Gradient w.r.t. the 3x4 affine (pose refinement): per OUTPUT voxel, the upstream gradient dotted with the 8 source taps
@@ -180,23 +211,26 @@ __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __
 // the box P^-1 (q - p0 + (-1, 1)^3): centre P^-1 (q - p0), half extents sum_b |P^-1_ab| (<= sqrt 3 for a rigid pose), ~8 hits among
 // <= 5^3 candidates. Each candidate is re-evaluated with the forward pass's own expressions (same taps, same weights), so the result is
 // the exact transpose of rotate_fwd_kernel; it is deterministic (fixed summation order) and dvox is written, not accumulated.
+template <int NQ>
 __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __restrict__ dout, const float* __restrict__ xf,
                                                                 const int* __restrict__ mode, float4* __restrict__ dvox,
-                                                                int C4, int D, int H, int W, long long per_vol, unsigned blocks_per_vol) {
+                                                                int C4, int D, int H, int W, unsigned per_vol, unsigned blocks_per_vol) {
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int n = bid / blocks_per_vol;
-    const long long e = (long long)(bid % blocks_per_vol) * 256 + threadIdx.x;
-    if (e >= per_vol) return;
-    const float4* g = dout + (long long)n * per_vol;
+    const unsigned n = bid / blocks_per_vol;
+    const unsigned CQ = (unsigned)C4 / NQ;                           // threads per voxel, NQ channel groups each (as in rotate_fwd_kernel)
+    const unsigned tq = (bid % blocks_per_vol) * 256u + threadIdx.x;
+    if (tq >= per_vol / NQ) return;
+    const float4* g = dout + (size_t)n * per_vol;
+    float4* dv = dvox + (size_t)n * per_vol;
+    const unsigned c4 = tq % CQ;
+    int qx, qy, qz;
+    voxel_of(tq / CQ, W, H, D, qx, qy, qz);
+    const unsigned eq = (((unsigned)qz * H + qy) * W + qx) * C4 + c4;
     if (mode[n] == 0) {
-        dvox[(long long)n * per_vol + e] = g[e];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) dv[eq + q * CQ] = g[eq + q * CQ];
         return;
     }
-    const int c4 = (int)(e % C4);
-    long long v = e / C4;
-    const int qx = (int)(v % W); v /= W;
-    const int qy = (int)(v % H);
-    const int qz = (int)(v / H);
     const float* A = xf + n * 12;
     const float Nf[3] = {(float)W, (float)H, (float)D};
     float P[3][3], p0[3];
@@ -223,8 +257,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __
             hi[a] = min((int)floorf(fminf(cc + hh, Nf[a])), (int)Nf[a] - 1);
         }
     }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
+    float4 acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned sW = (unsigned)C4, sH = (unsigned)W * C4, sD = (unsigned)H * W * C4;
     for (int z = lo[2]; z <= hi[2]; ++z) {
         const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
         for (int y = lo[1]; y <= hi[1]; ++y) {
@@ -239,12 +275,15 @@ __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __
                 const unsigned ux = (unsigned)(qx - t.x0), uy = (unsigned)(qy - t.y0), uz = (unsigned)(qz - t.z0);
                 if (ux <= 1u && uy <= 1u && uz <= 1u) {
                     const float w = (ux ? t.wx1 : t.wx0) * (uy ? t.wy1 : t.wy0) * (uz ? t.wz1 : t.wz0);
-                    acc = f4_fma(w, g[z * sD + y * sH + x * sW + c4], acc);
+                    const unsigned off = (unsigned)z * sD + (unsigned)y * sH + (unsigned)x * sW + c4;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = f4_fma(w, g[off + q * CQ], acc[q]);
                 }
             }
         }
     }
-    dvox[(long long)n * per_vol + e] = acc;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dv[eq + q * CQ] = acc[q];
 }
 
 // poses [B][t][16] row-major camera poses -> xf [B*t][12], mode [B*t]: T = P_0 P_i^-1 (models/rotate.py:64-89, general
@@ -306,10 +345,16 @@ extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mo
     if (int rc = check_rotate_args(vox, xf, mode, out, n, C, D, H, W)) return rc;
     const int C4 = C / 4;
     const long long per_vol = (long long)D * H * W * C4;
-    const unsigned bpv = (unsigned)((per_vol + 255) / 256);
+    FORGE_REQUIRE(per_vol < (1ll << 31), FORGE_ESHAPE, "forge_rotate_fwd: a volume holds >= 2^31 float4 elements");
+    const int nq = (C4 >= 16 && C4 % 2 == 0) ? 2 : 1;                  // channel groups per thread (narrow volumes: one, for coalescing)
+    const unsigned bpv = (unsigned)((per_vol / nq + 255) / 256);
     FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_fwd: grid too large");
-    hipLaunchKernelGGL(rotate_fwd_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, per_vol, bpv);
+    if (nq == 2)
+        hipLaunchKernelGGL(rotate_fwd_kernel<2>, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
+    else
+        hipLaunchKernelGGL(rotate_fwd_kernel<1>, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                           (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_fwd");
     return 0;
 }
@@ -333,8 +378,16 @@ extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float
     const long long per_vol = (long long)D * H * W * C4;
     const unsigned bpv = (unsigned)((per_vol + 255) / 256);
     FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_bwd: grid too large");
-    hipLaunchKernelGGL(rotate_bwd_gather_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)dout, xf, mode, (float4*)dvox, C4, D, H, W, per_vol, bpv);
+    FORGE_REQUIRE(per_vol < (1ll << 31), FORGE_ESHAPE, "forge_rotate_bwd: a volume holds >= 2^31 float4 elements");
+    const int nq = (C4 >= 32 && C4 % 4 == 0) ? 4 : (C4 >= 16 && C4 % 2 == 0) ? 2 : 1;   // the candidate tests are per voxel: amortise them
+    const unsigned bpg = (unsigned)((per_vol / nq + 255) / 256);
+#define FORGE_LAUNCH_GATHER(NQv)                                                                                            \
+    hipLaunchKernelGGL(rotate_bwd_gather_kernel<NQv>, dim3(bpg * (unsigned)n), dim3(256), 0, (hipStream_t)stream,           \
+                       (const float4*)dout, xf, mode, (float4*)dvox, C4, D, H, W, (unsigned)per_vol, bpg)
+    if (nq == 4) FORGE_LAUNCH_GATHER(4);
+    else if (nq == 2) FORGE_LAUNCH_GATHER(2);
+    else FORGE_LAUNCH_GATHER(1);
+#undef FORGE_LAUNCH_GATHER
     if (dxf)
         hipLaunchKernelGGL(rotate_bwd_affine_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                            (const float4*)dout, (const float4*)vox, xf, mode, dxf, C4, D, H, W, per_vol, bpv);

@@ -258,6 +258,27 @@ def test_forge_gt_pose_5in5out_vs_oracle(dev):
     assert (masks.cpu() - om).abs().max().item() < 5e-4
 
 
+@pytest.mark.parametrize("t", [1, 2, 3])
+def test_forge_ragged_view_counts_vs_oracle(dev, t):
+    """fewer input views than the training configuration (t = 1: the fusion GRU runs a single step on the un-warped reference view;
+    t = 2, 3: `demo.py` style few-view inputs): same kernels, different sequence lengths / launch plans."""
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(w)
+    model = model.to(dev).eval()
+    sample = syn.make_sample(1, t, 256, 1.5, seed=20 + t)
+    with torch.no_grad():
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+        oi, om = fo.forward_hot_path(sample["images"], sample["cam_poses_cv2_canonicalized"],
+                                     sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
+                                     order_by_distance=True)
+    assert imgs.shape == (t, 3, 256, 256)
+    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
+    assert (masks.cpu() - om).abs().max().item() < 5e-4
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D

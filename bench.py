@@ -83,7 +83,10 @@ def stage_timers(model):
         M = grid[0] * grid[1] * grid[2] * grid[3]
         # the plan forge_conv_igemm itself uses (forge_conv_igemm_plan): names match the rocprofv3 kernel names; a split-K launch
         # (GEMM + reduction kernel) is attributed to its GEMM instantiation
-        tile, ksplit = co.conv_plan(M, Cout, C1 + C2, len(taps), kw.get("epilogue", co.EPI_BIAS), a[12])
+        nphase = 1
+        if tuple(kw.get("phase", (0, 0, 0))) == (-1, -1, -1):       # merged transposed-conv phases: 8 (3-D) or 4 (2-D, D not doubled)
+            nphase = 8 if kw["out_grid"][0] == 2 * grid[1] else 4
+        tile, ksplit = co.conv_plan(M, Cout, C1 + C2, len(taps), kw.get("epilogue", co.EPI_BIAS), a[12], nphase)
         key = "conv_igemm_n16_kernel" if tile == "N" else "conv_igemm_kernel<%s>" % co.TILE_NAMES[tile]
         rec.setdefault(key, []).append((e0, e1, 2.0 * M * Cout * len(taps) * (C1 + C2), (M, Cout, len(taps), C1 + C2)))
         return out

@@ -66,6 +66,13 @@ def convT_phases(w, pad, nd):
     return out
 
 
+def convT_phases_merged(w, pad, nd):
+    """All output phases of convT_phases back to back for ONE forge_conv_igemm launch (phase = (-1,-1,-1)): (taps, wp)."""
+    ph = convT_phases(w, pad, nd)
+    taps = [t for _, tp, _ in ph for t in tp]
+    return taps, torch.cat([wp for _, _, wp in ph], dim=0).contiguous()
+
+
 def convT3d_k4s2p1_phases(w):
     """nn.ConvTranspose3d(k=4, s=2, p=1): 8 phases x 8 taps (per axis p=0: (d=0,k=1), (d=-1,k=3); p=1: (d=+1,k=0), (d=0,k=2))."""
     return convT_phases(w, 1, 3)
@@ -115,11 +122,12 @@ def _splitk_workspace(device):
 TILE_NAMES = {"A": "128, 128, 8", "B": "64, 128, 8", "C": "128, 64, 8", "D": "64, 64, 4", "E": "128, 32, 4"}
 
 
-def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo):
-    """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only)."""
+def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
+    """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only). nphase = 4 / 8
+    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases)."""
     import ctypes
     tile, ks = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(epilogue), int(ldo), SPLITK_WS_BYTES,
+    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
                                                 ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
     return chr(tile.value), ks.value
 
@@ -347,9 +355,9 @@ class _ConvTS2Rows(torch.autograd.Function):
         Cout, k = weight.shape[1], weight.shape[-1]
         Do = 2 * D if nd == 3 else 1
         out = torch.empty(n, Do, 2 * H, 2 * W, Cout, dtype=torch.float32, device=x.device)
-        for (pz, py, px), taps, wp in convT_phases(weight, pad, nd):
-            conv_igemm(x, Cin, Cin, None, 0, 0, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
-                       taps, out_grid=(Do, 2 * H, 2 * W), ostride=2, phase=(pz, py, px), epilogue=EPI_BIAS)
+        taps, wp = convT_phases_merged(weight, pad, nd)
+        conv_igemm(x, Cin, Cin, None, 0, 0, wp, bias, None, None, 1.0, None, None, None, out, None, (n, D, H, W), (D, H, W), Cout, Cout,
+                   taps, out_grid=(Do, 2 * H, 2 * W), ostride=2, phase=(-1, -1, -1), epilogue=EPI_BIAS)
         ctx.save_for_backward(x, weight)
         ctx.meta = (bias is not None, pad, nd, k)
         return out

@@ -56,6 +56,7 @@ struct ConvArgs {
     int Cout, ldo;                         // output channels, output row stride (floats)
     int ntaps;
     int os, pz, py, px, Do, Ho, Wo;        // output voxel = (z os + pz, y os + py, x os + px) in an (Do,Ho,Wo) grid
+    int nphase, tpp;                       // > 1: all output phases of a stride-2 transposed conv in ONE launch: phase p = (pz,py,px) bits uses taps [p tpp, (p+1) tpp)
     int epi;
     int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
     float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
@@ -97,12 +98,21 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int ntile_n = (a.Cout + BN - 1) / BN;
     const unsigned bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = (int)(bid_all % (unsigned)a.ksplit);           // K-slice of this workgroup (split-K for small M x N problems)
-    const unsigned bid = bid_all / (unsigned)a.ksplit;
+    unsigned bid = bid_all / (unsigned)a.ksplit;
+    int phase = 0;
+    if (a.nphase > 1) {                                             // merged transposed-conv phases: workgroups [p tiles, (p+1) tiles) do phase p
+        const unsigned tiles = (unsigned)((M + BM - 1) / BM) * (unsigned)ntile_n;
+        phase = (int)(bid / tiles);
+        bid -= (unsigned)phase * tiles;
+    }
+    const int pz = a.nphase > 1 ? (a.nphase == 8 ? (phase >> 2) & 1 : 0) : a.pz;
+    const int py = a.nphase > 1 ? (phase >> 1) & 1 : a.py, px = a.nphase > 1 ? phase & 1 : a.px;
+    const int t_lo = phase * a.tpp;
     const long long m0 = (long long)(bid / ntile_n) * BM;
     const int n0 = (bid % ntile_n) * BN;
     const int Cin = a.C1 + a.C2;
     const int kchunks = Cin / BK;
-    const int nsteps_all = a.ntaps * kchunks;
+    const int nsteps_all = a.tpp * kchunks;
     const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
     const int nsteps = s_end - s_begin;
 
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 
     const int half = lane >> 5, l31 = lane & 31;
     int t = s_begin / kchunks, kc = s_begin - t * kchunks;
+    t += t_lo;
     prep_tap(t);
     load_step(t, kc);
     store_step(0);
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                             const int x = (int)(q % a.W); q /= a.W;
                             const int y = (int)(q % a.H); q /= a.H;
                             const int z = (int)(q % a.D); q /= a.D;
-                            orow = ((q * a.Do + (z * a.os + a.pz)) * a.Ho + (y * a.os + a.py)) * a.Wo + (x * a.os + a.px);
+                            orow = ((q * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
                         }
                         if constexpr (EPI == EPI_BIAS) {
                             a.out[orow * a.ldo + col] = v;
@@ -370,11 +381,20 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long M = (long long)a.n * a.D * a.H * a.W;
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    int phase = 0;
+    if (a.nphase > 1) {                                             // merged transposed-conv phases (see conv_igemm_kernel)
+        const unsigned tiles = (unsigned)((M + BM16 - 1) / BM16);
+        phase = (int)(bid / tiles);
+        bid -= (unsigned)phase * tiles;
+    }
+    const int pz = a.nphase > 1 ? (a.nphase == 8 ? (phase >> 2) & 1 : 0) : a.pz;
+    const int py = a.nphase > 1 ? (phase >> 1) & 1 : a.py, px = a.nphase > 1 ? phase & 1 : a.px;
+    const int t_lo = phase * a.tpp;
     const long long m0 = (long long)bid * BM16;
     const int Cin = a.C1 + a.C2;
     const int kchunks = Cin / BK16;
-    const int nsteps = a.ntaps * kchunks;
+    const int nsteps = a.tpp * kchunks;
 
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
@@ -436,9 +456,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
         for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
 
     const int kq = lane >> 4, l15 = lane & 15;
-    int t = 0, kc = 0;
-    prep_tap(0);
-    load_step(0, 0);
+    int t = t_lo, kc = 0;
+    prep_tap(t);
+    load_step(t, 0);
     store_step(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
@@ -485,7 +505,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
                         const int x = (int)(q % a.W); q /= a.W;
                         const int y = (int)(q % a.H); q /= a.H;
                         const int z = (int)(q % a.D); q /= a.D;
-                        orow = ((q * a.Do + (z * a.os + a.pz)) * a.Ho + (y * a.os + a.py)) * a.Wo + (x * a.os + a.px);
+                        orow = ((q * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
                     }
                     float v = acc[i][r] + bias;
                     if (a.epi == EPI_AFFINE_ACT) {
@@ -558,12 +578,13 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
 
 using namespace forge;
 
-extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int epilogue, int ldo, long long splitk_ws_bytes,
+extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
                                      int* tile, int* ksplit) {
-    FORGE_REQUIRE(tile && ksplit && M > 0 && Cout > 0 && Cin > 0 && ntaps > 0, FORGE_EINVAL, "forge_conv_igemm_plan: bad argument");
+    FORGE_REQUIRE(tile && ksplit && M > 0 && Cout > 0 && Cin > 0 && ntaps > 0 && (nphase == 1 || nphase == 4 || nphase == 8) && ntaps % nphase == 0,
+                  FORGE_EINVAL, "forge_conv_igemm_plan: bad argument");
     if (Cout <= 16) { *tile = 'N'; *ksplit = 1; return 0; }                         // conv_igemm_n16_kernel
-    const ConvPlan pl = plan_conv(M, Cout, Cin, ntaps,
-                                  splitk_ws_bytes > 0 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
+    const ConvPlan pl = plan_conv(M * nphase, Cout, Cin, ntaps / nphase,
+                                  nphase == 1 && splitk_ws_bytes > 0 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
                                   splitk_ws_bytes);
     *tile = pl.tile; *ksplit = pl.ksplit;
     return 0;
@@ -602,6 +623,15 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                   "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
+    a.nphase = 1; a.tpp = ntaps;
+    if (pz < 0) {   // all output phases of a stride-2 transposed convolution in one launch
+        FORGE_REQUIRE(os == 2 && py < 0 && px < 0 && Ho == 2 * H && Wo == 2 * W && (Do == 2 * D || Do == D), FORGE_EINVAL,
+                      "forge_conv_igemm: merged phases (pz = py = px = -1) need os = 2 and a doubled output grid");
+        a.nphase = Do == 2 * D ? 8 : 4;
+        FORGE_REQUIRE(ntaps % a.nphase == 0, FORGE_EINVAL, "forge_conv_igemm: merged phases need ntaps %% %d == 0", a.nphase);
+        a.tpp = ntaps / a.nphase;
+        a.pz = a.py = a.px = 0;
+    }
     for (int t = 0; t < MAX_TAPS; ++t) {
         for (int k = 0; k < 3; ++k) a.tap[t][k] = (signed char)(t < ntaps ? taps[t * 3 + k] : 0);
         a.tap[t][3] = 0;
@@ -610,19 +640,19 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 16) {
         FORGE_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT, FORGE_EINVAL, "forge_conv_igemm: GRU epilogues need Cout > 16");
-        const long long grid = (M + BM16 - 1) / BM16;
+        const long long grid = (M + BM16 - 1) / BM16 * a.nphase;
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
     } else {
-        const ConvPlan pl = plan_conv(M, Cout, C1 + C2, ntaps,
-                                      splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
+        const ConvPlan pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp,
+                                      a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
                                       splitk_ws_bytes);
         const char tile = pl.tile;
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
 #define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
     do {                                                                                                                   \
-        const long long grid = nblk(BMv, BNv) * a.ksplit;                                                                  \
+        const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase;                                                       \
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
         const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
         static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv>,            \

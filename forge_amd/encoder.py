@@ -325,7 +325,7 @@ class Encoder3D(nn.Module):
 
     def _heads_hip(self, z):
         """Both heads (models/encoder.py:16-34) on one fused volume: the two ConvTranspose3d(128,32,4,s2,p1)+BN+LReLU
-        run as ONE N=64 GEMM per output phase (8 phases x 8 taps), then Conv3d(32,16)+BN and
+        run as ONE N=64 launch covering the 8 output phases x 8 taps, then Conv3d(32,16)+BN and
         Conv3d(32,8)+BN+LReLU read their 32-channel halves of the shared [..,64] tensor in place, then Conv3d(8,1)+ReLU.
         Results are cached per input tensor so get_density3D / get_render_features share the work."""
         memo = getattr(self, "_heads_memo", None)
@@ -338,7 +338,7 @@ class Encoder3D(nn.Module):
                dh[6].weight, dh[6].bias] + [t for bn in (fh[1], dh[1], fh[4], dh[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
 
         def build():
-            ct = co.convT3d_k4s2p1_phases(torch.cat([fh[0].weight, dh[0].weight], dim=1))      # Cout = 32 + 32
+            ct = co.convT_phases_merged(torch.cat([fh[0].weight, dh[0].weight], dim=1), 1, 3)  # Cout = 32 + 32; 8 phases x 8 taps, one launch
             s1 = [torch.cat(v) for v in zip(co.bn_affine(fh[1]), co.bn_affine(dh[1]))]
             w6 = co.pad_cin(co.pack_conv3d_weight(dh[6].weight), 16)
             return {"ct": ct, "ct_b": torch.cat([fh[0].bias, dh[0].bias]).detach().contiguous(), "ct_aff": s1,
@@ -352,10 +352,9 @@ class Encoder3D(nn.Module):
         dev = z.device
         xr = self._rows(z)
         up = torch.empty(n, D2, H2, W2, 64, dtype=torch.float32, device=dev)
-        for (pz, py, px), taps, wp in p["ct"]:
-            co.conv_igemm(xr, C, C, None, 0, 0, wp, p["ct_b"], p["ct_aff"][0], p["ct_aff"][1], 0.01, None, None, None, up, None,
-                          (n, D, H, W), (D, H, W), 64, 64, taps, out_grid=(D2, H2, W2), ostride=2, phase=(pz, py, px),
-                          epilogue=co.EPI_AFFINE_ACT)
+        co.conv_igemm(xr, C, C, None, 0, 0, p["ct"][1], p["ct_b"], p["ct_aff"][0], p["ct_aff"][1], 0.01, None, None, None, up, None,
+                      (n, D, H, W), (D, H, W), 64, 64, p["ct"][0], out_grid=(D2, H2, W2), ostride=2, phase=(-1, -1, -1),
+                      epilogue=co.EPI_AFFINE_ACT)
         g2, ig2 = (n, D2, H2, W2), (D2, H2, W2)
         feat = torch.empty(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)
         co.conv_igemm(up, 32, 64, None, 0, 0, p["f3_w"], p["f3_b"], p["f4"][0], p["f4"][1], 1.0, None, None, None, feat, None,

@@ -94,8 +94,8 @@ class VolRender(nn.Module):
         return tuple(result)
 
     def _conv_rgb_hip(self, x):
-        """conv_rgb + ReLU (models/volume_render.py:29-37,73) on the MFMA GEMM kernel: ConvTranspose2d(16,16,k+1,s2,p) as 4
-        output-phase GEMMs + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
+        """conv_rgb + ReLU (models/volume_render.py:29-37,73) on the MFMA GEMM kernel: ConvTranspose2d(16,16,k+1,s2,p) as its 4
+        output phases in one launch + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
         channels-last memory (what the ray-marcher writes) -> [V,3,2Hr,2Wr] (channels-last memory)."""
         cr = self.conv_rgb
         if not hasattr(self, "_rgb_cache"):
@@ -106,7 +106,7 @@ class VolRender(nn.Module):
         def build():
             w3, taps3 = co.pack_conv2d_weight(cr[3].weight)
             w6, taps6 = co.pack_conv2d_weight(cr[6].weight)
-            return {"ct": co.convT_phases(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
+            return {"ct": co.convT_phases_merged(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
                     "w3": w3, "taps3": taps3, "b3": cr[3].bias.detach().contiguous(), "bn4": co.bn_affine(cr[4]),
                     "w6": co.pad_cin(w6, 16), "taps6": taps6, "b6": cr[6].bias.detach().contiguous(),
                     "one": torch.ones(3, device=x.device), "zero": torch.zeros(3, device=x.device)}
@@ -117,10 +117,9 @@ class VolRender(nn.Module):
         H2, W2 = 2 * Hr, 2 * Wr
         dev = x.device
         up = torch.empty(V, H2, W2, 16, dtype=torch.float32, device=dev)
-        for (pz, py, px), taps, wp in p["ct"]:
-            co.conv_igemm(xr, C, C, None, 0, 0, wp, p["ct_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, up, None,
-                          (V, 1, Hr, Wr), (1, Hr, Wr), 16, 16, taps, out_grid=(1, H2, W2), ostride=2, phase=(0, py, px),
-                          epilogue=co.EPI_AFFINE_ACT)
+        co.conv_igemm(xr, C, C, None, 0, 0, p["ct"][1], p["ct_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, up, None,
+                      (V, 1, Hr, Wr), (1, Hr, Wr), 16, 16, p["ct"][0], out_grid=(1, H2, W2), ostride=2, phase=(-1, -1, -1),
+                      epilogue=co.EPI_AFFINE_ACT)
         g2, ig2 = (V, 1, H2, W2), (1, H2, W2)
         mid = torch.zeros(V, H2, W2, 16, dtype=torch.float32, device=dev)             # 8 real channels + 8 zero (16-wide K-step)
         co.conv_igemm(up, 16, 16, None, 0, 0, p["w3"], p["b3"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, mid, None,

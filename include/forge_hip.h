@@ -129,6 +129,9 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *   out rows                    output voxel of GEMM-grid voxel (z,y,x) is (z os+pz, y os+py, x os+px)
  *                               in an (n,Do,Ho,Wo) grid; row stride ldo floats.
  *                               plain conv: is=os=1, Di=Do=D..; strided conv: is=2; ConvTranspose phase: os=2.
+ *                               pz = py = px = -1 with os = 2: ALL output phases of a stride-2 transposed convolution in one
+ *                               launch - taps / wp hold the phases back to back (8 phases for Do = 2D, 4 for a 2-D grid with
+ *                               Do = D; phase p = pz*4 + py*2 + px uses taps [p*ntaps/P, (p+1)*ntaps/P)); no split-K.
  *   epilogue 0  out = acc + bias
  *            1  out = lrelu((acc + bias) * scale + shift + residual, slope)   eval-BN folded; residual
  *               [rows][ldo] nullable (ResNet shortcut); slope 1 = identity, 0 = ReLU
@@ -155,9 +158,10 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
 
 /* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
  * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
- * *ksplit the number of K-slices (1 = no split-K). Pure host arithmetic (a makespan model of the 256-CU chip), no launch; lets a
+ * *ksplit the number of K-slices (1 = no split-K); nphase = 1, or 4 / 8 for a merged-phase transposed-conv launch (M rows and ntaps / nphase
+ * taps per phase). Pure host arithmetic (a makespan model of the 256-CU chip), no launch; lets a
  * caller size the split-K workspace (ksplit * M * Cout floats) and lets profilers attribute launches to kernel instantiations. */
-int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int epilogue, int ldo, long long splitk_ws_bytes,
+int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
                           int* tile, int* ksplit);
 
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):

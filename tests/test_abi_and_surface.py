@@ -168,6 +168,7 @@ def test_conv_plan_is_host_arithmetic_and_sane():
     t, k = co.conv_plan(5120, 512, 512, 9, co.EPI_AFFINE_ACT, 512)                       # ResNet layer4 3x3 at one scene: split-K
     assert k > 1 and t in "ABCD"
     assert co.conv_plan(5120, 512, 512, 9, co.EPI_GRU_OUT, 512)[1] == 1                  # GRU epilogues cannot be split
+    assert co.conv_plan(32768, 64, 128, 64, co.EPI_AFFINE_ACT, 64, nphase=8)[1] == 1     # merged transposed-conv phases: no split-K
     for M in (1, 63, 5120, 20480, 131072):
         for N in (17, 32, 64, 96, 2048):
             t, k = co.conv_plan(M, N, 64, 1, co.EPI_BIAS, N)

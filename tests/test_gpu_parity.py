@@ -6,6 +6,8 @@ Stated fp32 tolerances (the op is trilinear interpolation / compositing of O(1) 
   backward (vs autograd through the oracle)   max-abs 1e-4 relative to the gradient scale
   full forward vs reference golden            PSNR > 60 dB and max-abs 2e-3 (cuts through ~70 conv layers)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -454,6 +456,29 @@ def test_conv_igemm_strided2d_and_transpose_phases(dev):
         co.conv_igemm(_rows(x).to(dev), 32, 32, None, 0, 0, wp.to(dev), b.to(dev), None, None, 1.0, None, None, None, out, None,
                       (1, 4, 5, 3), (4, 5, 3), 40, 40, tp, out_grid=(8, 10, 6), ostride=2, phase=(pz, py, px), epilogue=co.EPI_BIAS)
     assert (out.permute(0, 4, 1, 2, 3).cpu() - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+    # the same 8 phases merged into ONE launch (phase = (-1,-1,-1)): identical results, for every tile the plan may pick
+    taps_all, wp_all = co.convT_phases_merged(wt, 1, 3)
+    for tile in "CDE":
+        os.environ["FORGE_CONV_TILE"] = tile
+        try:
+            out2 = torch.full((1, 8, 10, 6, 40), float("nan"), device=dev)
+            co.conv_igemm(_rows(x).to(dev), 32, 32, None, 0, 0, wp_all.to(dev), b.to(dev), None, None, 1.0, None, None, None, out2, None,
+                          (1, 4, 5, 3), (4, 5, 3), 40, 40, taps_all, out_grid=(8, 10, 6), ostride=2, phase=(-1, -1, -1), epilogue=co.EPI_BIAS)
+        finally:
+            os.environ.pop("FORGE_CONV_TILE", None)
+        assert torch.equal(out2, out), tile
+    # 2-D, narrow-N kernel: ConvTranspose2d(16, 16, 6, stride 2, padding 2) as 4 merged phases (conv_rgb's first layer)
+    x2 = torch.randn(2, 16, 9, 11, generator=g)
+    wt2 = torch.randn(16, 16, 6, 6, generator=g) / 24
+    b2 = torch.randn(16, generator=g)
+    ref2 = torch.nn.functional.conv_transpose2d(x2, wt2, b2, stride=2, padding=2)
+    taps2, wp2 = co.convT_phases_merged(wt2, 2, 2)
+    o2 = torch.full((2, 1, 18, 22, 16), float("nan"), device=dev)
+    co.conv_igemm(x2.permute(0, 2, 3, 1).contiguous().to(dev), 16, 16, None, 0, 0, wp2.to(dev), b2.to(dev), None, None, 1.0, None, None, None, o2, None,
+                  (2, 1, 9, 11), (1, 9, 11), 16, 16, taps2, out_grid=(1, 18, 22), ostride=2, phase=(-1, -1, -1), epilogue=co.EPI_BIAS)
+    assert (o2[:, 0].permute(0, 3, 1, 2).cpu() - ref2).abs().max().item() < 3e-5 * ref2.abs().max().item()
 
 
 def test_fuse_hip_vs_oracle(dev):

@@ -1,0 +1,128 @@
+/* A host with no Python and no torch: plain C against include/forge_hip.h + the HIP runtime (tests/test_gpu_c_host.py builds
+ * and runs it). Exercises the C-ABI the way a foreign-language binding would: device buffers from hipMalloc, an explicit
+ * stream, integer return codes, forge_last_error.
+ *   1. forge_rotate_fwd: a mode-0 volume comes back bit-identical; an identity affine reproduces the reference's
+ *      align_corners mismatch (interior values shrink towards the centre) - checked against a scalar
+ *      re-computation of the trilinear sample for one voxel;
+ *   2. forge_render_fwd: an empty density volume renders exact zeros; a uniform density d renders opacity 1 - (1 - d)^k;
+ *   3. error path: a NULL pointer returns FORGE_EINVAL and sets forge_last_error.
+ */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "forge_hip.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define CHECK_FORGE(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "forge error %d: %s (%s:%d)\n", rc_, forge_last_error(), __FILE__, __LINE__); return 3; } } while (0)
+#define EXPECT(cond, msg) do { if (!(cond)) { fprintf(stderr, "FAILED: %s (%s:%d)\n", msg, __FILE__, __LINE__); return 1; } } while (0)
+
+int main(void) {
+    printf("forge_version = %d\n", forge_version());
+    hipStream_t st;
+    CHECK_HIP(hipStreamCreate(&st));
+
+    /* ---------------- rotate: 2 volumes of 16^3 x 8 channels, volume 0 = pass-through, volume 1 = identity affine */
+    const int n = 2, C = 8, D = 16;
+    const size_t vol = (size_t)D * D * D * C, bytes = n * vol * sizeof(float);
+    float* h_in = (float*)malloc(bytes);
+    float* h_out = (float*)malloc(bytes);
+    for (size_t i = 0; i < n * vol; ++i) h_in[i] = (float)((i * 2654435761u) % 1000u) / 1000.0f - 0.5f;
+    float h_xf[24] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    int h_mode[2] = {0, 1};
+    float *d_in, *d_out, *d_xf;
+    int* d_mode;
+    CHECK_HIP(hipMalloc((void**)&d_in, bytes));
+    CHECK_HIP(hipMalloc((void**)&d_out, bytes));
+    CHECK_HIP(hipMalloc((void**)&d_xf, sizeof(h_xf)));
+    CHECK_HIP(hipMalloc((void**)&d_mode, sizeof(h_mode)));
+    CHECK_HIP(hipMemcpy(d_in, h_in, bytes, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_xf, h_xf, sizeof(h_xf), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_mode, h_mode, sizeof(h_mode), hipMemcpyHostToDevice));
+    CHECK_FORGE(forge_rotate_fwd(d_in, d_xf, d_mode, d_out, n, C, D, D, D, (forge_stream_t)st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost));
+    EXPECT(memcmp(h_in, h_out, vol * sizeof(float)) == 0, "mode-0 volume must be copied bit-exactly");
+    {   /* voxel (z,y,x) = (5,9,3) of volume 1 under the identity affine: s = 2 i / (D-1) - 1, p = ((s + 1) D - 1) / 2 */
+        const int q[3] = {3, 9, 5};                            /* x, y, z */
+        float p[3]; int i0[3]; float w1[3];
+        for (int a = 0; a < 3; ++a) {
+            const float s = 2.f * (float)q[a] / (float)(D - 1) - 1.f;
+            p[a] = ((s + 1.f) * (float)D - 1.f) * 0.5f;
+            i0[a] = (int)floorf(p[a]);
+            w1[a] = p[a] - (float)i0[a];
+        }
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                const int x = i0[0] + dx, y = i0[1] + dy, z = i0[2] + dz;
+                if (x < 0 || x >= D || y < 0 || y >= D || z < 0 || z >= D) continue;
+                const float w = (dx ? w1[0] : 1.f - w1[0]) * (dy ? w1[1] : 1.f - w1[1]) * (dz ? w1[2] : 1.f - w1[2]);
+                acc += w * h_in[vol + (((size_t)z * D + y) * D + x) * C + c];
+            }
+            const float got = h_out[vol + (((size_t)q[2] * D + q[1]) * D + q[0]) * C + c];
+            EXPECT(fabsf(got - acc) < 1e-5f, "identity-affine warp does not match the scalar trilinear re-computation");
+        }
+        EXPECT(fabsf(p[0] - (float)q[0]) > 1e-3f, "align_corners mismatch: the identity affine must NOT be an identity resample");
+    }
+
+    /* ---------------- render: 1 view of 16 x 16 rays x 24 samples through a 16^3 x 4-channel volume */
+    const int V = 1, Cr = 4, Hr = 16, Wr = 16, S = 24;
+    const size_t nv = (size_t)D * D * D;
+    float* h_feat = (float*)malloc(nv * Cr * sizeof(float));
+    float* h_dens = (float*)calloc(nv, sizeof(float));
+    for (size_t i = 0; i < nv * Cr; ++i) h_feat[i] = 1.0f;
+    /* camera on the +z axis looking at the origin: R = I, T = (0,0,1.5); fx = fy = 16, cx = cy = 8 */
+    float h_cam[16] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 1.5f, 16, 16, 8, 8};
+    int h_v2v[1] = {0};
+    float *d_feat, *d_dens, *d_cam, *d_of, *d_oo;
+    int* d_v2v;
+    CHECK_HIP(hipMalloc((void**)&d_feat, nv * Cr * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&d_dens, nv * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&d_cam, sizeof(h_cam)));
+    CHECK_HIP(hipMalloc((void**)&d_v2v, sizeof(h_v2v)));
+    CHECK_HIP(hipMalloc((void**)&d_of, (size_t)V * Hr * Wr * Cr * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&d_oo, (size_t)V * Hr * Wr * sizeof(float)));
+    CHECK_HIP(hipMemcpy(d_feat, h_feat, nv * Cr * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_dens, h_dens, nv * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_cam, h_cam, sizeof(h_cam), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(d_v2v, h_v2v, sizeof(h_v2v), hipMemcpyHostToDevice));
+    const float half = 0.5f * (float)(D - 1) / (float)D;
+    float* h_of = (float*)malloc((size_t)Hr * Wr * Cr * sizeof(float));
+    float* h_oo = (float*)malloc((size_t)Hr * Wr * sizeof(float));
+    CHECK_FORGE(forge_render_fwd(d_feat, d_dens, d_cam, d_v2v, d_of, d_oo, NULL, V, 1, Cr, D, D, D, Hr, Wr, S, 0.5f, 2.5f, half, half, half, (forge_stream_t)st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipMemcpy(h_of, d_of, (size_t)Hr * Wr * Cr * sizeof(float), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_oo, d_oo, (size_t)Hr * Wr * sizeof(float), hipMemcpyDeviceToHost));
+    for (int i = 0; i < Hr * Wr; ++i) EXPECT(h_oo[i] == 0.0f && h_of[i * Cr] == 0.0f, "empty volume must render exact zeros");
+    /* uniform density 0.1, unit features: every sample inside the cube has d = 0.1, f = 1, so feature == opacity == 1 - 0.9^k */
+    for (size_t i = 0; i < nv; ++i) h_dens[i] = 0.1f;
+    CHECK_HIP(hipMemcpy(d_dens, h_dens, nv * sizeof(float), hipMemcpyHostToDevice));
+    CHECK_FORGE(forge_render_fwd(d_feat, d_dens, d_cam, d_v2v, d_of, d_oo, NULL, V, 1, Cr, D, D, D, Hr, Wr, S, 0.5f, 2.5f, half, half, half, (forge_stream_t)st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    CHECK_HIP(hipMemcpy(h_of, d_of, (size_t)Hr * Wr * Cr * sizeof(float), hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_oo, d_oo, (size_t)Hr * Wr * sizeof(float), hipMemcpyDeviceToHost));
+    {
+        const int centre = (Hr / 2) * Wr + Wr / 2;
+        const float op = h_oo[centre];
+        EXPECT(op > 0.3f && op < 1.0f, "central ray through a uniform fog must be partially opaque");
+        /* samples strictly inside the cube all have d = 0.1; the two boundary samples may be partially interpolated against the zero
+         * padding, so 1 - 0.9^k holds for some integer k within one sample */
+        const float k = logf(1.f - op) / logf(0.9f);
+        EXPECT(k > 5.f && k < (float)S, "opacity is not of the form 1 - (1 - d)^k");
+        /* unit features composite to the opacity, except that the boundary samples interpolate features AND density against the zero
+         * padding (f_s < 1 there): feature <= opacity, within the weight of one boundary sample */
+        for (int c = 0; c < Cr; ++c)
+            EXPECT(h_of[centre * Cr + c] <= op + 1e-6f && h_of[centre * Cr + c] > op - 0.1f && h_of[centre * Cr + c] == h_of[centre * Cr],
+                   "unit features must composite to (just below) the opacity, identically in every channel");
+    }
+
+    /* ---------------- error path */
+    EXPECT(forge_rotate_fwd(NULL, d_xf, d_mode, d_out, n, C, D, D, D, (forge_stream_t)st) == FORGE_EINVAL, "NULL input must return FORGE_EINVAL");
+    EXPECT(strlen(forge_last_error()) > 0, "forge_last_error must describe the failure");
+    printf("C host: rotate + render + error path OK (central opacity %.6f)\n", h_oo[(Hr / 2) * Wr + Wr / 2]);
+    return 0;
+}

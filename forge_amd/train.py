@@ -1,5 +1,6 @@
 """Row f1 — loss assembly and the optimisation step around the model, mirroring the reference's
-scripts/kubric_compute_loss.py (:9-42 `compute_reconstruction_loss`, :121-172 `compute_all_loss_nvs`),
+scripts/kubric_compute_loss.py (:9-42 `compute_reconstruction_loss`, :45-68 `compute_pose_loss`, :71-118 `compute_all_loss`,
+:121-172 `compute_all_loss_nvs`; pinned against the reference's functions by tests/golden/loss_terms.npz),
 scripts/kubric_trainer.py (:21-59: clip-norm 10 (Kubric) / 5 (OmniObject3D), gradient accumulation, optimizer step) and
 utils/train_utils.py (:149-164 `adjust_lr`). Same names, argument order and return tuples, so the reference's trainer can call
 them; the reference's own functions also work unchanged on the forge_amd models (they only call `model(sample, dataset, device)`).
@@ -60,6 +61,47 @@ def compute_all_loss_nvs(config, epoch, sample, dataset, model, losses, device, 
     }
     if config.loss.perceptual_img > 0:
         tgt = torch.cat([clips, clips_nvs], dim=1).reshape(b * t_all, c, h, w)
+        terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
+    if getattr(config.loss, "regu_origin_proj", 0) > 0:
+        terms["regu_origin"] = config.loss.regu_origin_proj * F.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))
+    loss = sum(terms.values())
+    return loss, _publish(losses, terms), rendered_imgs, rendered_masks
+
+
+def compute_pose_loss(config, epoch, sample, dataset, model, losses, device, perceptual_loss=None):
+    """Pose-only training (scripts/kubric_compute_loss.py:45-68: `parameter` in {'pose', 'pose_head'}): model returns
+    (pose dict, origin projection). The reference's origin regulariser branch (epoch >= 100) reads an undefined variable; here it is the
+    same term `compute_all_loss` uses (target (0.5, 0.5))."""
+    pose, origin_proj = model(sample, dataset, device)
+    terms = {
+        "pose": F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]),
+        "trans": F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]),
+    }
+    if getattr(config.loss, "regu_origin_proj", 0) > 0 and epoch >= 100:
+        terms["regu_origin"] = config.loss.regu_origin_proj * F.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))
+    loss = sum(terms.values())
+    return loss, _publish(losses, terms), None, None
+
+
+def compute_all_loss(config, epoch, sample, dataset, model, losses, device, perceptual_loss=None):
+    """Reconstruction + pose loss with the 2t-view layout of the GT-pose model (scripts/kubric_compute_loss.py:71-118)."""
+    rendered_imgs, rendered_masks, origin_proj, pose = model(sample, dataset, device)
+    clips = sample["images"].to(device)
+    masks = sample["fg_probabilities"].to(device)
+    b, t, c, h, w = clips.shape
+    target_imgs, target_masks = clips.reshape(b * t, c, h, w), masks.reshape(b * t, 1, h, w)
+    rendered_imgs = rendered_imgs.reshape(b, 2 * t, c, h, w)
+    rendered_masks = rendered_masks.reshape(b, 2 * t, 1, h, w)
+    terms = {
+        "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
+        "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
+        "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
+        "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
+        "pose": F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]),
+        "trans": F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]),
+    }
+    if config.loss.perceptual_img > 0:
+        tgt = target_imgs.reshape(b, t, c, h, w).repeat(1, 2, 1, 1, 1).reshape(b * 2 * t, c, h, w)
         terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
     if getattr(config.loss, "regu_origin_proj", 0) > 0:
         terms["regu_origin"] = config.loss.regu_origin_proj * F.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))

@@ -141,5 +141,40 @@ def main():
         npz("state_dict_keys_joint", keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
 
 
+def loss_goldens(m):
+    """f1: the reference's four loss functions (scripts/kubric_compute_loss.py) on fixed tensors through a stub model."""
+    import importlib
+    from easydict import EasyDict
+    kcl = importlib.import_module("scripts.kubric_compute_loss")
+    g = torch.Generator().manual_seed(77)
+    b, t, c, h, w = 2, 5, 3, 8, 8
+    sample10 = {"images": torch.rand(b, 2 * t, c, h, w, generator=g), "fg_probabilities": torch.rand(b, 2 * t, 1, h, w, generator=g)}
+    sample5 = {k: v[:, :t].contiguous() for k, v in sample10.items()}
+    r_img, r_msk = torch.rand(b * 2 * t, c, h, w, generator=g), torch.rand(b * 2 * t, 1, h, w, generator=g)
+    origin = torch.rand(b * 2 * t, 2, generator=g)
+    pose = {"pred": torch.randn(b * (t - 1), 7, generator=g), "gt": torch.randn(b * (t - 1), 7, generator=g)}
+    cfg = EasyDict({"loss": {"recon_rgb": 5.0, "recon_mask": 1.0, "perceptual_img": 0.0, "regu_origin_proj": 0.2}})
+    out = {"images": sample10["images"], "fg": sample10["fg_probabilities"], "r_img": r_img, "r_msk": r_msk, "origin": origin,
+           "pose_pred": pose["pred"], "pose_gt": pose["gt"], "recon_rgb": 5.0, "recon_mask": 1.0, "regu_origin_proj": 0.2}
+    cases = {
+        "recon": (kcl.compute_reconstruction_loss, sample5, lambda s, d, dev: (r_img, r_msk), 0),
+        "pose": (kcl.compute_pose_loss, sample5, lambda s, d, dev: (pose, origin), 0),        # epoch 0: the reference's epoch >= 100 branch is broken
+        "all": (kcl.compute_all_loss, sample5, lambda s, d, dev: (r_img, r_msk, origin, pose), 0),
+        "all_nvs": (kcl.compute_all_loss_nvs, sample10, lambda s, d, dev: (r_img, r_msk, origin, pose), 0),
+    }
+    for name, (fn, smp, model, epoch) in cases.items():
+        loss, terms, _, _ = fn(cfg, epoch, smp, None, model, {}, "cpu", None)
+        out["total_" + name] = float(loss)
+        for k, v in terms.items():
+            out["%s__%s" % (name, k)] = float(v)
+        print("  reference %-8s total %.6f  terms %s" % (name, float(loss), {k: round(v, 6) for k, v in terms.items()}))
+    npz("loss_terms", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "loss":          # only the loss fixture (the others are unchanged)
+        os.makedirs(OUT, exist_ok=True)
+        loss_goldens(ref_import.import_reference())
+    else:
+        main()
+        loss_goldens(ref_import.import_reference())

@@ -173,3 +173,31 @@ def test_conv_plan_is_host_arithmetic_and_sane():
         for N in (17, 32, 64, 96, 2048):
             t, k = co.conv_plan(M, N, 64, 1, co.EPI_BIAS, N)
             assert t in "ABCDE" and k == 1                                               # 2 K-steps: never split
+
+
+def test_loss_functions_match_reference_golden():
+    """f1: forge_amd.train's four loss functions against the values the REFERENCE's scripts/kubric_compute_loss.py produced on the same
+    tensors through a stub model (tests/golden/loss_terms.npz, generated by oracle/make_golden.py)."""
+    import types
+    import numpy as np
+    from forge_amd import train as tr
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_terms.npz"))
+    T = lambda k: torch.from_numpy(gold[k])
+    sample10 = {"images": T("images"), "fg_probabilities": T("fg")}
+    sample5 = {k: v[:, :5].contiguous() for k, v in sample10.items()}
+    pose = {"pred": T("pose_pred"), "gt": T("pose_gt")}
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(recon_rgb=float(gold["recon_rgb"]), recon_mask=float(gold["recon_mask"]),
+                                                           perceptual_img=0.0, regu_origin_proj=float(gold["regu_origin_proj"])))
+    cases = {
+        "recon": (tr.compute_reconstruction_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"))),
+        "pose": (tr.compute_pose_loss, sample5, lambda s, d, dev: (pose, T("origin"))),
+        "all": (tr.compute_all_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
+        "all_nvs": (tr.compute_all_loss_nvs, sample10, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
+    }
+    for name, (fn, smp, model) in cases.items():
+        loss, terms, _, _ = fn(cfg, 0, smp, None, model, {}, "cpu", None)
+        assert abs(float(loss) - float(gold["total_" + name])) < 1e-5 * max(1.0, abs(float(gold["total_" + name]))), name
+        ref_terms = {k.split("__", 1)[1]: float(gold[k]) for k in gold.files if k.startswith(name + "__")}
+        assert set(terms) == set(ref_terms), (name, sorted(terms), sorted(ref_terms))
+        for k, v in ref_terms.items():
+            assert abs(terms[k] - v) < 1e-5 * max(1.0, abs(v)), (name, k)

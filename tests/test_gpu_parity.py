@@ -281,6 +281,27 @@ def test_forge_ragged_view_counts_vs_oracle(dev, t):
     assert (masks.cpu() - om).abs().max().item() < 5e-4
 
 
+def test_forge_non_default_render_config_vs_oracle(dev):
+    """the config surface the model reads (config/config.py: render.{volume_size, n_pts_per_ray, min_depth, max_depth, k_size}): a
+    non-default combination - 48 samples on [0.7, 2.3], a 1.2-unit volume, 3x3 conv_rgb kernels (ConvTranspose2d k=4, p=1)."""
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config(volume_size=1.2, n_pts_per_ray=48, min_depth=0.7, max_depth=2.3)
+    cfg.render.k_size = 3
+    model = FORGE(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 5)
+    model.load_state_dict(w)
+    model = model.to(dev).eval()
+    sample = syn.make_sample(1, 4, 256, 1.5, seed=31)
+    with torch.no_grad():
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+        oi, om = fo.forward_hot_path(sample["images"], sample["cam_poses_cv2_canonicalized"],
+                                     sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
+                                     order_by_distance=True)
+    assert imgs.shape == (4, 3, 256, 256)
+    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
+    assert (masks.cpu() - om).abs().max().item() < 5e-4
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D

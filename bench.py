@@ -376,6 +376,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
         print(json.dumps(result), flush=True)
     fdist.barrier()
+    fdist.shutdown()
     return result
 
 

@@ -54,6 +54,12 @@ def barrier():
         dist.barrier()
 
 
+def shutdown():
+    """Tear the default process group down (clean exit of the RCCL communicator); no-op for world size 1."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def psnr_from_sse(sse, count):
     """10 log10(1 / MSE), data_range = 1 (utils/eval_utils.py:8-12)."""
     import math

@@ -142,6 +142,14 @@ class Encoder3D(nn.Module):
             return self.fusion_feature.fuse_autograd_hip(x)             # training / refinement: HIP convs with autograd
         return self.fusion_feature(x, [self.fusion_feature.fusion_conv(x.mean(dim=1))])
 
+    def fuse_groups(self, x, groups):
+        """[self.fuse(x[:, g]) for g in groups], sharing the per-view work between the groups where that pays: with an autograd graph on
+        the MI355X the input halves of the GRU convolutions are computed once per view (ConvGRU_3D.fuse_groups_autograd_hip)."""
+        if (not hip_inference(self, x)) and x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0 and \
+                self.fusion_feature.n_layers == 1 and len(groups) > 1:
+            return self.fusion_feature.fuse_groups_autograd_hip(x, groups)
+        return [self.fuse(x[:, list(g)]) for g in groups]
+
     @staticmethod
     def _bn2d_rows(bn, rows, relu=True):
         y = bn(rows.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)

@@ -81,9 +81,8 @@ class FORGE_poseEstimator3D(nn.Module):
         features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2[:, :t], grid_size=D)
 
         # three fusions: first 3 views, last 2 views, all views (:108-109, :120)
-        features_3v = self.encoder_3d.fuse(features_transformed[:, :3])
-        features_2v = self.encoder_3d.fuse(features_transformed[:, -2:])
-        features_mv = self.encoder_3d.fuse(features_transformed)
+        features_3v, features_2v, features_mv = self.encoder_3d.fuse_groups(
+            features_transformed, [list(range(min(3, t))), list(range(max(t - 2, 0), t)), list(range(t))])
         fused = torch.cat([features_3v, features_2v, features_mv], dim=0)              # [3b,128,D,H,W]
         densities = self.encoder_3d.get_density3D(fused)                               # [3b,1,2D,..]
         features = self.encoder_3d.get_render_features(fused)                          # [3b,16,2D,..]

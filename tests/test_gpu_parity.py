@@ -302,6 +302,33 @@ def test_forge_non_default_render_config_vs_oracle(dev):
     assert (masks.cpu() - om).abs().max().item() < 5e-4
 
 
+def test_fuse_groups_shared_inputs_equals_separate_fusions(dev):
+    """FORGE_poseEstimator3D's three fusions (views (0,1,2), (3,4), (0..4) of the same rotated features) with the input halves of the GRU
+    convolutions computed once per view (fuse_groups_autograd_hip) against three independent fuse_autograd_hip calls: outputs, input
+    gradient and parameter gradients. Stated tolerance: 2e-4 of the respective max magnitude (fp32 summation order, atomics in wgrad)."""
+    import copy
+    from forge_amd.fusion import ConvGRU_3D
+    torch.manual_seed(11)
+    a = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).train()
+    bmod = copy.deepcopy(a)
+    x = (torch.randn(1, 5, 128, 16, 16, 16) * 0.5).to(dev)
+    groups = [[0, 1, 2], [3, 4], [0, 1, 2, 3, 4]]
+    ws = [torch.randn(1, 128, 16, 16, 16, device=dev) for _ in groups]
+    xa = x.clone().requires_grad_(True)
+    outs_a = a.fuse_groups_autograd_hip(xa, groups)
+    sum((o * w).sum() for o, w in zip(outs_a, ws)).backward()
+    xb = x.clone().requires_grad_(True)
+    outs_b = [bmod.fuse_autograd_hip(xb[:, g]) for g in groups]
+    sum((o * w).sum() for o, w in zip(outs_b, ws)).backward()
+    rel = lambda u, v: (u - v).abs().max().item() / max(v.abs().max().item(), 1e-6)
+    for oa, ob in zip(outs_a, outs_b):
+        assert rel(oa.detach(), ob.detach()) < 2e-4
+    assert rel(xa.grad, xb.grad) < 2e-4
+    gscale = max(p.grad.abs().max().item() for p in bmod.parameters() if p.grad is not None)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), bmod.named_parameters()):
+        assert (pa.grad - pb.grad).abs().max().item() < 3e-4 * max(pb.grad.abs().max().item(), 1e-2 * gscale), k
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D

@@ -273,8 +273,8 @@ class ConvGRU_3D(nn.Module):
         lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
         h = self._bn_rows(fc[1], co.conv3x3x3_rows(xr.mean(dim=1), None, fc[0].weight, fc[0].bias), lrelu)
         h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
-        for ti in range(t):
-            h = gru_cell_rows(xr[:, ti], h, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias)
+        for xv in xr.unbind(1):                       # unbind: ONE stack in backward instead of a zero-filled [b,t,...] scatter per view
+            h = gru_cell_rows(xv, h, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias)
         return self.fusion_norm(h.permute(0, 4, 1, 2, 3))
 
     def fuse_groups_autograd_hip(self, x, groups):
@@ -287,14 +287,17 @@ class ConvGRU_3D(nn.Module):
         cell, fc = self.cells[0], self.fusion_conv
         Wg, Wo = cell.conv_gate.weight, cell.out_gate.weight
         flat = xt.reshape(t * b, D, H, W, C)
-        gx_all = co.conv3x3x3_rows(flat, None, Wg[:, :C], None).reshape(t, b, D, H, W, 2 * C)
-        cx_all = co.conv3x3x3_rows(flat, None, Wo[:, :C], None).reshape(t, b, D, H, W, C)
+        # per-view tensors via unbind: their gradients (one per group that uses the view) are summed view-sized and stacked once
+        gx_all = co.conv3x3x3_rows(flat, None, Wg[:, :C], None).reshape(t, b, D, H, W, 2 * C).unbind(0)
+        cx_all = co.conv3x3x3_rows(flat, None, Wo[:, :C], None).reshape(t, b, D, H, W, C).unbind(0)
+        xviews = xt.unbind(0)
         wgh, woh = co._pack3d(Wg[:, C:]), co._pack3d(Wo[:, C:])
         lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
         outs = []
         for grp in groups:
             grp = list(grp)
-            h = self._bn_rows(fc[1], co.conv3x3x3_rows(xt[grp].mean(dim=0), None, fc[0].weight, fc[0].bias), lrelu)
+            xm = sum(xviews[ti] for ti in grp) / float(len(grp))
+            h = self._bn_rows(fc[1], co.conv3x3x3_rows(xm, None, fc[0].weight, fc[0].bias), lrelu)
             h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
             for ti in grp:
                 h = _GRUCellPreRows.apply(gx_all[ti], cx_all[ti], h, wgh, cell.conv_gate.bias, woh, cell.out_gate.bias)

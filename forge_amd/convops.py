@@ -132,21 +132,42 @@ def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
     return chr(tile.value), ks.value
 
 
+MAX_OPERAND_BYTES = (1 << 31) - 1       # 32-bit buffer offsets of the kernel's gathered operands (tests lower it to exercise the chunking)
+
+
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
                bs1=0, bs2=0, lift=0):
-    """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid)."""
+    """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid).
+    The kernel addresses its gathered operands through 32-bit buffer offsets (< 2 GiB per operand); batches whose inputs span more
+    (e.g. 32 scenes of 64^3 x 64-channel head activations) are launched in batch chunks here."""
     n, D, H, W = grid
     Di, Hi, Wi = in_grid
     Do, Ho, Wo = out_grid if out_grid is not None else (D, H, W)
     if wp.shape != (len(taps), Cout, C1 + C2):
         raise ValueError("packed weight %s does not match taps=%d Cout=%d Cin=%d" % (tuple(wp.shape), len(taps), Cout, C1 + C2))
-    p = _lib.ptr
-    _lib.check(_lib.lib().forge_conv_igemm(
-        p(in1), C1, ld1, int(bs1), p(in2), C2, ld2, int(bs2), p(wp), p(bias), p(scale), p(shift), float(slope), p(residual), p(aux_h), p(aux_z),
-        p(out), p(out2), n, D, H, W, istride, Di, Hi, Wi, Cout, ldo, _taps_array(taps), len(taps), ostride,
-        phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), p(_splitk_workspace(out.device)), SPLITK_WS_BYTES,
-        _lib.current_stream()), "forge_conv_igemm")
+    in_rows, out_rows = Di * Hi * Wi, Do * Ho * Wo
+    b1, b2 = (int(bs1) or in_rows), (int(bs2) or in_rows)
+    span = lambda k, br, ld: ((k - 1) * br + in_rows) * ld * 4
+    limit = MAX_OPERAND_BYTES
+    nc = n
+    while nc > 1 and (span(nc, b1, ld1) > limit or (in2 is not None and span(nc, b2, ld2) > limit)):
+        nc = (nc + 1) // 2
+    ws = _splitk_workspace(out.device)
+    L, st, arr = _lib.lib(), _lib.current_stream(), _taps_array(taps)
+
+    def off(t, floats):                       # device pointer of tensor t advanced by `floats` elements (None -> NULL)
+        return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * floats)
+    gate_w = Cout // 2 if epilogue == EPI_GRU_GATES else Cout           # row width of the GRU side tensors
+    for s0 in range(0, n, nc):
+        k = min(nc, n - s0)
+        orow = s0 * out_rows                  # first output row of the chunk (lift: rows of the un-lifted GEMM grid, same product)
+        o_ld = gate_w if epilogue == EPI_GRU_GATES else ldo
+        _lib.check(L.forge_conv_igemm(
+            off(in1, s0 * b1 * ld1), C1, ld1, int(bs1), off(in2, s0 * b2 * ld2), C2, ld2, int(bs2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(scale),
+            _lib.ptr(shift), float(slope), off(residual, orow * (Cout if lift else ldo)), off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
+            off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo, arr, len(taps), ostride,
+            phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st), "forge_conv_igemm")
     return out
 
 

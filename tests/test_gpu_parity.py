@@ -329,6 +329,22 @@ def test_fuse_groups_shared_inputs_equals_separate_fusions(dev):
         assert (pa.grad - pb.grad).abs().max().item() < 3e-4 * max(pb.grad.abs().max().item(), 1e-2 * gscale), k
 
 
+def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
+    """operands beyond the kernel's 2 GiB buffer-offset range are launched in batch chunks (convops.conv_igemm): with the limit lowered
+    so that a 6-scene batch splits into chunks of 2, 1-scene ... the fused-GRU, residual and lifted epilogues must give bit-identical
+    results to the single launch."""
+    from forge_amd import convops as co
+    from forge_amd.fusion import ConvGRU_3D
+    torch.manual_seed(5)
+    gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).eval()
+    x = (torch.randn(6, 3, 128, 8, 8, 8) * 0.5).to(dev)
+    with torch.no_grad():
+        ref = gru.fuse_hip(x).clone()
+        monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 3 * 8 * 8 * 8 * 128 * 4 * 2)          # two scenes' worth of the [b,t,...] input
+        chunked = gru.fuse_hip(x)
+    assert torch.equal(ref, chunked)
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D

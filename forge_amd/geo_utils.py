@@ -10,7 +10,8 @@ import torch.nn.functional as F
 def _se3(rot, trans):
     B = rot.shape[0]
     top = torch.cat([rot, trans.reshape(B, 3, 1)], dim=2)
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=rot.dtype, device=rot.device).expand(B, 1, 4)
+    bottom = torch.zeros(B, 1, 4, dtype=rot.dtype, device=rot.device)        # built on the device (no host->device copy: capturable)
+    bottom[..., 3] = 1.0
     return torch.cat([top, bottom], dim=1)
 
 
@@ -102,3 +103,20 @@ def get_relative_pose(cam_1, cam_2):
 def canonicalize_poses(canonical_pose, cam_poses_rel):
     """utils/geo_utils.py:268-287"""
     return canonical_pose[None] @ cam_poses_rel
+
+
+def inverse_affine(P):
+    """Inverse of affine 4x4 matrices [..., 4, 4] whose last row is (0, 0, 0, 1) - camera poses / extrinsics - in closed form:
+    A^-1 = [b x c, c x a, a x b] / det for the rows a, b, c of the 3x3 block, t' = -A^-1 t. Differentiable torch ops without
+    the LU + info check (a host synchronisation per call) of torch.inverse, so a loop that inverts poses every iteration
+    (pose refinement, kubric_eval.py:412-530) stays asynchronous and can be captured into a hipGraph."""
+    A, t = P[..., :3, :3], P[..., :3, 3]
+    a, b, c = A[..., 0, :], A[..., 1, :], A[..., 2, :]
+    bc, ca, ab = torch.cross(b, c, dim=-1), torch.cross(c, a, dim=-1), torch.cross(a, b, dim=-1)
+    det = (a * bc).sum(dim=-1)[..., None, None]
+    Ai = torch.stack([bc, ca, ab], dim=-1) / det
+    ti = -(Ai @ t[..., None])
+    top = torch.cat([Ai, ti], dim=-1)
+    bottom = torch.zeros_like(top[..., :1, :])
+    bottom[..., 0, 3] = 1.0
+    return torch.cat([top, bottom], dim=-2)

@@ -6,7 +6,8 @@ Every kernel of the loop is a hand-written HIP kernel: the pose gradient flows t
 forge_rotate_bwd (affine gradients) and the data-gradient GEMMs of the ConvGRU / heads; weight gradients are switched off.
 Same optimiser as the reference (Adam, lr 1e-3 rotation / 5e-4 translation, ExponentialLR with gamma = 1), same loss
 (recon_rgb * MSE(rgb) + recon_mask * MSE(mask)); the per-iteration host-side pose metric (`.cpu()` every iteration in the
-reference, kubric_eval.py:508-517) is evaluated only every `log_every` iterations.
+reference, kubric_eval.py:508-517) is evaluated only every `log_every` iterations. The fixed-shape iteration is captured into a
+hipGraph and replayed (`use_graph`).
 """
 import time
 
@@ -17,14 +18,15 @@ from . import geo_utils
 from .model import chose_selected, sequence_from_distance
 
 
-def _render_views(model, config, dataset, features, pose7, K, device):
+def _render_views(model, config, dataset, features, pose7, K, device, canonical=None):
     b, t = features.shape[:2]
     D = features.shape[3]
     rel = model.encoder_traj.toSE3(pose7)                                              # [b(t-1),4,4]
-    can_p = dataset.get_canonical_pose_cv2(device=device)
-    can_e = dataset.get_canonical_extrinsics_cv2(device=device)
+    if canonical is None:                                                              # (pose, extrinsics) of the reference view, on `device`
+        canonical = (dataset.get_canonical_pose_cv2(device=device), dataset.get_canonical_extrinsics_cv2(device=device))
+    can_p, can_e = canonical
     poses = (can_p.unsqueeze(0) @ rel)
-    extr = torch.inverse(poses).reshape(b, t - 1, 4, 4)
+    extr = geo_utils.inverse_affine(poses).reshape(b, t - 1, 4, 4)                      # closed form: no host sync (torch.inverse has one)
     poses = torch.cat([can_p.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), poses.reshape(b, t - 1, 4, 4)], dim=1)
     extr = torch.cat([can_e.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), extr], dim=1)
     ft = model.rotate(voxels=features, camPoses_cv2=poses, grid_size=D)
@@ -38,35 +40,56 @@ def _render_views(model, config, dataset, features, pose7, K, device):
     return imgs, masks, depths, origin, poses
 
 
-def refine_poses(model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, iter_num=500, log_every=0):
+def refine_poses(model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, iter_num=500, log_every=0,
+                 use_graph=True):
     """features [b,t,C,D,H,W] (detached encoder output), poses_cam [b(t-1),7] initial (quat, trans), target_imgs [b*t,3,H,W],
-    target_masks [b*t,1,H,W], K [b,t,3,3]. Returns (refined poses [b(t-1),7], list of losses, seconds per iteration)."""
+    target_masks [b*t,1,H,W], K [b,t,3,3]. Returns (refined poses [b(t-1),7], list of losses, seconds per iteration).
+
+    use_graph: after a few eager iterations (weight packing, allocator warm-up) ONE iteration - forward, loss, backward through every
+    HIP kernel, Adam step - is captured into a hipGraph and replayed; the loop body is fixed-shape and free of host synchronisation
+    (closed-form pose inverses, device-side view ordering, capturable Adam), so the replay does exactly what the eager iteration does."""
     model.eval()
     frozen = [p for p in model.parameters() if p.requires_grad]
     for p in frozen:                                   # no weight gradients: only the poses are optimised
         p.requires_grad_(False)
     try:
         features = features.detach().to(device)
+        target_imgs, target_masks, K = target_imgs.to(device), target_masks.to(device), K.to(device)
+        canonical = (dataset.get_canonical_pose_cv2(device=device), dataset.get_canonical_extrinsics_cv2(device=device))
         rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
         trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
         lr = 0.001
-        opt = torch.optim.Adam([{"params": rot, "lr": lr}, {"params": trans, "lr": lr / 2.0}], lr=lr)
-        sched = torch.optim.lr_scheduler.ExponentialLR(opt, 1.0)
-        w_rgb, w_mask = config.loss.recon_rgb, config.loss.recon_mask
-        history = []
-        warm = min(3, iter_num)
-        t0 = None
-        for it in range(iter_num + 1):
-            if it == warm:                              # time the steady state (first iterations load kernels / warm the allocator)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
+        opt = torch.optim.Adam([{"params": rot, "lr": lr}, {"params": trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
+        w_rgb, w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
+
+        def iteration():
             pose7 = torch.cat([F.normalize(rot), trans], dim=1)
-            imgs, masks, _, _, _ = _render_views(model, config, dataset, features, pose7, K.to(device), device)
+            imgs, masks, _, _, _ = _render_views(model, config, dataset, features, pose7, K, device, canonical)
             loss = w_rgb * F.mse_loss(imgs, target_imgs) + w_mask * F.mse_loss(masks, target_masks)
-            opt.zero_grad()
             loss.backward()
             opt.step()
-            sched.step()
+            return loss.detach()
+
+        history = []
+        warm = min(3, iter_num)
+        graph, static_loss, t0 = None, None, None
+        for it in range(iter_num + 1):
+            if it == warm:                              # time the steady state (first iterations load kernels / warm the allocator)
+                if use_graph:
+                    torch.cuda.synchronize(device)
+                    graph = torch.cuda.CUDAGraph()
+                    opt.zero_grad(set_to_none=True)     # gradients are (re)allocated inside the graph's private pool
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        static_loss = iteration()
+                    # the capture pass did not execute: this iteration is the first replay below
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+            if graph is not None:
+                graph.replay()
+                loss = static_loss
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = iteration()
             if log_every and it % log_every == 0:
                 history.append(loss.item())
         torch.cuda.synchronize(device)

@@ -10,7 +10,7 @@ reach predicted poses through autograd.
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import geo_utils, ops
 
 _SUPPORTED = (16, 32, 48, 64, 128)   # grids the reference pre-computes (models/rotate.py:18-35)
 
@@ -40,7 +40,7 @@ class Rotate_world(nn.Module):
         B, t = camPoses_cv2.shape[:2]
         pose_0 = camPoses_cv2[:, 0:1].repeat(1, t - 1, 1, 1).reshape(B * (t - 1), 4, 4)
         pose_1 = camPoses_cv2[:, 1:].reshape(B * (t - 1), 4, 4)
-        return pose_0 @ torch.inverse(pose_1)
+        return pose_0 @ geo_utils.inverse_affine(pose_1)        # poses are affine (last row 0 0 0 1): closed form, no host sync
 
     def forward(self, voxels, camPoses_cv2, grid_size=32):
         """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged)."""

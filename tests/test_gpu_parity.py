@@ -980,6 +980,36 @@ def test_pose_refinement_recovers_perturbed_poses(dev):
     print("refinement: %.1f ms/iteration (t=3 views), rot err %.2f -> %.2f deg" % (dt * 1e3, e0[0].mean().item(), e1[0].mean().item()))
 
 
+def test_pose_refinement_graph_replay_matches_eager(dev):
+    """f2: the refinement iteration captured into a hipGraph (forward, loss, backward through rotate / fuse / heads / ray-march, Adam)
+    follows the same trajectory as the eager loop (atomics in the backward make the two runs differ in the last bits only)."""
+    from forge_amd import geo_utils, refine
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+    ds = syn.SyntheticDataset(1.5)
+    sample = syn.make_sample(1, 3, 256, 1.5, seed=41)
+    with torch.no_grad():
+        feats = model.encoder_3d.get_feat3D(sample["images"][0].to(dev)).reshape(1, 3, 128, 32, 32, 32)
+        gt7 = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][0, 1:]).to(dev)
+        tgt_i, tgt_m, _, _, _ = refine._render_views(model, cfg, ds, feats, gt7, sample["K_cv2"].to(dev), dev)
+    g = torch.Generator().manual_seed(9)
+    init = gt7.clone()
+    init[:, :4] = torch.nn.functional.normalize(init[:, :4] + 0.03 * torch.randn(2, 4, generator=g).to(dev))
+    init[:, 4:] += 0.02 * torch.randn(2, 3, generator=g).to(dev)
+    runs = [refine.refine_poses(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, iter_num=12, log_every=4, use_graph=ug)
+            for ug in (False, True)]
+    (pe, he, _), (pg, hg, _) = runs
+    assert len(he) == len(hg) == 4
+    # Adam normalises the gradient: the atomics' last-bit noise can move a pose component by a fraction of lr = 1e-3 per step
+    assert (pe - pg).abs().max().item() < 2e-3 and (pe - init).abs().max().item() > 5e-3
+    for a, b in zip(he, hg):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(a))
+    assert hg[-1] < hg[0]
+
+
 def test_row_band_render_equals_full_render_rows(dev):
     """per-ray sharding building block: marching rows [h0,h1) with cy shifted by h0 reproduces those rows of the full render bit for bit."""
     from forge_amd import dist as fd

@@ -26,7 +26,8 @@ init = gt7.clone()
 init[:, :4] = torch.nn.functional.normalize(init[:, :4] + 0.03 * torch.randn(t - 1, 4, device=dev))
 init[:, 4:] += 0.02 * torch.randn(t - 1, 3, device=dev)
 e0 = refine.pose_errors(init, sample["cam_poses_rel_cv2"][0, 1:].to(dev))
-out, hist, dt = refine.refine_poses(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, iter_num=iters, log_every=10)
+use_graph = os.environ.get("REFINE_GRAPH", "1") != "0"
+out, hist, dt = refine.refine_poses(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, iter_num=iters, log_every=10, use_graph=use_graph)
 e1 = refine.pose_errors(out, sample["cam_poses_rel_cv2"][0, 1:].to(dev))
-print("refinement t=%d: %.1f ms/iteration; loss %.5f -> %.5f; rot err %.2f -> %.2f deg; trans err %.4f -> %.4f"
-      % (t, dt * 1e3, hist[0], hist[-1], e0[0].mean().item(), e1[0].mean().item(), e0[1].mean().item(), e1[1].mean().item()))
+print("refinement t=%d (%s): %.1f ms/iteration; loss %.5f -> %.5f; rot err %.2f -> %.2f deg; trans err %.4f -> %.4f"
+      % (t, "hipGraph replay" if use_graph else "eager", dt * 1e3, hist[0], hist[-1], e0[0].mean().item(), e1[0].mean().item(), e0[1].mean().item(), e1[1].mean().item()))

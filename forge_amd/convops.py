@@ -259,7 +259,7 @@ class _ConvTapsRows(torch.autograd.Function):
                         if not sel:
                             continue                                                 # no tap reaches this pixel parity: gradient stays 0
                         ptaps = [(0, (ph_y - taps[i][1]) // 2, (ph_x - taps[i][2]) // 2) for i in sel]
-                        conv_igemm(dy, Cout, Cout, None, 0, 0, wd[sel].contiguous(), None, None, None, 1.0, None, None, None, dx, None,
+                        conv_igemm(dy, Cout, Cout, None, 0, 0, torch.stack([wd[i] for i in sel]), None, None, None, 1.0, None, None, None, dx, None,
                                    (n, 1, H, W), (1, H, W), Cin, Cin, ptaps, out_grid=(1, Hi, Wi), ostride=2, phase=(0, ph_y, ph_x),
                                    epilogue=EPI_BIAS)
             dx1 = dx[..., :C1] if ctx.needs_input_grad[0] else None

@@ -42,3 +42,38 @@ class GraphedForward:
                     self.static_in[k].copy_(v, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+class GraphedStep:
+    """hipGraph capture of a whole fixed-shape optimisation step: `step_fn()` must run forward, loss, backward and the optimizer step on
+    STATIC tensors (inputs that are overwritten in place between replays, parameters, a `capturable=True` optimizer) and return the
+    loss tensor. The eager training step of the b = 1 scene configuration is host-bound (~600 kernel launches from Python per step);
+    the replay is not.
+
+        opt = torch.optim.Adam(params, lr=..., capturable=True)
+        def step_fn():
+            loss = loss_of(model(static_sample, dataset, device))
+            loss.backward(); torch.nn.utils.clip_grad_norm_(params, 10.0); opt.step()
+            return loss.detach()
+        g = GraphedStep(step_fn, opt)          # runs `warmup` eager steps (kernel loading, weight packing, optimizer state), then captures
+        for batch in loader:
+            for k, v in batch.items(): static_sample[k].copy_(v, non_blocking=True)
+            loss = g()                         # one replay = one optimisation step
+
+    Everything inside must be capture-safe: no host synchronisation (`.item()`, `torch.inverse`, `torch.tensor(..., device=cuda)`), no
+    host->device copies. BatchNorm running statistics and Adam's step counters are device tensors updated in place by the replay."""
+
+    def __init__(self, step_fn, optimizer, warmup=3):
+        self.optimizer = optimizer
+        for _ in range(warmup):
+            optimizer.zero_grad(set_to_none=True)
+            step_fn()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)              # gradients are (re)allocated inside the graph's private pool
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss = step_fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss

@@ -19,7 +19,8 @@ cfg = syn.kubric_config()
 model = FORGE_poseEstimator3D(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).train()
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+use_graph = os.environ.get("TRAIN_GRAPH", "0") == "1"       # capture fwd + bwd + clip + Adam into one hipGraph (forge_amd.graph.GraphedStep)
+opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=use_graph)
 sample = {k: v.to(dev) for k, v in syn.make_sample(b, 5, 256, 1.5, seed=3).items()}
 ds = syn.SyntheticDataset(1.5)
 tgt_i = sample["images"].repeat(1, 2, 1, 1, 1).reshape(-1, 3, 256, 256)
@@ -36,6 +37,17 @@ def step():
     return loss
 
 
+if use_graph:
+    from forge_amd.graph import GraphedStep
+
+    def graph_fn():
+        imgs, masks = model(sample, ds, dev)
+        loss = 5.0 * F.mse_loss(imgs, tgt_i) + F.mse_loss(masks, tgt_m)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return loss.detach()
+    step = GraphedStep(graph_fn, opt, warmup=2)
 for _ in range(2):
     l = step()
 torch.cuda.synchronize()
@@ -44,8 +56,8 @@ for _ in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("train step b=%d: %.1f ms/step, %.1f rendered views/s (fwd+bwd+Adam), loss %.5f, peak mem %.1f GB"
-      % (b, dt * 1e3, b * 10 / dt, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
+print("train step b=%d%s: %.1f ms/step, %.1f rendered views/s (fwd+bwd+Adam), loss %.5f, peak mem %.1f GB"
+      % (b, " (hipGraph replay)" if use_graph else "", dt * 1e3, b * 10 / dt, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
 
 if os.environ.get("TRAIN_PROFILE"):
     # per-launch HIP-event timing of every conv GEMM / wgrad launch of one step, grouped by shape

@@ -29,7 +29,7 @@ SIGNATURES = {
     "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 10 + [_P, _LL, _P],
     "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _P, _P],
     "forge_conv_wgrad": [_P, _I, _P, _I, _I, _LL, _P, _I, _I, _LL, _P] + [_I] * 9 + [_P, _I, _P],
-    "forge_conv_direct_fwd": [_P, _I, _P, _P, _P, _I] + [_I] * 6 + [_P, _I, _P],
+    "forge_conv_direct_fwd": [_P, _I, _P, _P, _F, _P, _I] + [_I] * 6 + [_P, _I, _P],
     "forge_conv_direct_dgrad": [_P, _I, _P, _P, _I] + [_I] * 6 + [_P, _I, _P],
     "forge_conv_direct_wgrad": [_P, _I, _P, _I, _P] + [_I] * 6 + [_P, _I, _P],
     "forge_gru_gates_fwd": [_P, _P, _P, _P, _P, _LL, _I, _P],

@@ -311,7 +311,7 @@ class _ConvDirectRows(torch.autograd.Function):
         x = x.contiguous()
         wpc = wp.detach().contiguous()
         out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().forge_conv_direct_fwd(_lib.ptr(x), Cin, _lib.ptr(wpc), _lib.ptr(bias), _lib.ptr(out), Cout, n, D, H, W, Cin, Cout,
+        _lib.check(_lib.lib().forge_conv_direct_fwd(_lib.ptr(x), Cin, _lib.ptr(wpc), _lib.ptr(bias), 1.0, _lib.ptr(out), Cout, n, D, H, W, Cin, Cout,
                                                     _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_fwd")
         ctx.save_for_backward(x, wpc)
         ctx.meta = (tuple(taps), bias is not None)
@@ -336,6 +336,14 @@ class _ConvDirectRows(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.reshape(-1, Cout).sum(dim=0)
         return dx, dwp, db, None
+
+
+def conv_direct(x, ld_in, wp, bias, slope, out, grid, Cin, Cout, taps):
+    """Inference launcher of the direct kernel: out [M][Cout] = LeakyReLU(conv(x [M][ld_in], wp [T][Cout][Cin]) + bias, slope)."""
+    n, D, H, W = grid
+    _lib.check(_lib.lib().forge_conv_direct_fwd(_lib.ptr(x), ld_in, _lib.ptr(wp), _lib.ptr(bias), float(slope), _lib.ptr(out), Cout, n, D, H, W, Cin, Cout,
+                                                _taps_array(taps), len(taps), _lib.current_stream()), "forge_conv_direct_fwd")
+    return out
 
 
 def conv_direct_rows(x, wp, bias, taps):

@@ -15,7 +15,7 @@ namespace forge {
 
 struct DirectArgs {
     const float* a; const float* b; float* o;     // fwd: in, -, out | dgrad: dy, -, dx | wgrad: dy, x, dw
-    const float* w; const float* bias;
+    const float* w; const float* bias; float slope;          // fwd: out = lrelu(conv + bias, slope) (1 = none, 0 = ReLU)
     int lda, ldb, ldo;
     int n, D, H, W, ntaps;
     signed char tap[64][4];
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectArgs a) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < CO; ++c) a.o[m * a.ldo + c] = acc[c];
+        for (int c = 0; c < CO; ++c) a.o[m * a.ldo + c] = acc[c] > 0.f ? acc[c] : acc[c] * a.slope;
     } else {
         float4 acc[CI4];
 #pragma unroll
@@ -168,13 +168,13 @@ static int fill_direct(const char* fn, DirectArgs& a, int n, int D, int H, int W
 
 using namespace forge;
 
-extern "C" int forge_conv_direct_fwd(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
+extern "C" int forge_conv_direct_fwd(const float* in, int ld_in, const float* w, const float* bias, float slope, float* out, int ld_out,
                                      int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream) {
     FORGE_REQUIRE(in && w && out, FORGE_EINVAL, "forge_conv_direct_fwd: null pointer argument");
     DirectArgs a;
     if (int rc = fill_direct("forge_conv_direct_fwd", a, n, D, H, W, Cin, Cout, taps, ntaps)) return rc;
     FORGE_REQUIRE(ld_in >= Cin && ld_in % 4 == 0 && ld_out >= Cout, FORGE_ESHAPE, "forge_conv_direct_fwd: bad row strides");
-    a.a = in; a.b = nullptr; a.o = out; a.w = w; a.bias = bias; a.lda = ld_in; a.ldb = 0; a.ldo = ld_out;
+    a.a = in; a.b = nullptr; a.o = out; a.w = w; a.bias = bias; a.slope = slope; a.lda = ld_in; a.ldb = 0; a.ldo = ld_out;
     const long long M = (long long)n * D * H * W;
     FORGE_DIRECT_DISPATCH(Cin, Cout, hipLaunchKernelGGL((conv_direct_kernel<CI4, CO, false>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                                                         (hipStream_t)stream, a));
@@ -188,7 +188,7 @@ extern "C" int forge_conv_direct_dgrad(const float* dy, int ld_dy, const float* 
     DirectArgs a;
     if (int rc = fill_direct("forge_conv_direct_dgrad", a, n, D, H, W, Cin, Cout, taps, ntaps)) return rc;
     FORGE_REQUIRE(ld_dy >= Cout && ld_dx >= Cin && ld_dx % 4 == 0, FORGE_ESHAPE, "forge_conv_direct_dgrad: bad row strides");
-    a.a = dy; a.b = nullptr; a.o = dx; a.w = w; a.bias = nullptr; a.lda = ld_dy; a.ldb = 0; a.ldo = ld_dx;
+    a.a = dy; a.b = nullptr; a.o = dx; a.w = w; a.bias = nullptr; a.slope = 1.f; a.lda = ld_dy; a.ldb = 0; a.ldo = ld_dx;
     const long long M = (long long)n * D * H * W;
     FORGE_DIRECT_DISPATCH(Cin, Cout, hipLaunchKernelGGL((conv_direct_kernel<CI4, CO, true>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
                                                         (hipStream_t)stream, a));
@@ -202,7 +202,7 @@ extern "C" int forge_conv_direct_wgrad(const float* dy, int ld_dy, const float* 
     DirectArgs a;
     if (int rc = fill_direct("forge_conv_direct_wgrad", a, n, D, H, W, Cin, Cout, taps, ntaps)) return rc;
     FORGE_REQUIRE(ld_dy >= Cout && ld_x >= Cin && ld_x % 4 == 0, FORGE_ESHAPE, "forge_conv_direct_wgrad: bad row strides");
-    a.a = dy; a.b = x; a.o = dw; a.w = nullptr; a.bias = nullptr; a.lda = ld_dy; a.ldb = ld_x; a.ldo = 0;
+    a.a = dy; a.b = x; a.o = dw; a.w = nullptr; a.bias = nullptr; a.slope = 1.f; a.lda = ld_dy; a.ldb = ld_x; a.ldo = 0;
     const long long M = (long long)n * D * H * W;
     long long gx = (M + 255) / 256;
     if (gx > 2048) gx = 2048;                                     // grid-stride: every workgroup ends with a reduction + atomics

@@ -348,12 +348,11 @@ class Encoder3D(nn.Module):
         def build():
             ct = co.convT_phases_merged(torch.cat([fh[0].weight, dh[0].weight], dim=1), 1, 3)  # Cout = 32 + 32; 8 phases x 8 taps, one launch
             s1 = [torch.cat(v) for v in zip(co.bn_affine(fh[1]), co.bn_affine(dh[1]))]
-            w6 = co.pad_cin(co.pack_conv3d_weight(dh[6].weight), 16)
+            w6 = co.pack_conv3d_weight(dh[6].weight)                                       # [27][1][8]: direct (vector-ALU) kernel
             return {"ct": ct, "ct_b": torch.cat([fh[0].bias, dh[0].bias]).detach().contiguous(), "ct_aff": s1,
                     "f3_w": co.pack_conv3d_weight(fh[3].weight), "f3_b": fh[3].bias.detach().contiguous(), "f4": co.bn_affine(fh[4]),
                     "d3_w": co.pack_conv3d_weight(dh[3].weight), "d3_b": dh[3].bias.detach().contiguous(), "d4": co.bn_affine(dh[4]),
-                    "d6_w": w6, "d6_b": dh[6].bias.detach().contiguous(),
-                    "one": torch.ones(1, device=z.device), "zero": torch.zeros(1, device=z.device)}
+                    "d6_w": w6, "d6_b": dh[6].bias.detach().contiguous()}
         p = self._heads_cache.get(src, build)
         n, C, D, H, W = z.shape
         D2, H2, W2 = 2 * D, 2 * H, 2 * W
@@ -367,12 +366,11 @@ class Encoder3D(nn.Module):
         feat = torch.empty(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)
         co.conv_igemm(up, 32, 64, None, 0, 0, p["f3_w"], p["f3_b"], p["f4"][0], p["f4"][1], 1.0, None, None, None, feat, None,
                       g2, ig2, 16, 16, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
-        d8 = torch.zeros(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)          # 8 real channels, zero-padded to the 16-wide K-step
+        d8 = torch.empty(n, D2, H2, W2, 8, dtype=torch.float32, device=dev)
         co.conv_igemm(up[..., 32:], 32, 64, None, 0, 0, p["d3_w"], p["d3_b"], p["d4"][0], p["d4"][1], 0.01, None, None, None, d8, None,
-                      g2, ig2, 8, 16, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+                      g2, ig2, 8, 8, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
         dens = torch.empty(n, D2, H2, W2, 1, dtype=torch.float32, device=dev)
-        co.conv_igemm(d8, 16, 16, None, 0, 0, p["d6_w"], p["d6_b"], p["one"], p["zero"], 0.0, None, None, None, dens, None,
-                      g2, ig2, 1, 1, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+        co.conv_direct(d8, 8, p["d6_w"], p["d6_b"], 0.0, dens, g2, 8, 1, co.TAPS_3x3x3)       # Conv3d(8, 1) + ReLU: 216 MACs per voxel
         res = (feat.permute(0, 4, 1, 2, 3), dens.permute(0, 4, 1, 2, 3))
         self._heads_memo = (weakref.ref(z), z._version, res)
         return res

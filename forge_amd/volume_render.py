@@ -108,8 +108,7 @@ class VolRender(nn.Module):
             w6, taps6 = co.pack_conv2d_weight(cr[6].weight)
             return {"ct": co.convT_phases_merged(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
                     "w3": w3, "taps3": taps3, "b3": cr[3].bias.detach().contiguous(), "bn4": co.bn_affine(cr[4]),
-                    "w6": co.pad_cin(w6, 16), "taps6": taps6, "b6": cr[6].bias.detach().contiguous(),
-                    "one": torch.ones(3, device=x.device), "zero": torch.zeros(3, device=x.device)}
+                    "w6": w6, "taps6": taps6, "b6": cr[6].bias.detach().contiguous()}
         p = self._rgb_cache.get(src, build)
         V, C, Hr, Wr = x.shape
         xr = x.permute(0, 2, 3, 1)
@@ -121,12 +120,11 @@ class VolRender(nn.Module):
                       (V, 1, Hr, Wr), (1, Hr, Wr), 16, 16, p["ct"][0], out_grid=(1, H2, W2), ostride=2, phase=(-1, -1, -1),
                       epilogue=co.EPI_AFFINE_ACT)
         g2, ig2 = (V, 1, H2, W2), (1, H2, W2)
-        mid = torch.zeros(V, H2, W2, 16, dtype=torch.float32, device=dev)             # 8 real channels + 8 zero (16-wide K-step)
+        mid = torch.empty(V, H2, W2, 8, dtype=torch.float32, device=dev)
         co.conv_igemm(up, 16, 16, None, 0, 0, p["w3"], p["b3"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, mid, None,
-                      g2, ig2, 8, 16, p["taps3"], epilogue=co.EPI_AFFINE_ACT)
+                      g2, ig2, 8, 8, p["taps3"], epilogue=co.EPI_AFFINE_ACT)
         rgb = torch.empty(V, H2, W2, 3, dtype=torch.float32, device=dev)
-        co.conv_igemm(mid, 16, 16, None, 0, 0, p["w6"], p["b6"], p["one"], p["zero"], 0.0, None, None, None, rgb, None,
-                      g2, ig2, 3, 3, p["taps6"], epilogue=co.EPI_AFFINE_ACT)
+        co.conv_direct(mid, 8, p["w6"], p["b6"], 0.0, rgb, g2, 8, 3, p["taps6"])              # Conv2d(8, 3, k) + ReLU on the vector ALUs
         return rgb.permute(0, 3, 1, 2)
 
     def _conv_rgb_autograd_hip(self, x):

@@ -180,11 +180,12 @@ int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1,
  * (Conv3d(8, 1, 3), models/encoder.py:31) and of conv_rgb (Conv2d(8, 3, 5), models/volume_render.py:36). A matrix-core tile pads such
  * a layer to 16 or 32 channels on both sides (up to 128x the useful FLOPs); these are streaming problems and run on the vector ALUs.
  * Stride-1 "same" geometry on channels-last rows: in [M][ld_in], w [ntaps][Cout][Cin], taps (dz,dy,dx) inside the (n,D,H,W) grid.
- *   fwd    out[m][co] = bias[co] + sum_t sum_ci w[t][co][ci] in[m + tap_t][ci]          (bias nullable)
+ *   fwd    out[m][co] = act(bias[co] + sum_t sum_ci w[t][co][ci] in[m + tap_t][ci])     (bias nullable; act = LeakyReLU(slope):
+ *          slope 1 = none, 0 = ReLU - the inference path fuses the layer's trailing ReLU)
  *   dgrad  dx[m][ci]  = sum_t sum_co w[t][co][ci] dy[m - tap_t][co]
  *   wgrad  dw[t][co][ci] += sum_m dy[m][co] x[m + tap_t][ci]                              (dw zero-filled by the caller; fp32 atomics)
  */
-int forge_conv_direct_fwd(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
+int forge_conv_direct_fwd(const float* in, int ld_in, const float* w, const float* bias, float slope, float* out, int ld_out,
                           int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream);
 int forge_conv_direct_dgrad(const float* dy, int ld_dy, const float* w, float* dx, int ld_dx,
                             int n, int D, int H, int W, int Cin, int Cout, const int* taps, int ntaps, forge_stream_t stream);

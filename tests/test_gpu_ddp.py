@@ -79,7 +79,20 @@ def test_ddp_two_ranks_equal_one_process_batch_of_two():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    import queue
+    import time
+    res, deadline = [], time.time() + 420
+    while len(res) < len(procs):                     # fail fast when a rank dies instead of waiting out the queue timeout
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("a DDP rank exited with %s before reporting (or the run timed out)" % (dead or "timeout",))
+    res.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

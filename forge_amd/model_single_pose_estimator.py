@@ -83,9 +83,17 @@ class FORGE_poseEstimator3D(nn.Module):
         # three fusions: first 3 views, last 2 views, all views (:108-109, :120)
         features_3v, features_2v, features_mv = self.encoder_3d.fuse_groups(
             features_transformed, [list(range(min(3, t))), list(range(max(t - 2, 0), t)), list(range(t))])
-        fused = torch.cat([features_3v, features_2v, features_mv], dim=0)              # [3b,128,D,H,W]
-        densities = self.encoder_3d.get_density3D(fused)                               # [3b,1,2D,..]
-        features = self.encoder_3d.get_render_features(fused)                          # [3b,16,2D,..]
+        if self.encoder_3d.training:
+            # BatchNorm batch statistics (and the running-stat updates) follow the reference's call structure: the heads run on
+            # cat([3v, 2v]) (:110-111) and on the all-view volume (:121-122) SEPARATELY - one 3b batch would normalise differently
+            f32 = torch.cat([features_3v, features_2v], dim=0)
+            d32, r32 = self.encoder_3d.get_density3D(f32), self.encoder_3d.get_render_features(f32)
+            dm, rm = self.encoder_3d.get_density3D(features_mv), self.encoder_3d.get_render_features(features_mv)
+            densities, features = torch.cat([d32, dm], dim=0), torch.cat([r32, rm], dim=0)
+        else:
+            fused = torch.cat([features_3v, features_2v, features_mv], dim=0)          # eval BN: one [3b,128,D,H,W] batch is the same arithmetic
+            densities = self.encoder_3d.get_density3D(fused)                           # [3b,1,2D,..]
+            features = self.encoder_3d.get_render_features(fused)                      # [3b,16,2D,..]
         if self.config.dataset.name == "omniobject3d":
             densities = densities.clamp(min=0.0, max=1.0)
 

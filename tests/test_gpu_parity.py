@@ -345,6 +345,40 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
     assert torch.equal(ref, chunked)
 
 
+def test_training_loss_and_gradients_vs_oracle_autograd(dev):
+    """End-to-end pin of the TRAINING path: FORGE_poseEstimator3D in train mode (BatchNorm batch statistics, three fusions, heads
+    batched as the reference batches them), loss = 5 MSE(rgb) + MSE(mask), against autograd through the CPU oracle (training=True) on
+    the same sample and weights: loss value, and the gradient of parameters from every stage. Stated tolerance: 1e-2 of each
+    gradient's max magnitude (~150 layers of fp32 forward + backward, fp32 atomics in the weight-gradient kernels)."""
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(w)
+    model = model.to(dev).train()
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=4)
+    tgt_i = sample["images"][0].repeat(2, 1, 1, 1)
+    tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1)
+    imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+    loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i.to(dev)) + torch.nn.functional.mse_loss(masks, tgt_m.to(dev))
+    loss.backward()
+    keys = ["encoder_3d.feature_extraction.0.weight", "encoder_3d.feature_extraction.6.2.conv2.weight", "encoder_3d.conv1.0.weight",
+            "encoder_3d.fusion_feature.cells.0.conv_gate.weight", "encoder_3d.fusion_feature.cells.0.out_gate.bias",
+            "encoder_3d.fusion_feature.fusion_conv.3.weight", "encoder_3d.fusion_feature.fusion_norm.weight",
+            "encoder_3d.features_head.0.weight", "encoder_3d.density_head.3.weight", "encoder_3d.density_head.6.weight",
+            "render.conv_rgb.0.weight", "render.conv_rgb.3.weight", "render.conv_rgb.6.bias"]
+    wo = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in w.items()}
+    oi, om = fo.forward_pose3d_gt(sample, wo, cfg, training=True)
+    lo = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item()))
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref, got = wo[k].grad, named[k].grad.cpu()
+        err = (got - ref).abs().max().item()
+        assert err < 1e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
@@ -365,7 +399,7 @@ def test_training_step_runs(dev):
     g = model.encoder_3d.fusion_feature.cells[0].conv_gate.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
     g0 = model.encoder_3d.feature_extraction[0].weight.grad
-    assert g0 is not None and torch.isfinite(g0).all()
+    assert g0 is not None and torch.isfinite(g0).all() and g0.abs().max().item() > 0      # the gradient reaches the image encoder
 
 
 # ------------------------------------------------------------------ fp32-MFMA implicit-GEMM convolution

@@ -1014,6 +1014,55 @@ def test_pose_refinement_recovers_perturbed_poses(dev):
     print("refinement: %.1f ms/iteration (t=3 views), rot err %.2f -> %.2f deg" % (dt * 1e3, e0[0].mean().item(), e1[0].mean().item()))
 
 
+def test_refinement_pose_gradient_vs_oracle_autograd(dev):
+    """End-to-end pin of row f2's objective: d loss / d (quaternion, translation) of the non-reference views through pose algebra ->
+    rotate (affine gradient) -> view ordering -> fuse -> heads -> ray-march (camera gradient) -> conv_rgb, against autograd through
+    the CPU oracle on the same features and weights. Stated tolerance: 2e-2 of the gradient's max magnitude."""
+    from forge_amd import geo_utils, refine
+    from forge_amd.model import FORGE, chose_selected, sequence_from_distance
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(w)
+    model = model.to(dev).eval()
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    ds = syn.SyntheticDataset(1.5)
+    t = 3
+    sample = syn.make_sample(1, t, 256, 1.5, seed=51)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(1, t, 128, 32, 32, 32, generator=g) * 0.5
+    pose7 = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][0, 1:t])
+    pose7[:, :4] = torch.nn.functional.normalize(pose7[:, :4] + 0.02 * torch.randn(t - 1, 4, generator=g))
+    tgt_i, tgt_m = torch.rand(t, 3, 256, 256, generator=g), torch.rand(t, 1, 256, 256, generator=g)
+    K = sample["K_cv2"][:, :t]
+    # HIP path
+    ph = pose7.clone().to(dev).requires_grad_(True)
+    imgs, masks, _, _, _ = refine._render_views(model, cfg, ds, feats.to(dev), ph, K.to(dev), dev)
+    lh = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i.to(dev)) + torch.nn.functional.mse_loss(masks, tgt_m.to(dev))
+    lh.backward()
+    # oracle path (same pose algebra in torch on the CPU, then the oracle's stages)
+    po = pose7.clone().requires_grad_(True)
+    rel = geo_utils.quat2mat(po)
+    can_p, can_e = ds.get_canonical_pose_cv2(device="cpu"), ds.get_canonical_extrinsics_cv2(device="cpu")
+    poses = can_p.unsqueeze(0) @ rel
+    extr = torch.inverse(poses)
+    poses = torch.cat([can_p.reshape(1, 1, 4, 4), poses.reshape(1, t - 1, 4, 4)], dim=1)
+    extr = torch.cat([can_e.reshape(1, 1, 4, 4), extr.reshape(1, t - 1, 4, 4)], dim=1).reshape(t, 4, 4)
+    ft = fo.rotate_world(feats, poses, cfg.render.volume_size)
+    ft = chose_selected(ft, sequence_from_distance(poses[:, :, :3, 3]))
+    fm = fo.fuse(ft, w)
+    dm, rm = fo.density_head(fm, w), fo.render_features_head(fm, w)
+    rep = lambda v: v.repeat(t, 1, 1, 1, 1)
+    oi, om = fo.vol_render(rep(rm), rep(dm), extr[:, :3, :3], extr[:, :3, 3], K.reshape(t, 3, 3), w, cfg.dataset.img_size,
+                           cfg.render.n_pts_per_ray, cfg.render.min_depth, cfg.render.max_depth, cfg.render.volume_size, cfg.render.k_size)[:2]
+    lo = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
+    lo.backward()
+    assert abs(lh.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item()))
+    err = (ph.grad.cpu() - po.grad).abs().max().item()
+    assert err < 2e-2 * po.grad.abs().max().item(), (err, po.grad.abs().max().item())
+
+
 def test_pose_refinement_graph_replay_matches_eager(dev):
     """f2: the refinement iteration captured into a hipGraph (forward, loss, backward through rotate / fuse / heads / ray-march, Adam)
     follows the same trajectory as the eager loop (atomics in the backward make the two runs differ in the last bits only)."""

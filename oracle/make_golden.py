@@ -141,6 +141,46 @@ def main():
         npz("state_dict_keys_joint", keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
 
 
+TRAIN_KEYS = ["encoder_3d.feature_extraction.0.weight", "encoder_3d.feature_extraction.7.2.bn3.weight", "encoder_3d.conv1.0.bias",
+              "encoder_3d.conv1.1.weight", "encoder_3d.fusion_feature.cells.0.conv_gate.bias", "encoder_3d.fusion_feature.cells.0.out_gate.bias",
+              "encoder_3d.fusion_feature.fusion_conv.4.weight", "encoder_3d.fusion_feature.fusion_norm.weight",
+              "encoder_3d.fusion_feature.fusion_norm.bias", "encoder_3d.features_head.1.weight", "encoder_3d.features_head.3.bias",
+              "encoder_3d.density_head.3.bias", "encoder_3d.density_head.6.weight", "encoder_3d.density_head.6.bias",
+              "render.conv_rgb.0.weight", "render.conv_rgb.1.weight", "render.conv_rgb.3.weight", "render.conv_rgb.6.weight",
+              "render.conv_rgb.6.bias"]
+
+
+def train_goldens(m):
+    """Training path of the REFERENCE itself: FORGE_poseEstimator3D.train() (BatchNorm batch statistics, its own head batching),
+    loss = 5 MSE(rgb) + MSE(mask) on a seeded sample and seeded weights (neither stored: both are regenerated from the seeds), backward.
+    The fixture holds the loss and the gradients of small parameters from every stage."""
+    cfg = ref_import.kubric_config()
+    model = m["models.model_single_pose_estimator"].FORGE_poseEstimator3D(cfg)
+    sdm = syn.seeded_state_dict(model.state_dict(), 0)
+    model.load_state_dict(sdm)
+    model.train()
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=4)
+    ds = syn.SyntheticDataset(1.5)
+    tgt_i = sample["images"][0].repeat(2, 1, 1, 1)
+    tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1)
+    imgs, masks = model({k: v.clone() for k, v in sample.items()}, ds, "cpu")
+    loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, tgt_m)
+    loss.backward()
+    named = dict(model.named_parameters())
+    out = {"sample_seed": 4, "weight_seed": 0, "loss": float(loss), "imgs_sub": imgs.detach()[:, :, ::16, ::16], "masks_sub": masks.detach()[:, :, ::16, ::16]}
+    for k in TRAIN_KEYS:
+        out["grad__" + k] = named[k].grad
+    # the oracle in training mode against the same run
+    wo = {k: (v.clone().requires_grad_(True) if k in TRAIN_KEYS else v.clone()) for k, v in sdm.items()}
+    oi, om = fo.forward_pose3d_gt(sample, wo, cfg, training=True)
+    lo = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
+    lo.backward()
+    print("  training: loss reference %.6f oracle %.6f" % (float(loss), float(lo)))
+    for k in TRAIN_KEYS:
+        err("grad " + k.split(".", 1)[1][-34:], named[k].grad, wo[k].grad)
+    npz("train_pose3d", **out)
+
+
 def loss_goldens(m):
     """f1: the reference's four loss functions (scripts/kubric_compute_loss.py) on fixed tensors through a stub model."""
     import importlib
@@ -172,9 +212,10 @@ def loss_goldens(m):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "loss":          # only the loss fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("loss", "train"):   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
-        loss_goldens(ref_import.import_reference())
+        {"loss": loss_goldens, "train": train_goldens}[sys.argv[1]](ref_import.import_reference())
     else:
         main()
         loss_goldens(ref_import.import_reference())
+        train_goldens(ref_import.import_reference())

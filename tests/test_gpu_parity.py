@@ -379,6 +379,32 @@ def test_training_loss_and_gradients_vs_oracle_autograd(dev):
         assert err < 1e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
 
 
+def test_training_gradients_vs_reference_golden(dev, golden):
+    """The HIP training path against the REFERENCE's own training run (tests/golden/train_pose3d.npz: loss and gradients produced by
+    models/model_single_pose_estimator.py FORGE_poseEstimator3D.train() + backward in the build container)."""
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    gold = golden("train_pose3d")
+    cfg = syn.kubric_config()
+    model = FORGE_poseEstimator3D(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), int(gold["weight_seed"])))
+    model = model.to(dev).train()
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=int(gold["sample_seed"]))
+    tgt_i = sample["images"][0].repeat(2, 1, 1, 1).to(dev)
+    tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1).to(dev)
+    imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+    loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, tgt_m)
+    loss.backward()
+    assert abs(loss.item() - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    assert (imgs.detach()[:, :, ::16, ::16].cpu() - torch.from_numpy(gold["imgs_sub"])).abs().max().item() < 2e-3
+    keys = [k[len("grad__"):] for k in gold.files if k.startswith("grad__")]
+    gscale = max(float(np.abs(gold["grad__" + k]).max()) for k in keys)
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = torch.from_numpy(gold["grad__" + k])
+        err = (named[k].grad.cpu() - ref).abs().max().item()
+        assert err < 1e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
+
+
 def test_training_step_runs(dev):
     """fwd + bwd + Adam through the HIP ops in train mode (BN batch stats), loss finite and decreasing grads exist."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D

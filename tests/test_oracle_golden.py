@@ -132,3 +132,31 @@ def test_c_restatement_matches_golden(golden):
     raw = c_oracle.render(g["feat"], g["dens"], g["R"], g["T"], Kh, img // 2, img // 2, int(g["n_pts"]),
                           float(g["min_depth"]), float(g["max_depth"]), (h, h, h))
     assert np.abs(raw - g["raw"]).max() < 3e-5
+
+
+def test_training_loss_and_gradients_golden():
+    """The oracle in TRAINING mode (BatchNorm batch statistics, three fusions, the reference's head batching) against the loss and
+    gradients the reference's own FORGE_poseEstimator3D.train() produced on the same seeded sample and weights
+    (tests/golden/train_pose3d.npz, oracle/make_golden.py::train_goldens)."""
+    import os
+    import numpy as np
+    from forge_amd import synthetic as syn
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_pose3d.npz"))
+    cfg = syn.kubric_config()
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    w = syn.seeded_state_dict(FORGE_poseEstimator3D(cfg).state_dict(), int(gold["weight_seed"]))
+    keys = [k[len("grad__"):] for k in gold.files if k.startswith("grad__")]
+    wo = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in w.items()}
+    sample = syn.make_sample(1, 5, 256, 1.5, seed=int(gold["sample_seed"]))
+    tgt_i = sample["images"][0].repeat(2, 1, 1, 1)
+    tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1)
+    oi, om = fo.forward_pose3d_gt(sample, wo, cfg, training=True)
+    loss = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(gold["loss"])) < 1e-5 * abs(float(gold["loss"]))
+    assert (oi.detach()[:, :, ::16, ::16] - torch.from_numpy(gold["imgs_sub"])).abs().max().item() < 1e-3      # train-mode BN amplifies fp32 noise
+    gscale = max(float(np.abs(gold["grad__" + k]).max()) for k in keys)
+    for k in keys:
+        ref = torch.from_numpy(gold["grad__" + k])
+        err = (wo[k].grad - ref).abs().max().item()
+        assert err < 5e-3 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err)

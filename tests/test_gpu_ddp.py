@@ -25,16 +25,17 @@ def _free_port():
     return p
 
 
-def _build(dev):
+def _build(dev, batch_stats=False):
     from forge_amd import synthetic as syn
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
     cfg = syn.kubric_config()
     model = FORGE_poseEstimator3D(cfg)
     model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
     model = model.to(dev).train()
-    for m in model.modules():                       # running statistics: per-rank batch statistics would differ from the batch-of-2 run
-        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
-            m.eval()
+    if not batch_stats:
+        for m in model.modules():                   # running statistics: per-rank batch statistics would differ from the batch-of-2 run
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
     return cfg, model
 
 
@@ -53,14 +54,16 @@ def _sample(seeds, dev):
     return {k: torch.cat([p[k] for p in parts], dim=0).to(dev) for k in parts[0]}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, sync_bn=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd
     fd.init()                                       # 2 ranks on 1 GPU -> gloo, both on cuda:0
     dev = torch.device("cuda", torch.cuda.current_device())
-    _, model = _build(dev)
+    _, model = _build(dev, batch_stats=sync_bn)
+    if sync_bn:                                     # the reference's configuration (kubric_train_pose_3D.py:119-124): statistics over all ranks
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
     loss = _loss(ddp, _sample([100 + rank], dev), dev)
     loss.backward()
@@ -72,11 +75,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_ddp_two_ranks_equal_one_process_batch_of_two():
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_ddp_two_ranks_equal_one_process_batch_of_two(sync_bn):
+    """sync_bn = False: BatchNorm on running statistics (eval) in every module; sync_bn = True: SyncBatchNorm.convert_sync_batchnorm + train
+    mode, i.e. batch statistics over both ranks - which must equal ordinary train-mode BatchNorm over the batch of 2 in one process."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sync_bn)) for r in range(2)]
     for p in procs:
         p.start()
     import queue
@@ -101,7 +107,7 @@ def test_ddp_two_ranks_equal_one_process_batch_of_two():
         assert (res[0][2][k] == res[1][2][k]).all(), k
     # one process, both scenes as a batch of 2: mean loss over 2 scenes -> the same averaged gradients
     dev = torch.device("cuda:0")
-    _, model = _build(dev)
+    _, model = _build(dev, batch_stats=sync_bn)
     loss = _loss(model, _sample([100, 101], dev), dev)
     loss.backward()
     assert abs(float(loss.detach()) - 0.5 * (res[0][1] + res[1][1])) < 1e-5 * max(1.0, abs(float(loss.detach())))
@@ -109,4 +115,5 @@ def test_ddp_two_ranks_equal_one_process_batch_of_two():
     for k in KEYS:
         ref = named[k].grad.detach().cpu()
         err = (torch.from_numpy(res[0][2][k]) - ref).abs().max().item()
-        assert err < 2e-4 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
+        gscale = max(named[kk].grad.abs().max().item() for kk in KEYS)
+        assert err < (1e-2 if sync_bn else 2e-4) * max(ref.abs().max().item(), 1e-3 * gscale) + 1e-9, (k, err, ref.abs().max().item())

@@ -117,3 +117,59 @@ def test_ddp_two_ranks_equal_one_process_batch_of_two(sync_bn):
         err = (torch.from_numpy(res[0][2][k]) - ref).abs().max().item()
         gscale = max(named[kk].grad.abs().max().item() for kk in KEYS)
         assert err < (1e-2 if sync_bn else 2e-4) * max(ref.abs().max().item(), 1e-3 * gscale) + 1e-9, (k, err, ref.abs().max().item())
+
+
+def _ray_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from forge_amd import dist as fd, ops, synthetic as syn
+    fd.init()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    D, C, V, Hr, S = 64, 16, 3, 128, 64
+    feat, dens = syn.blob_volumes(1, D, C, seed=5)
+    feat, dens = feat.to(dev), dens.to(dev)
+    _, extr, _ = syn.orbit_cameras(10, 1.5, 15.0)
+    E = extr[:V]
+    K = syn.intrinsics(256) / 2.0
+    cam = torch.cat([E[:, :3, :3].reshape(V, 9), E[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1), K[0, 2].expand(V, 1),
+                     K[1, 2].expand(V, 1)], dim=1).contiguous().to(dev)
+    v2v = torch.zeros(V, dtype=torch.int32, device=dev)
+    h = [0.5 * (D - 1) / D] * 3
+    with torch.no_grad():
+        got = fd.render_rays_sharded(feat, dens, cam, v2v, Hr, Hr, S, 0.5, 2.0, h, True)       # each rank marches its row band, one all_gather
+        ref = ops.render_rays(feat, dens, cam, v2v, Hr, Hr, S, 0.5, 2.0, h, True)
+    torch.cuda.synchronize()
+    q.put((rank, [bool(torch.equal(a, b)) for a, b in zip(got, ref)], [tuple(a.shape) for a in got]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ray_sharded_render_two_ranks_on_the_gpu():
+    """BASELINE configs[4] "per-ray sharding": two ranks (sharing the test box's GPU, gloo) each ray-march a band of image rows of every
+    view with the HIP kernel and all_gather the bands; the assembled images equal the single-launch render bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ray_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    res, deadline = [], time.time() + 240
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("a rank exited with %s before reporting (or the run timed out)" % (dead or "timeout",))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, equal, shapes in res:
+        assert all(equal), (rank, equal)
+        assert shapes == [(3, 16, 128, 128), (3, 1, 128, 128), (3, 1, 128, 128)]

@@ -373,6 +373,11 @@ def main():
             import forge_oracle as fo
             result["psnr_vs_oracle_db"] = fo.psnr(out[0][:V_OUT].cpu(), ref[0])
             result["max_abs_err_vs_oracle"] = (out[0][:V_OUT].cpu() - ref[0]).abs().max().item()
+            # north_star: "PSNR within 0.1 dB of reference" - PSNR of both against the same target images (the scene's input views; with
+            # random-init weights the absolute value is meaningless, the DIFFERENCE is the criterion)
+            tgt = sample_cpu["images"][0, :V_OUT]
+            p_build, p_oracle = fo.psnr(out[0][:V_OUT].cpu(), tgt), fo.psnr(ref[0], tgt)
+            result["psnr_to_target_db"] = {"build": p_build, "oracle": p_oracle, "abs_diff": abs(p_build - p_oracle)}
             result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
         print(json.dumps(result), flush=True)
     fdist.barrier()

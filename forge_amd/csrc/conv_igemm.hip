@@ -144,16 +144,53 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         boff[j] = (n0 + br[j]) < a.Cout ? (unsigned)(((n0 + br[j]) * Cin + bsrc) * 4) : OOB;
     }
 
-    int erow[ACH], erow2[ACH];                                   // input row index (in1 / in2) of each A row for the current tap (-1: outside)
-    auto prep_tap = [&](int t) {
-        const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
+    // 128x128 tile (tap-inner K order, below): switching taps every K-step must be cheap. Per A row: bit t of vmask = tap t lands
+    // inside the input grid; the input row of tap t is base + delta(t) with the uniform delta(t) = (dz Hi + dy) Wi + dx (LDS table),
+    // so a tap switch costs a shift, a test and an add per row. The other tiles switch taps once per Cin / 32 K-steps and compute it directly.
+    constexpr bool KC_OUTER = (BM == 128 && BN == 128);
+    __shared__ int sdelta[KC_OUTER ? MAX_TAPS : 1];
+    unsigned long long vmask[KC_OUTER ? ACH : 1];
+    int base1[KC_OUTER ? ACH : 1], base2[KC_OUTER ? ACH : 1];
+    if constexpr (KC_OUTER) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
-            const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
-            const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
-            const int sp = (zi * a.Hi + yi) * a.Wi + xi;
-            erow[j] = ok ? an[j] * (int)a.bs1r + sp : -1;
-            erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
+            const int sp = (az[j] * a.Hi + ay[j]) * a.Wi + ax[j];
+            base1[j] = an[j] * (int)a.bs1r + sp;
+            base2[j] = an[j] * (int)a.bs2r + sp;
+            vmask[j] = 0ull;
+        }
+        for (int tt = 0; tt < a.ntaps; ++tt) {
+            const int dz = a.tap[tt][0], dy = a.tap[tt][1], dx = a.tap[tt][2];
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
+                const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+                vmask[j] |= (unsigned long long)ok << tt;
+            }
+        }
+        if (tid < a.ntaps) sdelta[tid] = (a.tap[tid][0] * a.Hi + a.tap[tid][1]) * a.Wi + a.tap[tid][2];
+        __syncthreads();
+    }
+    int erow[ACH], erow2[ACH];                                   // input row index (in1 / in2) of each A row for the current tap (-1: outside)
+    auto prep_tap = [&](int t) {
+        if constexpr (KC_OUTER) {
+            const int delta = sdelta[t];
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                const bool ok = (vmask[j] >> t) & 1ull;
+                erow[j] = ok ? base1[j] + delta : -1;
+                erow2[j] = ok ? base2[j] + delta : -1;
+            }
+        } else {
+            const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
+                const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
+                const int sp = (zi * a.Hi + yi) * a.Wi + xi;
+                erow[j] = ok ? an[j] * (int)a.bs1r + sp : -1;
+                erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
+            }
         }
     };
     float4 ra[ACH], rb[BCH];
@@ -190,7 +227,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
-    int t = s_begin / kchunks, kc = s_begin - t * kchunks;
+    // K order of the 128x128 tile: channel chunk OUTER, tap INNER. All workgroups of an XCD walk the taps of one 32-channel slice of
+    // their rows before moving to the next slice, so the slice (128 B per row, ~0.7 MB per XCD with its halo) stays in the 4 MiB L2
+    // across the 27 taps; with the tap outer the per-tap working set is the full 1 KB rows = the whole L2 and every tap re-fetches them
+    // from the fabric (ConvGRU gates launch: 502 -> 132 MB of L2 fills per launch, FETCH_SIZE). The 64-row tiles keep the tap outer:
+    // they measured 3-4 % slower with the chunk outer (tools/conv_ab.py).
+    int kc, t;
+    if constexpr (KC_OUTER) { kc = s_begin / a.tpp; t = s_begin - kc * a.tpp; }
+    else { t = s_begin / kchunks; kc = s_begin - t * kchunks; }
     t += t_lo;
     prep_tap(t);
     load_step(t, kc);
@@ -227,7 +271,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         const float* sb = sa + A_FLOATS;
         if (more) {
-            if (++kc == kchunks) { kc = 0; ++t; prep_tap(t); }
+            if constexpr (KC_OUTER) {
+                if (++t == t_lo + a.tpp) { t = t_lo; ++kc; }
+                prep_tap(t);
+            } else {
+                if (++kc == kchunks) { kc = 0; ++t; prep_tap(t); }
+            }
             load_step(t, kc);                                     // in flight under this step's MFMAs
         }
 #pragma unroll

@@ -1112,10 +1112,12 @@ def test_pose_refinement_graph_replay_matches_eager(dev):
             for ug in (False, True)]
     (pe, he, _), (pg, hg, _) = runs
     assert len(he) == len(hg) == 4
-    # Adam normalises the gradient: the atomics' last-bit noise can move a pose component by a fraction of lr = 1e-3 per step
-    assert (pe - pg).abs().max().item() < 2e-3 and (pe - init).abs().max().item() > 5e-3
+    # Adam normalises the gradient, so the last-bit noise of the fp32 atomics in the backward kernels can flip a near-zero gradient
+    # component's direction: two runs (eager or not) drift apart by a fraction of lr = 1e-3 per step and component
+    assert (pe - pg).abs().max().item() < 6e-3 and (pe - init).abs().max().item() > 5e-3
+    assert abs(he[0] - hg[0]) < 1e-4 * max(1.0, abs(he[0]))                   # same starting point, same first forward
     for a, b in zip(he, hg):
-        assert abs(a - b) < 2e-3 * max(1.0, abs(a))
+        assert abs(a - b) < 3e-2 * max(1.0, abs(a))
     assert hg[-1] < hg[0]
 
 

@@ -53,5 +53,10 @@ if "conv" in which:
     for _ in range(iters):
         co.conv_igemm(x, Cc, Cc, hbuf, Cc, Cc, wp, bias, None, None, 1.0, None, hbuf, None, o1, o2, (1, D, D, D), (D, D, D), 256, Cc,
                       co.TAPS_3x3x3, epilogue=co.EPI_GRU_GATES)
+    # ConvGRU state conv (N = 128: the 64x64 tile at one scene) - the other big share of the step
+    wps = torch.randn(27, 128, 256, device=dev) * 0.01
+    for _ in range(iters):
+        co.conv_igemm(x, Cc, Cc, o2, Cc, Cc, wps, bias[:128], None, None, 1.0, None, hbuf, zbuf, o1, None, (1, D, D, D), (D, D, D), 128, Cc,
+                      co.TAPS_3x3x3, epilogue=co.EPI_GRU_OUT)
 torch.cuda.synchronize()
 print("probe done")

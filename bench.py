@@ -66,8 +66,7 @@ def stage_timers(model):
     wrap(e3, "get_feat3D", "encoder_total")
     wrap(model.rotate, "forward", "rotate")
     wrap(e3, "fuse", "fuse")
-    wrap(e3, "get_density3D", "heads_density(+shared convT)")
-    wrap(e3, "get_render_features", "heads_features")
+    wrap(e3, "heads", "heads")
     wrap(model.render, "forward", "render_total")
     wrap(model.render, "_conv_rgb_hip", "conv_rgb")
     # every forge_conv_igemm launch: events + algorithmic FLOPs, keyed by kernel instantiation

@@ -5,7 +5,15 @@ behind the reference's own nn.Module surface. See DESIGN.md / INTEGRATION.md.
     from forge_amd.model import FORGE                                   # models.model.FORGE
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def invalidate_packed(module):
+    """Drop the packed-weight / folded-BatchNorm caches of every fused HIP inference path below `module`. Needed only after
+    editing parameters through `.data` (which bypasses the version counters the caches key on); optimizer steps, load_state_dict,
+    .to() and train()/eval() are tracked automatically."""
+    from .convops import invalidate_packed as _inv
+    _inv(module)
 
 
 def install_reference_aliases():

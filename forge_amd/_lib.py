@@ -72,4 +72,23 @@ def ptr(t):
 
 
 def current_stream():
+    """torch's current stream of the CURRENT device (launchers run under on_tensor_device, which makes the operands' device current)."""
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_tensor_device(fn):
+    """Decorator for launch wrappers: run `fn` with the device of its first cuda tensor argument current, so that
+    `current_stream()` is that device's stream and per-device kernel attributes are applied to it (a process may hold models on
+    several GPUs while torch's current device is another one)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        for a in args:
+            if torch.is_tensor(a) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+        return fn(*args, **kw)
+    return wrapped

@@ -93,18 +93,59 @@ def bn_affine(bn):
 
 
 class PackCache:
-    """Re-pack derived tensors only when a source parameter/buffer changed (optimizer step, load_state_dict, .to())."""
+    """Derived tensors (packed weights, folded BatchNorm) of one fused launch group, rebuilt when a source parameter / buffer changed.
+
+    The key is (data_ptr, version counter, device) of every source: optimizer steps, `load_state_dict`, `.to()` and in-place tensor ops
+    all bump one of them. In-place edits made through `.data` (`p.data.mul_()`, EMA swaps of legacy loaders) bump NONE of them, so the
+    owning modules (PackedModule) also drop their caches on `train()` / `eval()`, `load_state_dict` and `_apply` (`.to()`, `.float()`),
+    and `forge_amd.invalidate_packed(model)` is the explicit call after any other `.data` surgery."""
 
     def __init__(self):
         self._key = None
         self.val = None
 
+    def clear(self):
+        self._key = None
+        self.val = None
+
+    def key_of(self, sources):
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
+
     def get(self, sources, build):
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
+        key = self.key_of(sources)
         if key != self._key:
             self.val = build()
             self._key = key
         return self.val
+
+
+class PackedModule(torch.nn.Module):
+    """nn.Module whose fused HIP inference path keeps PackCache attributes: they are dropped whenever the module's mode or storage can
+    have changed behind the version counters (see PackCache)."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_packed())
+
+    def invalidate_packed(self):
+        for v in self.__dict__.values():
+            if isinstance(v, PackCache):
+                v.clear()
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
+        return super()._apply(fn, *args, **kwargs)
+
+
+def invalidate_packed(module):
+    """Drop every packed-weight cache below `module` (call after editing parameters through `.data`)."""
+    for m in module.modules():
+        if isinstance(m, PackedModule):
+            m.invalidate_packed()
 
 
 _SPLITK_WS = {}
@@ -135,6 +176,7 @@ def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
 MAX_OPERAND_BYTES = (1 << 31) - 1       # 32-bit buffer offsets of the kernel's gathered operands (tests lower it to exercise the chunking)
 
 
+@_lib.on_tensor_device
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
                bs1=0, bs2=0, lift=0):
@@ -175,6 +217,7 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
 # autograd: stride-1 3x3x3 convolution on channels-last rows, forward / data-gradient on forge_conv_igemm, weight-gradient
 # on forge_conv_wgrad. Used by the training / pose-refinement paths of the ConvGRU fusion and conv1.
 # ------------------------------------------------------------------------------------------------------------------
+@_lib.on_tensor_device
 def conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, in_grid, Cout, taps, istride=1, bs1=0, bs2=0):
     n, D, H, W = grid
     Di, Hi, Wi = in_grid
@@ -305,6 +348,7 @@ class _ConvDirectRows(torch.autograd.Function):
     on the direct vector-ALU kernels (csrc/conv_direct.hip). wp [T][Cout][Cin] is the differentiable packed weight."""
 
     @staticmethod
+    @_lib.on_tensor_device
     def forward(ctx, x, wp, bias, taps):
         n, D, H, W, Cin = x.shape
         T, Cout, _ = wp.shape
@@ -318,6 +362,7 @@ class _ConvDirectRows(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.on_tensor_device
     def backward(ctx, dy):
         x, wp = ctx.saved_tensors
         taps, has_bias = ctx.meta
@@ -338,6 +383,7 @@ class _ConvDirectRows(torch.autograd.Function):
         return dx, dwp, db, None
 
 
+@_lib.on_tensor_device
 def conv_direct(x, ld_in, wp, bias, slope, out, grid, Cin, Cout, taps):
     """Inference launcher of the direct kernel: out [M][Cout] = LeakyReLU(conv(x [M][ld_in], wp [T][Cout][Cin]) + bias, slope)."""
     n, D, H, W = grid

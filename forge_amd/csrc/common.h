@@ -27,6 +27,19 @@ void set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (the attribute is per device; a process may drive several GPUs). hipGetDevice
+// and the attribute call touch no stream, so this is safe under stream capture.
+#define FORGE_SET_MAX_LDS_ONCE(kernel_ptr, bytes)                                                                      \
+    do {                                                                                                               \
+        static bool done_[64] = {};                                                                                    \
+        int dev_ = 0;                                                                                                  \
+        (void)hipGetDevice(&dev_);                                                                                     \
+        if (dev_ >= 0 && dev_ < 64 && !done_[dev_]) {                                                                  \
+            (void)hipFuncSetAttribute((const void*)(kernel_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            done_[dev_] = true;                                                                                        \
+        }                                                                                                              \
+    } while (0)
+
 constexpr int NUM_XCD = 8;   // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 // Bijective remap of a linear workgroup id so that each XCD (private 4 MiB L2) gets one

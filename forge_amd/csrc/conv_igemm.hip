@@ -13,15 +13,17 @@
 // chain; 157 TFLOP/s chip peak = 1/16 of bf16) — the reference is fp32 and parity is stated in
 // fp32. There is no xf32/TF32 on gfx950.
 //
-// Tiling: 256 threads = 4 waves as 2x2, workgroup tile 128(M) x BN(N) x 32(K), wave tile
-// 64 x BN/2 made of 32x32 MFMA tiles. Both operands are staged as [row][32 k] images in LDS
-// (128-byte rows, 16-byte chunks XOR-swizzled with (row>>1)&7 so that the 16-lane groups of
-// ds_read_b128 hit 16 distinct slots), filled through registers (global_load_dwordx4 ->
-// ds_write_b128: zero-fill of out-of-grid taps is a select on the loaded value, and fp32 MFMA is
-// slow enough - 64 cycles each - that the staging path has >10x slack), double-buffered with one
-// barrier per K-step and the next K-step's global loads in flight under the current MFMAs.
-// The K order inside a 32-chunk is permuted identically for A and B: a lane's 16-byte read
-// supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of MFMA j.
+// Tiling: conv_igemm_kernel<BM, BN, NW, MT>: NW waves (8 or 4) arranged WM(M) x WN(N), workgroup
+// tile BM x BN x 32(K) (128x128, 64x128, 128x64 with 8 waves; 64x64, 128x32 with 4), wave tile
+// (32 MT) x (BN / WN) made of 32x32 MFMA tiles; the tile and a split-K factor are chosen per launch
+// by plan_conv(). Both operands are staged as [row][32 k] images in LDS (128-byte rows, 16-byte
+// chunks XOR-swizzled with (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct
+// slots), filled through registers (raw buffer_load_dwordx4 whose out-of-range offset returns 0 —
+// zero padding of out-of-grid taps / ragged tiles costs neither a branch nor a select — then
+// ds_write_b128), double-buffered with one barrier per K-step and the next K-step's loads in
+// flight under the current MFMAs. The K order inside a 32-chunk is permuted identically for A
+// and B: a lane's 16-byte read supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of
+// MFMA j.
 #include "common.h"
 #include <cmath>
 #include <cstdlib>
@@ -704,9 +706,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase;                                                       \
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
         const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
-        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_igemm_kernel<BMv, BNv, NWv>,            \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        (void)attr_once; /* set once per process: safe under stream capture */                                             \
+        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv>), lds);                                                    \
         hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
     } while (0)
         switch (tile) {

@@ -403,9 +403,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         if (ok) {
             const long long nseg = (long long)n * D * H * ((W + LSEG - 1) / LSEG);
             const size_t lds = (size_t)(LSEG * 32 + lt.nlines * (LSEG + 2 * lt.rx) * 32) * sizeof(float);
-            static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_lines_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                    (int)((LSEG * 32 + LMAXL * LROWS * 32) * sizeof(float)));
-            (void)attr_once;
+            FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines_kernel, (LSEG * 32 + LMAXL * LROWS * 32) * sizeof(float));
             const long long grid = nseg < 512 ? nseg : 512;          // 2 workgroups per CU (244 VGPRs), each walking its share of the segments
             a.mchunk = 0;
             hipLaunchKernelGGL(conv_wgrad_lines_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, lt);
@@ -449,9 +447,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
     const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 32 KiB
 #define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
     do {                                                                                                                             \
-        static const hipError_t attr_once = hipFuncSetAttribute((const void*)conv_wgrad_kernel<CIWv>,                               \
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-        (void)attr_once;                                                                                                             \
+        FORGE_SET_MAX_LDS_ONCE(conv_wgrad_kernel<CIWv>, lds);                                                                        \
         hipLaunchKernelGGL(conv_wgrad_kernel<CIWv>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);                  \
     } while (0)
     if (ciw == 32) FORGE_LAUNCH_WGRAD(32);

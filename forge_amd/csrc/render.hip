@@ -543,13 +543,11 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
         constexpr int TH = (256 / C4) / 8;
         dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
         if (dcam) {
-            static const hipError_t attr_once = hipFuncSetAttribute((const void*)render_bwd_kernel<C4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-            (void)attr_once;
+            FORGE_SET_MAX_LDS_ONCE((render_bwd_kernel<C4, true>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
                                view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
         } else {
-            static const hipError_t attr_once = hipFuncSetAttribute((const void*)render_bwd_kernel<C4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-            (void)attr_once;
+            FORGE_SET_MAX_LDS_ONCE((render_bwd_kernel<C4, false>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
                                view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
         }

@@ -6,13 +6,11 @@ methods (`get_feat3D`, `get_density3D`, `get_render_features`, `fuse`) and the s
 (SURVEY.md Appendix B). torchvision is not a dependency: the ResNet-50 trunk is built here with
 torchvision's module names so published checkpoints load with strict=True.
 """
-import weakref
-
 import torch
 import torch.nn as nn
 
-from . import convops as co
-from .fusion import ConvGRU_3D, hip_inference
+from . import _lib, convops as co
+from .fusion import ConvGRU_3D, hip_inference, require_hip_input
 
 
 class _Bottleneck(nn.Module):
@@ -72,11 +70,33 @@ def get_resnet50():
     return feature
 
 
-class Encoder3D(nn.Module):
+def load_imagenet_trunk(feature_extraction, state_dict, strict=True):
+    """Load a torchvision ResNet-50 state_dict (`resnet50(pretrained=True)`, what models/encoder.py:72 downloads) into the trunk built by
+    get_resnet50(): torchvision key -> nn.Sequential index  conv1 -> 0, bn1 -> 1, layerN -> N + 3; `fc.*` is dropped (children[:-2]).
+    Needed only for from-scratch training (stage 1.1 of the reference starts from ImageNet weights); a released FORGE checkpoint already
+    carries the trunk under `encoder_3d.feature_extraction.*`. Shapes are validated; returns load_state_dict's result."""
+    remap = {"conv1": "0", "bn1": "1", "layer1": "4", "layer2": "5", "layer3": "6", "layer4": "7"}
+    own = feature_extraction.state_dict()
+    out = {}
+    for k, v in state_dict.items():
+        head, _, rest = k.partition(".")
+        if head == "fc":
+            continue
+        if head not in remap:
+            raise KeyError("load_imagenet_trunk: unexpected torchvision ResNet-50 key %r" % k)
+        nk = remap[head] + "." + rest
+        if nk in own and tuple(own[nk].shape) != tuple(v.shape):
+            raise ValueError("load_imagenet_trunk: %s has shape %s, the trunk expects %s" % (k, tuple(v.shape), tuple(own[nk].shape)))
+        out[nk] = v
+    return feature_extraction.load_state_dict(out, strict=strict)
+
+
+class Encoder3D(co.PackedModule):
     """models/encoder.py:8-68."""
 
     def __init__(self, config):
         super().__init__()
+        self._trunk_cache, self._stem_cache, self._c1_cache, self._heads_cache = co.PackCache(), co.PackCache(), co.PackCache(), co.PackCache()
         self.feature_extraction = get_resnet50()
         self.features_head = nn.Sequential(
             nn.ConvTranspose3d(128, 32, 4, stride=2, padding=1),
@@ -107,46 +127,48 @@ class Encoder3D(nn.Module):
         (channel c = c3d*32 + z, models/encoder.py:49)."""
         if hip_inference(self, img):
             return self._conv1_hip(self._trunk_hip(img))
-        if img.is_cuda and img.dtype == torch.float32:
-            # training / refinement: every convolution (trunk, conv1) forward + dgrad on the MFMA GEMM, wgrad on the wgrad kernels;
-            # BatchNorm (batch statistics / SyncBN) and activations are torch ops on the same channels-last tensors
-            z = self._trunk_autograd_hip(img)                              # [N,H,W,2048] NHWC rows
-            N, H, W, _ = z.shape
-            rows = z.reshape(N, H, W, 64, 32).permute(0, 4, 1, 2, 3).contiguous()     # view(-1,64,32,H,W) as rows [N,32,H,W,64]
-            y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
-            return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
-        z_2d = self.feature_extraction(img)
-        B, C, H, W = z_2d.shape
-        z_3d = z_2d.view(-1, 64, 32, H, W)
-        return self.conv1(z_3d)
+        require_hip_input("Encoder3D.get_feat3D", img)
+        # training / refinement: every convolution (trunk, conv1) forward + dgrad on the MFMA GEMM, wgrad on the wgrad kernels;
+        # BatchNorm (batch statistics / SyncBN) and activations are torch ops on the same channels-last tensors
+        z = self._trunk_autograd_hip(img)                              # [N,H,W,2048] NHWC rows
+        N, H, W, _ = z.shape
+        rows = z.reshape(N, H, W, 64, 32).permute(0, 4, 1, 2, 3).contiguous()     # view(-1,64,32,H,W) as rows [N,32,H,W,64]
+        y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
+        return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
 
     def get_density3D(self, z_3d):
+        """models/encoder.py:53-54. Callers that need both heads of the same volume should use heads() (one shared launch)."""
         if hip_inference(self, z_3d):
-            return self._heads_hip(z_3d)[1]
-        if z_3d.is_cuda and z_3d.dtype == torch.float32:
-            return self._head_autograd_hip(self.density_head, z_3d)
-        return self.density_head(z_3d.contiguous())
+            return self._heads_hip(z_3d, "density")[1]
+        require_hip_input("Encoder3D.get_density3D", z_3d)
+        return self._head_autograd_hip(self.density_head, z_3d)
 
     def get_render_features(self, x):
+        """models/encoder.py:56-57."""
         if hip_inference(self, x):
-            return self._heads_hip(x)[0]
-        if x.is_cuda and x.dtype == torch.float32:
-            return self._head_autograd_hip(self.features_head, x)
-        return self.features_head(x.contiguous())
+            return self._heads_hip(x, "features")[0]
+        require_hip_input("Encoder3D.get_render_features", x)
+        return self._head_autograd_hip(self.features_head, x)
+
+    def heads(self, z_3d):
+        """(get_render_features(z), get_density3D(z)) of the same fused volume. In inference both heads' transposed convolutions run as
+        ONE N = 64 launch; nothing is memoised between calls (the model classes call this instead of the two getters)."""
+        if hip_inference(self, z_3d):
+            return self._heads_hip(z_3d, "both")
+        return self.get_render_features(z_3d), self.get_density3D(z_3d)
 
     def fuse(self, x):
         """x [b,t,c,d,h,w] -> [b,c,d,h,w] (models/encoder.py:59-63)"""
         if hip_inference(self, x):
             return self.fusion_feature.fuse_hip(x)
-        if x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0:
-            return self.fusion_feature.fuse_autograd_hip(x)             # training / refinement: HIP convs with autograd
-        return self.fusion_feature(x, [self.fusion_feature.fusion_conv(x.mean(dim=1))])
+        require_hip_input("Encoder3D.fuse", x)
+        return self.fusion_feature.fuse_autograd_hip(x)                 # training / refinement: HIP convs with autograd
 
     def fuse_groups(self, x, groups):
         """[self.fuse(x[:, g]) for g in groups], sharing the per-view work between the groups where that pays: with an autograd graph on
         the MI355X the input halves of the GRU convolutions are computed once per view (ConvGRU_3D.fuse_groups_autograd_hip)."""
-        if (not hip_inference(self, x)) and x.is_cuda and x.dtype == torch.float32 and x.shape[2] % 32 == 0 and \
-                self.fusion_feature.n_layers == 1 and len(groups) > 1:
+        if (not hip_inference(self, x)) and self.fusion_feature.n_layers == 1 and len(groups) > 1:
+            require_hip_input("Encoder3D.fuse_groups", x)
             return self.fusion_feature.fuse_groups_autograd_hip(x, groups)
         return [self.fuse(x[:, list(g)]) for g in groups]
 
@@ -156,10 +178,10 @@ class Encoder3D(nn.Module):
         y = y if y.is_contiguous() else y.contiguous()
         return torch.relu(y) if relu else y
 
+    @_lib.on_tensor_device
     def _trunk_autograd_hip(self, img):
         """ResNet-50 trunk with an autograd graph on the HIP kernels. Stem: patch gather + one-tap GEMM (the image needs no
         gradient), max-pool by torch; bottlenecks: 1x1 / 3x3 (stride 1 or 2) / 1x1 convolutions through convops.conv2d_rows."""
-        from . import _lib
         fe = self.feature_extraction
         conv0, bn0, pool = fe[0], fe[1], fe[3]
         N, Ci, Hi, Wi = img.shape
@@ -222,8 +244,6 @@ class Encoder3D(nn.Module):
         layer4's conv3/downsample and to Cin of the following conv1) that lets the last GEMM store the lifted
         [N,32,H,W,64] volume with contiguous 256-byte segments."""
         fe = self.feature_extraction
-        if not hasattr(self, "_trunk_cache"):
-            self._trunk_cache = co.PackCache()
         src = [t for li in (4, 5, 6, 7) for blk in fe[li] for t in list(blk.parameters()) + list(blk.buffers())]
 
         def build():
@@ -255,19 +275,17 @@ class Encoder3D(nn.Module):
             return blocks
         return self._trunk_cache.get(src, build)
 
+    @_lib.on_tensor_device
     def _trunk_hip(self, img):
         """The whole ResNet-50 trunk on the fp32 matrix cores: stem (patch gather + GEMM, max-pool kernel), layers 1-4 as
         im2col-free implicit GEMMs (1x1 = plain GEMM, 3x3 = 9 taps, strides via the input-stride argument), BN folded, ReLU
         and the residual add in the epilogue, activations NHWC, the 2D->3D lift fused into the last store.
         img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1)."""
-        from . import _lib
         fe = self.feature_extraction
         dev = img.device
         T1 = [(0, 0, 0)]
         # ---- stem: 7x7/s2 conv as patch-gather + one-tap GEMM (BN + ReLU folded), then the 3x3/s2 max-pool, all channels-last
         conv0, bn0, pool = fe[0], fe[1], fe[3]
-        if not hasattr(self, "_stem_cache"):
-            self._stem_cache = co.PackCache()
         kh, kw = conv0.kernel_size
         Kp = ((kh * kw * conv0.in_channels + 31) // 32) * 32
 
@@ -320,8 +338,6 @@ class Encoder3D(nn.Module):
     def _conv1_hip(self, vol_rows):
         """conv1 = Conv3d(64,128,3,p1)+BN+LeakyReLU as one GEMM (models/encoder.py:36-40). vol_rows [N,D,H,W,64]."""
         conv, bn = self.conv1[0], self.conv1[1]
-        if not hasattr(self, "_c1_cache"):
-            self._c1_cache = co.PackCache()
         w, bias, sc, sh = self._c1_cache.get(
             [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var],
             lambda: (co.pack_conv3d_weight(conv.weight), conv.bias.detach().contiguous()) + co.bn_affine(bn))
@@ -331,17 +347,12 @@ class Encoder3D(nn.Module):
                       (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
         return out.permute(0, 4, 1, 2, 3)
 
-    def _heads_hip(self, z):
-        """Both heads (models/encoder.py:16-34) on one fused volume: the two ConvTranspose3d(128,32,4,s2,p1)+BN+LReLU
-        run as ONE N=64 launch covering the 8 output phases x 8 taps, then Conv3d(32,16)+BN and
-        Conv3d(32,8)+BN+LReLU read their 32-channel halves of the shared [..,64] tensor in place, then Conv3d(8,1)+ReLU.
-        Results are cached per input tensor so get_density3D / get_render_features share the work."""
-        memo = getattr(self, "_heads_memo", None)
-        if memo is not None and memo[0]() is z and memo[1] == z._version:
-            return memo[2]
+    def _heads_hip(self, z, which="both"):
+        """The heads (models/encoder.py:16-34) on a fused volume, returns (features | None, density | None).
+        which = "both": the two ConvTranspose3d(128,32,4,s2,p1)+BN+LReLU run as ONE N=64 launch covering the 8 output phases x 8
+        taps, then Conv3d(32,16)+BN and Conv3d(32,8)+BN+LReLU read their 32-channel halves of the shared [..,64] tensor in place, then
+        Conv3d(8,1)+ReLU. which = "features" / "density": that head alone (N=32 transposed convolution), as the reference computes it."""
         fh, dh = self.features_head, self.density_head
-        if not hasattr(self, "_heads_cache"):
-            self._heads_cache = co.PackCache()
         src = [fh[0].weight, fh[0].bias, dh[0].weight, dh[0].bias, fh[3].weight, fh[3].bias, dh[3].weight, dh[3].bias,
                dh[6].weight, dh[6].bias] + [t for bn in (fh[1], dh[1], fh[4], dh[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
 
@@ -350,6 +361,7 @@ class Encoder3D(nn.Module):
             s1 = [torch.cat(v) for v in zip(co.bn_affine(fh[1]), co.bn_affine(dh[1]))]
             w6 = co.pack_conv3d_weight(dh[6].weight)                                       # [27][1][8]: direct (vector-ALU) kernel
             return {"ct": ct, "ct_b": torch.cat([fh[0].bias, dh[0].bias]).detach().contiguous(), "ct_aff": s1,
+                    "ct_f": co.convT_phases_merged(fh[0].weight, 1, 3), "ct_d": co.convT_phases_merged(dh[0].weight, 1, 3),
                     "f3_w": co.pack_conv3d_weight(fh[3].weight), "f3_b": fh[3].bias.detach().contiguous(), "f4": co.bn_affine(fh[4]),
                     "d3_w": co.pack_conv3d_weight(dh[3].weight), "d3_b": dh[3].bias.detach().contiguous(), "d4": co.bn_affine(dh[4]),
                     "d6_w": w6, "d6_b": dh[6].bias.detach().contiguous()}
@@ -358,22 +370,33 @@ class Encoder3D(nn.Module):
         D2, H2, W2 = 2 * D, 2 * H, 2 * W
         dev = z.device
         xr = self._rows(z)
-        up = torch.empty(n, D2, H2, W2, 64, dtype=torch.float32, device=dev)
-        co.conv_igemm(xr, C, C, None, 0, 0, p["ct"][1], p["ct_b"], p["ct_aff"][0], p["ct_aff"][1], 0.01, None, None, None, up, None,
-                      (n, D, H, W), (D, H, W), 64, 64, p["ct"][0], out_grid=(D2, H2, W2), ostride=2, phase=(-1, -1, -1),
+        if which == "both":
+            taps, wct, bct, sc, sh, Nup, fo, do = p["ct"][0], p["ct"][1], p["ct_b"], p["ct_aff"][0], p["ct_aff"][1], 64, 0, 32
+        elif which == "features":
+            taps, wct, bct, sc, sh, Nup, fo, do = p["ct_f"][0], p["ct_f"][1], p["ct_b"][:32], p["ct_aff"][0][:32], p["ct_aff"][1][:32], 32, 0, None
+        elif which == "density":
+            taps, wct, bct, sc, sh, Nup, fo, do = p["ct_d"][0], p["ct_d"][1], p["ct_b"][32:], p["ct_aff"][0][32:], p["ct_aff"][1][32:], 32, None, 0
+        else:
+            raise ValueError("which must be 'both', 'features' or 'density'")
+        up = torch.empty(n, D2, H2, W2, Nup, dtype=torch.float32, device=dev)
+        co.conv_igemm(xr, C, C, None, 0, 0, wct, bct, sc, sh, 0.01, None, None, None, up, None,
+                      (n, D, H, W), (D, H, W), Nup, Nup, taps, out_grid=(D2, H2, W2), ostride=2, phase=(-1, -1, -1),
                       epilogue=co.EPI_AFFINE_ACT)
         g2, ig2 = (n, D2, H2, W2), (D2, H2, W2)
-        feat = torch.empty(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)
-        co.conv_igemm(up, 32, 64, None, 0, 0, p["f3_w"], p["f3_b"], p["f4"][0], p["f4"][1], 1.0, None, None, None, feat, None,
-                      g2, ig2, 16, 16, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
-        d8 = torch.empty(n, D2, H2, W2, 8, dtype=torch.float32, device=dev)
-        co.conv_igemm(up[..., 32:], 32, 64, None, 0, 0, p["d3_w"], p["d3_b"], p["d4"][0], p["d4"][1], 0.01, None, None, None, d8, None,
-                      g2, ig2, 8, 8, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
-        dens = torch.empty(n, D2, H2, W2, 1, dtype=torch.float32, device=dev)
-        co.conv_direct(d8, 8, p["d6_w"], p["d6_b"], 0.0, dens, g2, 8, 1, co.TAPS_3x3x3)       # Conv3d(8, 1) + ReLU: 216 MACs per voxel
-        res = (feat.permute(0, 4, 1, 2, 3), dens.permute(0, 4, 1, 2, 3))
-        self._heads_memo = (weakref.ref(z), z._version, res)
-        return res
+        feat = dens = None
+        if fo is not None:
+            feat = torch.empty(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)
+            co.conv_igemm(up[..., fo:], 32, Nup, None, 0, 0, p["f3_w"], p["f3_b"], p["f4"][0], p["f4"][1], 1.0, None, None, None, feat, None,
+                          g2, ig2, 16, 16, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+            feat = feat.permute(0, 4, 1, 2, 3)
+        if do is not None:
+            d8 = torch.empty(n, D2, H2, W2, 8, dtype=torch.float32, device=dev)
+            co.conv_igemm(up[..., do:], 32, Nup, None, 0, 0, p["d3_w"], p["d3_b"], p["d4"][0], p["d4"][1], 0.01, None, None, None, d8, None,
+                          g2, ig2, 8, 8, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+            dens = torch.empty(n, D2, H2, W2, 1, dtype=torch.float32, device=dev)
+            co.conv_direct(d8, 8, p["d6_w"], p["d6_b"], 0.0, dens, g2, 8, 1, co.TAPS_3x3x3)   # Conv3d(8, 1) + ReLU: 216 MACs per voxel
+            dens = dens.permute(0, 4, 1, 2, 3)
+        return feat, dens
 
     def forward(self, x):
         raise NotImplementedError

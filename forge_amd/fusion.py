@@ -19,6 +19,16 @@ def hip_inference(module, x):
     return x.is_cuda and x.dtype == torch.float32 and not module.training and not torch.is_grad_enabled()
 
 
+def require_hip_input(what, x, channels=None):
+    """The product has ONE implementation per op - the HIP kernels. Anything they cannot take is an error, never a silent stock-PyTorch
+    detour (north_star: no dual code paths)."""
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32):
+        raise RuntimeError("forge_amd: %s runs only on the MI355X HIP kernels and needs a float32 tensor on a cuda/HIP device (got %s on %s); "
+                           "there is no CPU or stock-PyTorch path" % (what, getattr(x, "dtype", type(x)), getattr(x, "device", "?")))
+    if channels is not None and channels % 32:
+        raise RuntimeError("forge_amd: %s needs a channel count that is a multiple of the GEMM K-step 32 (got %d)" % (what, channels))
+
+
 class _GRUCellRows(torch.autograd.Function):
     """One ConvGRU step (models/fusion.py:29-35) on channels-last rows with an autograd graph. Both convolutions run on the MFMA
     implicit-GEMM kernel (bias epilogue), data / weight gradients on the same GEMM / the wgrad kernel, and each element-wise half of
@@ -26,6 +36,7 @@ class _GRUCellRows(torch.autograd.Function):
       x [b,D,H,W,C] (a view with a batch stride is fine), h [b,D,H,W,C] dense, wg [27][2C][2C], wo [27][C][2C] packed weights."""
 
     @staticmethod
+    @_lib.on_tensor_device
     def forward(ctx, x, h, wg, bg, wo, bo):
         b, D, H, W, C = h.shape
         M = b * D * H * W
@@ -49,6 +60,7 @@ class _GRUCellRows(torch.autograd.Function):
         return hn
 
     @staticmethod
+    @_lib.on_tensor_device
     def backward(ctx, dhn):
         x, h, z, r, hr, cand, wg, wo = ctx.saved_tensors
         b, D, H, W, C = h.shape
@@ -97,6 +109,7 @@ class _GRUCellPreRows(torch.autograd.Function):
       gx [b,D,H,W,2C], cx [b,D,H,W,C], h [b,D,H,W,C] dense rows; wgh [27][2C][C], woh [27][C][C] packed hidden-state weights."""
 
     @staticmethod
+    @_lib.on_tensor_device
     def forward(ctx, gx, cx, h, wgh, bg, woh, bo):
         b, D, H, W, C = h.shape
         M = b * D * H * W
@@ -120,6 +133,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         return hn
 
     @staticmethod
+    @_lib.on_tensor_device
     def backward(ctx, dhn):
         h, z, r, hr, cand, wg, wo = ctx.saved_tensors
         b, D, H, W, C = h.shape
@@ -171,21 +185,23 @@ class ConvGRUCell_3D(nn.Module):
         self.out_gate = nn.Conv3d(input_size + hidden_size, hidden_size, 3, padding=1)
 
     def forward(self, x, prev_state=None):
+        """x [b,C,d,h,w], prev_state [b,Ch,d,h,w] or None -> new state (models/fusion.py:21-35), on the HIP kernels (with autograd)."""
+        require_hip_input("ConvGRUCell_3D", x, self.input_size)
+        require_hip_input("ConvGRUCell_3D", x, self.hidden_size)
         b, c, d, h, w = x.shape
         if prev_state is None:
             prev_state = torch.zeros([b, self.hidden_size, d, h, w], dtype=x.dtype, device=x.device)
-        gates = self.conv_gate(torch.cat([x, prev_state], dim=1))
-        update, reset = torch.split(gates, self.hidden_size, dim=1)
-        update, reset = torch.sigmoid(update), torch.sigmoid(reset)
-        out_inputs = torch.tanh(self.out_gate(torch.cat([x, prev_state * reset], dim=1)))
-        return prev_state * (1 - update) + out_inputs * update
+        rows = lambda v: v.permute(0, 2, 3, 4, 1).contiguous()
+        hn = gru_cell_rows(rows(x), rows(prev_state), self.conv_gate.weight, self.conv_gate.bias, self.out_gate.weight, self.out_gate.bias)
+        return hn.permute(0, 4, 1, 2, 3)
 
 
-class ConvGRU_3D(nn.Module):
+class ConvGRU_3D(co.PackedModule):
     """models/fusion.py:39-95."""
 
     def __init__(self, config, n_layers=1, input_size=16, hidden_size=16):
         super().__init__()
+        self._pack_cache = co.PackCache()
         self.input_size = input_size
         self.hidden_size = hidden_size
         self.n_layers = n_layers
@@ -208,8 +224,6 @@ class ConvGRU_3D(nn.Module):
         src = [cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias,
                fc[0].weight, fc[0].bias, fc[3].weight, fc[3].bias] + \
               [t for bn in (fc[1], fc[4], self.fusion_norm) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
-        if not hasattr(self, "_pack_cache"):
-            self._pack_cache = co.PackCache()
 
         def build():
             return {
@@ -221,11 +235,12 @@ class ConvGRU_3D(nn.Module):
             }
         return self._pack_cache.get(src, build)
 
-    def fuse_hip(self, x):
-        """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs, then per view
-        two implicit-GEMM launches (gates: cat/conv/sigmoid/h*r fused; state: cat/conv/tanh/lerp fused, the final
-        fusion_norm folded into the last one). x [b,t,C,D,H,W] -> [b,C,D,H,W] (channels-last memory)."""
+    def fuse_hip(self, x, h0=None):
+        """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs (or the caller's h0
+        [b,C,D,H,W]), then per view two implicit-GEMM launches (gates: cat/conv/sigmoid/h*r fused; state: cat/conv/tanh/lerp fused,
+        the final fusion_norm folded into the last one). x [b,t,C,D,H,W] -> [b,C,D,H,W] (channels-last memory)."""
         assert self.n_layers == 1 and self.input_size == self.hidden_size
+        require_hip_input("ConvGRU_3D.fuse_hip", x, x.shape[2])
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)                          # [b,t,D,H,W,C] rows view
         if not xr.is_contiguous():
@@ -234,13 +249,16 @@ class ConvGRU_3D(nn.Module):
         dev, M, vol = x.device, b * D * H * W, D * H * W
         grid, ig = (b, D, H, W), (D, H, W)
         new = lambda: torch.empty(M, C, dtype=torch.float32, device=dev)
-        mean = xr.mean(dim=1).reshape(M, C)
         taps = co.TAPS_3x3x3
         t0, h = new(), new()
-        co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None,
-                      t0, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
-        co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None,
-                      h, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+        if h0 is None:
+            mean = xr.mean(dim=1).reshape(M, C)
+            co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None,
+                          t0, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+            co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None,
+                          h, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+        else:
+            h.copy_(h0.permute(0, 2, 3, 4, 1).reshape(M, C))
         z, hr, h2, out = new(), new(), t0, new()
         for ti in range(t):
             xt = xr[:, ti]                                        # base pointer of view ti; batch stride t*vol rows
@@ -266,6 +284,7 @@ class ConvGRU_3D(nn.Module):
         tanh / lerp halves on the element-wise kernels of csrc/gru.hip (_GRUCellRows); BatchNorm (batch statistics / SyncBN) stays
         a torch module so that SyncBatchNorm conversion keeps working."""
         assert self.n_layers == 1
+        require_hip_input("ConvGRU_3D.fuse_autograd_hip", x, x.shape[2])
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
@@ -282,6 +301,7 @@ class ConvGRU_3D(nn.Module):
         the input halves of both GRU convolutions are computed once per view for all groups (_GRUCellPreRows), each group then
         runs h0 = fusion_conv(mean of its views) and its own recurrence on the hidden-state halves. Returns one fused volume per group."""
         assert self.n_layers == 1 and self.input_size == self.hidden_size
+        require_hip_input("ConvGRU_3D.fuse_groups_autograd_hip", x, x.shape[2])
         b, t, C, D, H, W = x.shape
         xt = x.permute(1, 0, 3, 4, 5, 2).contiguous()                                   # [t,b,D,H,W,C]: a view's rows are dense
         cell, fc = self.cells[0], self.fusion_conv
@@ -305,16 +325,22 @@ class ConvGRU_3D(nn.Module):
         return outs
 
     def forward(self, x, hidden=None):
-        """x [b,t,c,d,h,w] -> fusion_norm(h_T) [b,c',d,h,w]"""
-        seq_len = x.shape[1]
+        """x [b,t,c,d,h,w], hidden = [h0 per layer] (models/fusion.py:71-95; Encoder3D.fuse passes [fusion_conv(mean_t x)]) ->
+        fusion_norm(h_T) [b,c',d,h,w]. One implementation: the HIP kernels (fused epilogues in inference, the autograd cell otherwise)."""
+        require_hip_input("ConvGRU_3D", x, x.shape[2])
         if not hidden:
             hidden = [None] * self.n_layers
+        if self.n_layers == 1 and hip_inference(self, x) and self.input_size == self.hidden_size:
+            h0 = hidden[0]
+            if h0 is None:
+                h0 = torch.zeros(x.shape[0], self.hidden_size, *x.shape[3:], dtype=x.dtype, device=x.device)
+            return self.fuse_hip(x, h0=h0)
         cur = x
         h = None
         for layer_idx in range(self.n_layers):
             h = hidden[layer_idx]
             outs = []
-            for t in range(seq_len):
+            for t in range(x.shape[1]):
                 h = self.cells[layer_idx](cur[:, t], h)
                 if layer_idx + 1 < self.n_layers:
                     outs.append(h)

@@ -120,3 +120,24 @@ def inverse_affine(P):
     bottom = torch.zeros_like(top[..., :1, :])
     bottom[..., 0, 3] = 1.0
     return torch.cat([top, bottom], dim=-2)
+
+
+def predicted_camera_chain(pose_vec, to_se3, canonical_pose, canonical_extrinsics, b, t):
+    """Cameras of a scene from the pose heads' output (models/model.py:66-81, models/model_single_pose_estimator.py:45-60).
+
+    pose_vec [b(t-1), pose_dim]: relative pose of views 1..t-1 w.r.t. view 0; its first four entries are L2-normalised before the
+    conversion whatever the rotation representation (the reference does exactly that). View 0 is the canonical camera.
+    Returns (normalised pose_vec, camera->world poses [b,t,4,4], world->camera extrinsics [b,t,4,4]); the extrinsics come from the
+    closed-form affine inverse, so the chain carries gradients, needs no host synchronisation and can be captured into a hipGraph."""
+    pose_vec = torch.cat([F.normalize(pose_vec[:, :4]), pose_vec[:, 4:]], dim=1)
+    world_from_cam = (canonical_pose[None] @ to_se3(pose_vec)).reshape(b, t - 1, 4, 4)
+    first = lambda m: m.reshape(1, 1, 4, 4).expand(b, 1, 4, 4)
+    poses = torch.cat([first(canonical_pose), world_from_cam], dim=1)
+    extrinsics = torch.cat([first(canonical_extrinsics), inverse_affine(world_from_cam)], dim=1)
+    return pose_vec, poses, extrinsics
+
+
+def camera_dict(extrinsics, K):
+    """The {'R','T','K'} dict VolRender.forward takes (models/volume_render.py:40-48) from [..,4,4] extrinsics and [..,3,3] intrinsics."""
+    E = extrinsics.reshape(-1, 4, 4)
+    return {"R": E[:, :3, :3], "T": E[:, :3, 3], "K": K.reshape(-1, 3, 3)}

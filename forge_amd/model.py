@@ -16,10 +16,10 @@ Deliberate differences:
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import geo_utils
 from .encoder import Encoder3D
+from .staging import stage_sample
 from .pose_estimator_2d import PoseEstimator2D
 from .pose_estimator_3d import PoseEstimator3D
 from .rotate import Rotate_world
@@ -59,60 +59,44 @@ class FORGE(nn.Module):
         )
 
     def forward(self, sample, dataset, device):
+        sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
         b, t_all = sample["images"].shape[:2]
-        clips = sample["images"][:, :self.N_INPUT].to(device)
+        clips = sample["images"][:, :self.N_INPUT]
         b, t, c, h, w = clips.shape
         features_raw = self.encoder_3d.get_feat3D(clips.reshape(b * t, c, h, w))
         _, C, D, H, W = features_raw.shape
         features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
-            pose_feat_3d = self.encoder_traj(features_raw, return_features=True)       # [b(t-1),1024]
-            pose_feat_2d = self.encoder_traj_2d(clips, return_features=True)          # [b(t-1),1024]
-            pred = self.pose_head(torch.cat([pose_feat_3d, pose_feat_2d], dim=-1))
-            poses_cam, conf = pred.split([self.encoder_traj.pose_dim, 1], dim=-1)
-            tmp = torch.zeros_like(poses_cam)
-            tmp[:, :4] = F.normalize(poses_cam[:, :4])
-            tmp[:, 4:] = poses_cam[:, 4:]
-            poses_cam = tmp
-            camPoseRel_cv2 = self.encoder_traj.toSE3(poses_cam)
-            canonical_pose_cv2 = dataset.get_canonical_pose_cv2(device=device)
-            canonical_extrinsics_cv2 = dataset.get_canonical_extrinsics_cv2(device=device)
-            camPoses_cv2 = canonical_pose_cv2.unsqueeze(0) @ camPoseRel_cv2
-            camE_cv2 = torch.inverse(camPoses_cv2).reshape(b, t - 1, 4, 4)
-            camPoses_cv2 = camPoses_cv2.reshape(b, t - 1, 4, 4)
-            camPoses_cv2 = torch.cat([canonical_pose_cv2.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), camPoses_cv2], dim=1)
-            camE_cv2 = torch.cat([canonical_extrinsics_cv2.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), camE_cv2], dim=1)
-            poses_cam_gt = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].to(device).reshape(b * (t - 1), 4, 4)
-            camPose_return = {"gt": geo_utils.mat2quat(poses_cam_gt), "pred": poses_cam, "conf": conf}
+            pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True),            # [b(t-1),1024] each
+                                   self.encoder_traj_2d(clips, return_features=True)], dim=-1)
+            pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
+            pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
+                pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
+                dataset.get_canonical_extrinsics_cv2(device=device), b, t)
+            gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
+            camPose_return = {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
         else:
             suffix = "_canonicalized" if self.config.train.canonicalize else ""
-            camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t].to(device)
-            camPoses_cv2 = sample["cam_poses_cv2" + suffix][:, :t].to(device)
+            camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t]
+            camPoses_cv2 = sample["cam_poses_cv2" + suffix][:, :t]
             camPose_return = None
         idxs = sequence_from_distance(camPoses_cv2[:, :, :3, 3])
 
         if self.config.train.parameter in ("pose", "pose_head"):                       # :98-114
-            camK = sample["K_cv2"].to(device)[:, :t]
-            cams = {"R": camE_cv2.reshape(b * t, 4, 4)[:, :3, :3], "T": camE_cv2.reshape(b * t, 4, 4)[:, :3, 3],
-                    "K": camK.reshape(b * t, 3, 3)}
-            origin_proj = self.render.proj_origin(cams, device)
+            origin_proj = self.render.proj_origin(geo_utils.camera_dict(camE_cv2, sample["K_cv2"][:, :t]), device)
             return camPose_return, 2 * origin_proj / self.config.dataset.img_size
 
         # cameras to render: the t input cameras + the sample's remaining (novel) GT cameras (:117-125)
-        camE_all = torch.cat([camE_cv2, sample["cam_extrinsics_cv2_canonicalized"][:, self.N_INPUT:].to(device)], dim=1)
-        camK = sample["K_cv2"].to(device)
+        camE_all = torch.cat([camE_cv2, sample["cam_extrinsics_cv2_canonicalized"][:, self.N_INPUT:]], dim=1)
         V = camE_all.shape[1]
         assert V == t_all, "sample must carry intrinsics for every rendered camera"
-        cameras = {"R": camE_all.reshape(b * V, 4, 4)[:, :3, :3], "T": camE_all.reshape(b * V, 4, 4)[:, :3, 3],
-                   "K": camK.reshape(b * V, 3, 3)}
+        cameras = geo_utils.camera_dict(camE_all, sample["K_cv2"])
 
         features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2[:, :t], grid_size=D)
         features_transformed = chose_selected(features_transformed, idxs)
 
-        features_mv = self.encoder_3d.fuse(features_transformed)
-        densities_mv = self.encoder_3d.get_density3D(features_mv)
-        features_mv = self.encoder_3d.get_render_features(features_mv)
+        features_mv, densities_mv = self.encoder_3d.heads(self.encoder_3d.fuse(features_transformed))
         if self.config.dataset.name == "omniobject3d":
             densities_mv = densities_mv.clamp(min=0.0, max=1.0)
 

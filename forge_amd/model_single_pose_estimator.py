@@ -14,9 +14,10 @@ MI355X-first differences (results identical, memory traffic not):
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from . import geo_utils
 from .encoder import Encoder3D
+from .staging import stage_sample
 from .pose_estimator_3d import PoseEstimator3D
 from .rotate import Rotate_world
 from .volume_render import VolRender
@@ -32,47 +33,28 @@ class FORGE_poseEstimator3D(nn.Module):
         self.encoder_traj = PoseEstimator3D(config)
 
     def forward(self, sample, dataset, device):
-        clips = sample["images"].to(device)
+        sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
+        clips = sample["images"]
         b, t, c, h, w = clips.shape
         features_raw = self.encoder_3d.get_feat3D(clips.reshape(b * t, c, h, w))      # [b*t,C,D,H,W]
         _, C, D, H, W = features_raw.shape
         features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
-            poses_cam, conf = self.encoder_traj(features_raw)                          # :45
-            tmp = torch.zeros_like(poses_cam)
-            tmp[:, :4] = F.normalize(poses_cam[:, :4])
-            tmp[:, 4:] = poses_cam[:, 4:]
-            poses_cam = tmp
-            camPoseRel_cv2 = self.encoder_traj.toSE3(poses_cam)                       # [b*(t-1),4,4]
-            canonical_pose_cv2 = dataset.get_canonical_pose_cv2(device=device)
-            canonical_extrinsics_cv2 = dataset.get_canonical_extrinsics_cv2(device=device)
-            camPoses_cv2 = canonical_pose_cv2.unsqueeze(0) @ camPoseRel_cv2
-            camE_cv2 = torch.inverse(camPoses_cv2).reshape(b, t - 1, 4, 4)
-            camPoses_cv2 = camPoses_cv2.reshape(b, t - 1, 4, 4)
-            camPoses_cv2 = torch.cat([canonical_pose_cv2.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), camPoses_cv2], dim=1)
-            camE_cv2 = torch.cat([canonical_extrinsics_cv2.reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), camE_cv2], dim=1)
-            from .geo_utils import mat2quat
-            poses_cam_gt = mat2quat(sample["cam_poses_rel_cv2"][:, 1:].to(device).reshape(b * (t - 1), 4, 4))
-            camPose_return = {"gt": poses_cam_gt, "pred": poses_cam, "conf": conf}
+            pose_vec, conf = self.encoder_traj(features_raw)                           # :45
+            pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
+                pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
+                dataset.get_canonical_extrinsics_cv2(device=device), b, t)
+            gt_rel = sample["cam_poses_rel_cv2"][:, 1:].reshape(b * (t - 1), 4, 4)
+            camPose_return = {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
         else:
-            if self.config.train.canonicalize:
-                camE_cv2 = sample["cam_extrinsics_cv2_canonicalized"].to(device)
-                camPoses_cv2 = sample["cam_poses_cv2_canonicalized"].to(device)
-            else:
-                camE_cv2 = sample["cam_extrinsics_cv2"].to(device)
-                camPoses_cv2 = sample["cam_poses_cv2"].to(device)
+            suffix = "_canonicalized" if self.config.train.canonicalize else ""
+            camE_cv2 = sample["cam_extrinsics_cv2" + suffix]
+            camPoses_cv2 = sample["cam_poses_cv2" + suffix]
             camPose_return = None
 
         # cameras for rendering: every input camera twice (:77-85)
-        camE_cv2 = camE_cv2.repeat(1, 2, 1, 1)
-        camPoses_cv2 = camPoses_cv2.repeat(1, 2, 1, 1)
-        camK = sample["K_cv2"].repeat(1, 2, 1, 1).to(device)
-        cameras = {
-            "R": camE_cv2.reshape(b * 2 * t, 4, 4)[:, :3, :3],
-            "T": camE_cv2.reshape(b * 2 * t, 4, 4)[:, :3, 3],
-            "K": camK.reshape(b * 2 * t, 3, 3),
-        }
+        cameras = geo_utils.camera_dict(camE_cv2.repeat(1, 2, 1, 1), sample["K_cv2"].repeat(1, 2, 1, 1))
 
         if self.config.train.parameter == "pose":                                      # :87-99
             origin_proj = self.render.proj_origin(cameras, device)
@@ -87,13 +69,12 @@ class FORGE_poseEstimator3D(nn.Module):
             # BatchNorm batch statistics (and the running-stat updates) follow the reference's call structure: the heads run on
             # cat([3v, 2v]) (:110-111) and on the all-view volume (:121-122) SEPARATELY - one 3b batch would normalise differently
             f32 = torch.cat([features_3v, features_2v], dim=0)
-            d32, r32 = self.encoder_3d.get_density3D(f32), self.encoder_3d.get_render_features(f32)
-            dm, rm = self.encoder_3d.get_density3D(features_mv), self.encoder_3d.get_render_features(features_mv)
+            r32, d32 = self.encoder_3d.heads(f32)
+            rm, dm = self.encoder_3d.heads(features_mv)
             densities, features = torch.cat([d32, dm], dim=0), torch.cat([r32, rm], dim=0)
         else:
             fused = torch.cat([features_3v, features_2v, features_mv], dim=0)          # eval BN: one [3b,128,D,H,W] batch is the same arithmetic
-            densities = self.encoder_3d.get_density3D(fused)                           # [3b,1,2D,..]
-            features = self.encoder_3d.get_render_features(fused)                      # [3b,16,2D,..]
+            features, densities = self.encoder_3d.heads(fused)                         # [3b,16,2D,..], [3b,1,2D,..]
         if self.config.dataset.name == "omniobject3d":
             densities = densities.clamp(min=0.0, max=1.0)
 

@@ -39,6 +39,7 @@ class _RotateWarp(torch.autograd.Function):
     """forge_rotate_fwd / forge_rotate_bwd (models/rotate.py:127-141)."""
 
     @staticmethod
+    @_lib.on_tensor_device
     def forward(ctx, vox, xf, mode):
         _require_cuda(vox, xf, mode)
         vox_cl = to_channels_last_3d(vox)
@@ -51,6 +52,7 @@ class _RotateWarp(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.on_tensor_device
     def backward(ctx, g):
         vox_cl, xf_c, mode = ctx.saved_tensors
         n, C, D, H, W = vox_cl.shape
@@ -72,6 +74,7 @@ class _RenderRays(torch.autograd.Function):
     """forge_render_fwd / forge_render_bwd (models/volume_render.py:53-63)."""
 
     @staticmethod
+    @_lib.on_tensor_device
     def forward(ctx, feat, dens, cam, view2vol, Hr, Wr, S, zmin, zmax, half, want_depth):
         _require_cuda(feat, dens, cam, view2vol)
         feat_cl = to_channels_last_3d(feat)
@@ -96,6 +99,7 @@ class _RenderRays(torch.autograd.Function):
         return out_feat, out_opac
 
     @staticmethod
+    @_lib.on_tensor_device
     def backward(ctx, g_feat, g_opac, g_depth=None):
         feat_cl, dens_c, cam_c, view2vol = ctx.saved_tensors
         Hr, Wr, S, zmin, zmax, half, want_depth = ctx.cfg

@@ -32,8 +32,7 @@ def _render_views(model, config, dataset, features, pose7, K, device, canonical=
     ft = model.rotate(voxels=features, camPoses_cv2=poses, grid_size=D)
     ft = chose_selected(ft, sequence_from_distance(poses[:, :, :3, 3]))
     fused = model.encoder_3d.fuse(ft)
-    dens = model.encoder_3d.get_density3D(fused)
-    feat = model.encoder_3d.get_render_features(fused)
+    feat, dens = model.encoder_3d.heads(fused)
     cams = {"R": extr.reshape(b * t, 4, 4)[:, :3, :3], "T": extr.reshape(b * t, 4, 4)[:, :3, 3], "K": K.reshape(b * t, 3, 3)}
     v2v = torch.arange(b, device=device, dtype=torch.int32).repeat_interleave(t)
     imgs, masks, depths, origin = model.render(cams, feat, dens, return_origin_proj=True, render_depth=True, view2vol=v2v)

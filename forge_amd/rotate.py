@@ -10,7 +10,7 @@ reach predicted poses through autograd.
 import torch
 import torch.nn as nn
 
-from . import geo_utils, ops
+from . import _lib, geo_utils, ops
 
 _SUPPORTED = (16, 32, 48, 64, 128)   # grids the reference pre-computes (models/rotate.py:18-35)
 
@@ -42,6 +42,7 @@ class Rotate_world(nn.Module):
         pose_1 = camPoses_cv2[:, 1:].reshape(B * (t - 1), 4, 4)
         return pose_0 @ geo_utils.inverse_affine(pose_1)        # poses are affine (last row 0 0 0 1): closed form, no host sync
 
+    @_lib.on_tensor_device
     def forward(self, voxels, camPoses_cv2, grid_size=32):
         """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged)."""
         B, t, C, D, H, W = voxels.shape
@@ -55,7 +56,6 @@ class Rotate_world(nn.Module):
         if not (torch.is_grad_enabled() and poses.requires_grad):
             # no gradient to the poses: T = P_0 P_i^-1 and the affine packing run in one tiny kernel (no torch.inverse,
             # whose LU + info check costs more host time than the whole warp)
-            from . import _lib
             xf = torch.empty(B * t, 12, dtype=torch.float32, device=device)
             mode = torch.empty(B * t, dtype=torch.int32, device=device)
             _lib.check(_lib.lib().forge_rotate_xf_from_poses(_lib.ptr(poses.contiguous()), _lib.ptr(xf), _lib.ptr(mode), B, t, e,

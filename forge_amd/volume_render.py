@@ -21,9 +21,10 @@ from . import convops as co, ops
 from .fusion import hip_inference
 
 
-class VolRender(nn.Module):
+class VolRender(co.PackedModule):
     def __init__(self, config):
         super().__init__()
+        self._rgb_cache = co.PackCache()
         self.img_size = config.dataset.img_size
         self.volume_physical_size = config.render.volume_size
         self.n_pts_per_ray = config.render.n_pts_per_ray
@@ -81,10 +82,8 @@ class VolRender(nn.Module):
                                self.min_depth, self.max_depth, half, want_depth=render_depth)
         if hip_inference(self, outs[0]):
             rendered_imgs = self._conv_rgb_hip(outs[0])
-        elif outs[0].is_cuda:
-            rendered_imgs = self._conv_rgb_autograd_hip(outs[0])
         else:
-            rendered_imgs = F.relu(self.conv_rgb(outs[0].contiguous()))
+            rendered_imgs = self._conv_rgb_autograd_hip(outs[0])      # ops.render_rays has already refused non-HIP tensors
         rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
         result = [rendered_imgs, rendered_silhouettes]
         if render_depth:
@@ -98,8 +97,6 @@ class VolRender(nn.Module):
         output phases in one launch + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
         channels-last memory (what the ray-marcher writes) -> [V,3,2Hr,2Wr] (channels-last memory)."""
         cr = self.conv_rgb
-        if not hasattr(self, "_rgb_cache"):
-            self._rgb_cache = co.PackCache()
         src = [cr[0].weight, cr[0].bias, cr[3].weight, cr[3].bias, cr[6].weight, cr[6].bias] + \
               [t for bn in (cr[1], cr[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
 

@@ -201,3 +201,78 @@ def test_loss_functions_match_reference_golden():
         assert set(terms) == set(ref_terms), (name, sorted(terms), sorted(ref_terms))
         for k, v in ref_terms.items():
             assert abs(terms[k] - v) < 1e-5 * max(1.0, abs(v)), (name, k)
+
+
+def test_packed_caches_are_dropped_on_mode_load_and_apply():
+    """packed-weight caches must not survive train()/eval(), load_state_dict or _apply (.to/.float) — `.data` edits do not
+    bump the version counters the cache keys on — and forge_amd.invalidate_packed() is the explicit call."""
+    import forge_amd
+    from forge_amd import convops as co
+    from forge_amd.fusion import ConvGRU_3D
+    gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=32, hidden_size=32)
+    w = gru.cells[0].conv_gate.weight
+
+    def arm():
+        gru._pack_cache._key, gru._pack_cache.val = gru._pack_cache.key_of([w]), "packed"
+    arm()
+    assert gru._pack_cache.get([w], lambda: "rebuilt") == "packed"
+    w.data.mul_(2.0)                                                   # invisible to the key ...
+    assert gru._pack_cache.get([w], lambda: "rebuilt") == "packed"
+    forge_amd.invalidate_packed(gru)                                   # ... so the explicit call exists
+    assert gru._pack_cache.get([w], lambda: "rebuilt") == "rebuilt"
+    for action in (lambda: gru.eval(), lambda: gru.train(), lambda: gru.load_state_dict(gru.state_dict()), lambda: gru.float()):
+        arm()
+        action()
+        assert gru._pack_cache._key is None and gru._pack_cache.val is None
+    with torch.no_grad():
+        arm()
+        w.mul_(0.5)                                                    # a versioned in-place op IS seen by the key
+    assert gru._pack_cache.get([w], lambda: "rebuilt") == "rebuilt"
+    assert isinstance(gru, co.PackedModule)
+
+
+def test_load_imagenet_trunk_key_mapping():
+    """torchvision resnet50 keys -> the nn.Sequential trunk (conv1 -> 0, bn1 -> 1, layerN -> N+3), fc dropped, shapes validated."""
+    from forge_amd.encoder import get_resnet50, load_imagenet_trunk
+    src, dst = get_resnet50(), get_resnet50()
+    names = {"0": "conv1", "1": "bn1", "4": "layer1", "5": "layer2", "6": "layer3", "7": "layer4"}
+    tv = {}
+    for k, v in src.state_dict().items():
+        head, rest = k.split(".", 1)
+        tv[names[head] + "." + rest] = v.clone() + (0.25 if v.is_floating_point() else 0)
+    tv["fc.weight"], tv["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    res = load_imagenet_trunk(dst, tv)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(b, a + (0.25 if a.is_floating_point() else 0)), k
+    bad = dict(tv)
+    bad["layer1.0.conv1.weight"] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        load_imagenet_trunk(dst, bad)
+    with pytest.raises(KeyError):
+        load_imagenet_trunk(dst, {"avgpool.weight": torch.zeros(1)})
+
+
+def test_stage_sample_passthrough_and_cpu():
+    """f4 staging helper: tensors already on the target device pass through untouched (same objects); non-tensor entries are kept."""
+    from forge_amd.staging import stage_sample
+    s = syn.make_sample(1, 5, 32, 1.5, seed=0)
+    s["seq_name"] = ["scene0"]
+    out = stage_sample(s, "cpu")
+    assert out is s
+    s64 = dict(s, K_cv2=s["K_cv2"].double())
+    out = stage_sample(s64, "cpu")
+    assert out["K_cv2"].dtype == torch.float32 and out["images"] is s["images"] and out["seq_name"] == ["scene0"]
+
+
+def test_modules_refuse_cpu_tensors_instead_of_falling_back():
+    """north_star "no dual code paths": the module entry points raise on inputs the HIP kernels cannot take."""
+    from forge_amd.encoder import Encoder3D
+    enc = Encoder3D(syn.kubric_config()).eval()
+    with torch.no_grad():
+        for call in (lambda: enc.get_feat3D(torch.zeros(1, 3, 64, 64)), lambda: enc.fuse(torch.zeros(1, 2, 128, 4, 4, 4)),
+                     lambda: enc.get_density3D(torch.zeros(1, 128, 4, 4, 4)), lambda: enc.get_render_features(torch.zeros(1, 128, 4, 4, 4)),
+                     lambda: enc.heads(torch.zeros(1, 128, 4, 4, 4)),
+                     lambda: enc.fusion_feature(torch.zeros(1, 2, 128, 4, 4, 4), None)):
+            with pytest.raises(RuntimeError, match="no CPU or stock-PyTorch path"):
+                call()

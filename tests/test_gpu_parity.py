@@ -617,7 +617,7 @@ def test_fuse_hip_vs_oracle(dev):
     ref = fo.fuse(x, w)
     with torch.no_grad():
         got = gru.fuse_hip(x.to(dev)).cpu()
-        stock = gru(x.to(dev), [gru.fusion_conv(x.to(dev).mean(dim=1))]).cpu()     # torch/MIOpen path, same module
+        stock = gru(x.to(dev), [gru.fusion_conv(x.to(dev).mean(dim=1))]).cpu()     # reference-style call: h0 from the caller (torch/MIOpen fusion_conv), recurrence on HIP
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
     assert (stock - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())

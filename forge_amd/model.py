@@ -58,6 +58,25 @@ class FORGE(nn.Module):
             nn.Linear(512, self.encoder_traj.pose_dim + 1),
         )
 
+    def reconstruct(self, features_raw, camPoses_cv2, cameras, idxs=None):
+        """a2..a7 on given per-view feature volumes: pose warp -> view order -> ConvGRU fusion -> heads -> ray-march of the V cameras of
+        `cameras` (b*V entries, scene-major) -> conv_rgb. features_raw [b,t,C,D,D,D] with D in Rotate_world's grid sizes: 32 is what
+        the encoder produces from 256^2 images (models/encoder.py:49); 64 is the reference's large-grid path (models/rotate.py:115-117)
+        -> 128^3 render volume (BASELINE configs[3]/[4]), fed with synthetic feature volumes by bench.py --grid 64.
+        Returns (rgb [b*V,3,img,img], masks [b*V,1,img,img], origin_proj [b*V,2])."""
+        b, t, C, D = features_raw.shape[:4]
+        device = features_raw.device
+        if idxs is None:
+            idxs = sequence_from_distance(camPoses_cv2[:, :, :3, 3])
+        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D)
+        features_transformed = chose_selected(features_transformed, idxs)
+        features_mv, densities_mv = self.encoder_3d.heads(self.encoder_3d.fuse(features_transformed))
+        if self.config.dataset.name == "omniobject3d":
+            densities_mv = densities_mv.clamp(min=0.0, max=1.0)
+        V = cameras["R"].shape[0] // b
+        view2vol = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
+        return self.render(cameras, features_mv, densities_mv, return_origin_proj=True, view2vol=view2vol)
+
     def forward(self, sample, dataset, device):
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
         b, t_all = sample["images"].shape[:2]
@@ -93,16 +112,7 @@ class FORGE(nn.Module):
         assert V == t_all, "sample must carry intrinsics for every rendered camera"
         cameras = geo_utils.camera_dict(camE_all, sample["K_cv2"])
 
-        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2[:, :t], grid_size=D)
-        features_transformed = chose_selected(features_transformed, idxs)
-
-        features_mv, densities_mv = self.encoder_3d.heads(self.encoder_3d.fuse(features_transformed))
-        if self.config.dataset.name == "omniobject3d":
-            densities_mv = densities_mv.clamp(min=0.0, max=1.0)
-
-        view2vol = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
-        rendered_imgs, rendered_masks, origin_proj = self.render(cameras, features_mv, densities_mv,
-                                                                 return_origin_proj=True, view2vol=view2vol)
+        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras, idxs)
         if self.config.train.use_gt_pose:
             return rendered_imgs, rendered_masks
         return rendered_imgs, rendered_masks, 2 * origin_proj / self.config.dataset.img_size, camPose_return

@@ -312,6 +312,25 @@ def forward_pose3d_gt(sample, w, cfg, training=False):
                       cfg.render.volume_size, cfg.render.k_size, training=training)[:2]
 
 
+def reconstruct_from_features(feats, poses, extrinsics, K, w, cfg, training=False, order_by_distance=False):
+    """a2..a7 of models/model.py:127-145 on GIVEN per-view feature volumes feats [b,t,C,D,D,D]: rotate -> [order] -> fuse -> heads ->
+    render the V = extrinsics.shape[1] cameras. D = 32 is what the encoder produces; D = 64 is the reference's large-grid path
+    (models/rotate.py:115-117 -> 128^3 render volume, BASELINE configs[3]/[4])."""
+    b = feats.shape[0]
+    ft = rotate_world(feats, poses, cfg.render.volume_size)
+    if order_by_distance:
+        ft = chose_selected(ft, sequence_from_distance(poses[:, :, :3, 3]))
+    fm = fuse(ft, w, training=training)
+    dm = density_head(fm, w, training=training)
+    rm = render_features_head(fm, w, training=training)
+    V = extrinsics.shape[1]
+    rep = lambda v: v.unsqueeze(1).repeat(1, V, 1, 1, 1, 1).reshape(b * V, *v.shape[1:])
+    E = extrinsics.reshape(b * V, 4, 4)
+    return vol_render(rep(rm), rep(dm), E[:, :3, :3], E[:, :3, 3], K.reshape(b * V, 3, 3), w,
+                      cfg.dataset.img_size, cfg.render.n_pts_per_ray, cfg.render.min_depth,
+                      cfg.render.max_depth, cfg.render.volume_size, cfg.render.k_size, training=training)[:2]
+
+
 def forward_hot_path(images, poses, extrinsics, K, w, cfg, training=False, order_by_distance=False,
                      render_extrinsics=None, render_K=None):
     """The 5-in / V-out hot path a1..a7 of models/model.py:42-148 with poses GIVEN (pose
@@ -321,20 +340,8 @@ def forward_hot_path(images, poses, extrinsics, K, w, cfg, training=False, order
     feats = get_feat3D(images.reshape(b * t, *images.shape[2:]), w, training)
     C, D = feats.shape[1], feats.shape[2]
     feats = feats.reshape(b, t, C, D, D, D)
-    ft = rotate_world(feats, poses, cfg.render.volume_size)
-    if order_by_distance:
-        ft = chose_selected(ft, sequence_from_distance(poses[:, :, :3, 3]))
-    fm = fuse(ft, w, training=training)
-    dm = density_head(fm, w, training=training)
-    rm = render_features_head(fm, w, training=training)
-    E = extrinsics if render_extrinsics is None else render_extrinsics
-    Kr = K if render_K is None else render_K
-    V = E.shape[1]
-    rep = lambda v: v.unsqueeze(1).repeat(1, V, 1, 1, 1, 1).reshape(b * V, *v.shape[1:])
-    E = E.reshape(b * V, 4, 4)
-    return vol_render(rep(rm), rep(dm), E[:, :3, :3], E[:, :3, 3], Kr.reshape(b * V, 3, 3), w,
-                      cfg.dataset.img_size, cfg.render.n_pts_per_ray, cfg.render.min_depth,
-                      cfg.render.max_depth, cfg.render.volume_size, cfg.render.k_size, training=training)[:2]
+    return reconstruct_from_features(feats, poses, extrinsics if render_extrinsics is None else render_extrinsics,
+                                     K if render_K is None else render_K, w, cfg, training, order_by_distance)
 
 
 def psnr(a, b):

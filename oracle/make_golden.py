@@ -211,11 +211,48 @@ def loss_goldens(m):
     npz("loss_terms", **out)
 
 
+def joint_goldens(m):
+    """a8 with PREDICTED poses, from the reference's own classes in eval mode (seeded sample / weights, neither stored):
+      joint        models/model.py:42-148            FORGE(use_gt_pose=False): 2-D + 3-D pose estimators + pose head -> cameras ->
+                                                     rotate -> order -> fuse -> heads -> render of 5 predicted + 5 GT novel cameras
+      joint_pose   models/model.py:98-114            the same model in parameter='pose' mode: (pose dict, origin projection) only
+      pose3d       models/model_single_pose_estimator.py:26-138  FORGE_poseEstimator3D(use_gt_pose=False): 3-D pose estimator alone
+    Pins forge_amd/pose_estimator_{2d,3d}.py, geo_utils.predicted_camera_chain and the pose-gradient-free predicted-pose branch."""
+    ds = syn.SyntheticDataset(1.5)
+    out = {"sample_seed": 12, "weight_seed": 0}
+    sample = syn.make_sample(1, 10, 256, 1.5, seed=12)
+    jm = m["models.model"].FORGE(ref_import.kubric_config(use_gt_pose=False, parameter="joint")).eval()
+    sdj = syn.seeded_state_dict(jm.state_dict(), 0)
+    jm.load_state_dict(sdj)
+    with torch.no_grad():
+        imgs, masks, oproj, pose = jm({k: v.clone() for k, v in sample.items()}, ds, "cpu")
+    out.update({"joint__imgs_sub": imgs[:, :, ::4, ::4], "joint__masks_sub": masks[:, :, ::4, ::4], "joint__imgs_mean": imgs.mean(dim=(1, 2, 3)),
+                "joint__masks_mean": masks.mean(dim=(1, 2, 3)), "joint__origin_proj": oproj, "joint__pose_pred": pose["pred"],
+                "joint__pose_gt": pose["gt"], "joint__conf": pose["conf"]})
+    print("  joint: mask mean %.4f, pose_pred[0] %s" % (masks.mean().item(), pose["pred"][0].tolist()))
+    jm.config.train.parameter = "pose"
+    with torch.no_grad():
+        pose2, oproj2 = jm({k: v.clone() for k, v in sample.items()}, ds, "cpu")
+    out.update({"joint_pose__origin_proj": oproj2, "joint_pose__pose_pred": pose2["pred"]})
+    pm = m["models.model_single_pose_estimator"].FORGE_poseEstimator3D(ref_import.kubric_config(use_gt_pose=False)).eval()
+    pm.load_state_dict(syn.seeded_state_dict(pm.state_dict(), 0))
+    s5 = {k: v[:, :5].clone() for k, v in sample.items()}
+    with torch.no_grad():
+        imgs, masks, oproj, pose = pm(s5, ds, "cpu")
+    out.update({"pose3d__imgs_sub": imgs[:, :, ::4, ::4], "pose3d__masks_sub": masks[:, :, ::4, ::4], "pose3d__imgs_mean": imgs.mean(dim=(1, 2, 3)),
+                "pose3d__masks_mean": masks.mean(dim=(1, 2, 3)), "pose3d__origin_proj": oproj, "pose3d__pose_pred": pose["pred"],
+                "pose3d__pose_gt": pose["gt"], "pose3d__conf": pose["conf"]})
+    print("  pose3d(pred): mask mean %.4f, pose_pred[0] %s" % (masks.mean().item(), pose["pred"][0].tolist()))
+    npz("forward_joint", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("loss", "train"):   # only that fixture (the others are unchanged)
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens}
+    if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
-        {"loss": loss_goldens, "train": train_goldens}[sys.argv[1]](ref_import.import_reference())
+        single[sys.argv[1]](ref_import.import_reference())
     else:
         main()
         loss_goldens(ref_import.import_reference())
         train_goldens(ref_import.import_reference())
+        joint_goldens(ref_import.import_reference())

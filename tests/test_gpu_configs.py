@@ -1,0 +1,373 @@
+"""GPU (-m gpu), round 2: the BASELINE configurations round 1 left unexercised, the analytic renderer KATs, the reference's
+predicted-pose forward, checkpoint round trips and the ADVICE r1 regressions — all through the C-ABI.
+
+  configs[2]  full HIP path, batch = 8 scenes, 64^3 render grid                   test_config2_batch8_*
+  configs[3]  training step on 128^3-voxel scenes (64^3 feature grid)            test_config3_*
+  configs[4]  joint 2D3D (predicted poses) + 128^3 voxel                          test_forge_joint_forward_vs_reference_golden, test_config4_*
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import forge_oracle as fo
+import kat_render
+from forge_amd import geo_utils, ops, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+T = lambda a: torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from forge_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _model(cls, dev, cfg=None, seed=0, train=False):
+    cfg = cfg or syn.kubric_config()
+    model = cls(cfg)
+    w = syn.seeded_state_dict(model.state_dict(), seed)
+    model.load_state_dict(w)
+    model = model.to(dev)
+    return (model.train() if train else model.eval()), w, cfg
+
+
+# ------------------------------------------------------------------------------------------------------------- a6 analytic KATs
+def test_render_analytic_kats_hip(dev):
+    """forge_render_fwd against the analytic known answers of tests/kat_render.py (derived from the documented PyTorch3D contracts,
+    not from the oracle or its shims): uniform slabs on cubic / anisotropic grids (x<->W, y<->H), single-voxel impulses under a
+    rotated camera with fx != fy, cx != cy (hit pixel = OpenCV projection of the voxel centre), a depth sample exactly on a voxel."""
+    for case in kat_render.cases():
+        cam = case["cam"]
+        D, H, W = case["dims"]
+        s = case["vol"] / D
+        half = (0.5 * (W - 1) * s, 0.5 * (H - 1) * s, 0.5 * (D - 1) * s)
+        cam16 = torch.tensor(list(cam["R"].reshape(9)) + list(cam["T"]) + [cam["fx"], cam["fy"], cam["cx"], cam["cy"]], dtype=torch.float32)[None]
+        feat = torch.from_numpy(case["feat"]).float()[None].to(dev)
+        dens = torch.from_numpy(case["dens"]).float()[None, None].to(dev)
+        of, oo, od = ops.render_rays(feat, dens, cam16.to(dev), torch.zeros(1, dtype=torch.int32, device=dev), case["Hr"], case["Wr"],
+                                     case["S"], case["zmin"], case["zmax"], half, True)
+        got = torch.cat([of, oo, od], dim=1)[0].permute(1, 2, 0).cpu().numpy()
+        kat_render.check(case, got)
+
+
+# ------------------------------------------------------------------------------------------------------------- a8 predicted poses
+def test_forge_joint_forward_vs_reference_golden(dev, golden):
+    """models/model.py:42-148 with use_gt_pose=False, eval mode: the REFERENCE's own output (tests/golden/forward_joint.npz) vs
+    forge_amd.model.FORGE on the MI355X — pins pose_estimator_{2d,3d}.py, the pose head, the predicted-camera chain, the ordering by
+    predicted translations and the HIP path behind them. Stated tolerance: poses 5e-4; images max-abs 5e-3 / PSNR > 55 dB (pose noise
+    of 1e-4 moves the warp / the cameras by a fraction of a voxel on top of the usual ~70-layer fp32 noise)."""
+    from forge_amd.model import FORGE
+    g = golden("forward_joint")
+    cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+    model, _, _ = _model(FORGE, dev, cfg, int(g["weight_seed"]))
+    sample = syn.make_sample(1, 10, 256, 1.5, seed=int(g["sample_seed"]))
+    with torch.no_grad():
+        imgs, masks, oproj, pose = model(sample, syn.SyntheticDataset(1.5), dev)
+    assert (pose["pred"].cpu() - T(g["joint__pose_pred"])).abs().max().item() < 5e-4
+    assert (pose["conf"].cpu() - T(g["joint__conf"])).abs().max().item() < 5e-4
+    assert (pose["gt"].cpu() - T(g["joint__pose_gt"])).abs().max().item() < 1e-5
+    assert (oproj.cpu() - T(g["joint__origin_proj"])).abs().max().item() < 2e-3
+    ref_i, ref_m = T(g["joint__imgs_sub"]), T(g["joint__masks_sub"])
+    assert (imgs.cpu()[:, :, ::4, ::4] - ref_i).abs().max().item() < 5e-3 and fo.psnr(imgs.cpu()[:, :, ::4, ::4], ref_i) > 55.0
+    assert (masks.cpu()[:, :, ::4, ::4] - ref_m).abs().max().item() < 5e-3
+    assert (imgs.cpu().mean(dim=(1, 2, 3)) - T(g["joint__imgs_mean"])).abs().max().item() < 2e-4
+    # pose-only mode (models/model.py:98-114)
+    model.config.train.parameter = "pose"
+    with torch.no_grad():
+        pose2, oproj2 = model(sample, syn.SyntheticDataset(1.5), dev)
+    assert (pose2["pred"].cpu() - T(g["joint_pose__pose_pred"])).abs().max().item() < 5e-4
+    assert (oproj2.cpu() - T(g["joint_pose__origin_proj"])).abs().max().item() < 2e-3
+
+
+def test_pose3d_predicted_pose_forward_vs_reference_golden(dev, golden):
+    """models/model_single_pose_estimator.py:26-138 with use_gt_pose=False (3-D pose estimator alone), eval mode, vs the reference."""
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    g = golden("forward_joint")
+    model, _, _ = _model(FORGE_poseEstimator3D, dev, syn.kubric_config(use_gt_pose=False), int(g["weight_seed"]))
+    sample = {k: v[:, :5].contiguous() for k, v in syn.make_sample(1, 10, 256, 1.5, seed=int(g["sample_seed"])).items()}
+    with torch.no_grad():
+        imgs, masks, oproj, pose = model(sample, syn.SyntheticDataset(1.5), dev)
+    assert (pose["pred"].cpu() - T(g["pose3d__pose_pred"])).abs().max().item() < 5e-4
+    assert (pose["conf"].cpu() - T(g["pose3d__conf"])).abs().max().item() < 5e-4
+    assert (oproj.cpu() - T(g["pose3d__origin_proj"])).abs().max().item() < 2e-3
+    assert (imgs.cpu()[:, :, ::4, ::4] - T(g["pose3d__imgs_sub"])).abs().max().item() < 5e-3
+    assert (masks.cpu()[:, :, ::4, ::4] - T(g["pose3d__masks_sub"])).abs().max().item() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------------------- configs[2]
+def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
+    """BASELINE configs[2]: full HIP path, batch = 8 scenes, 64^3 render grid, 1 GPU. Scenes 2 and 5 of the batch against the CPU
+    oracle; every scene of the batch equals the same scene run alone (b = 1) up to fp32 summation order under the default launch
+    plan (the plan model may pick another tile / split-K factor for another M), and BIT FOR BIT when both runs are pinned to one
+    plan (FORGE_CONV_TILE / FORGE_CONV_KSPLIT): the batch only changes M, never the per-row arithmetic."""
+    from forge_amd.model import FORGE
+    model, w, cfg = _model(FORGE, dev)
+    ds = syn.SyntheticDataset(1.5)
+    sample = syn.make_sample(8, 5, 256, 1.5, seed=31)
+    with torch.no_grad():
+        imgs, masks = model(sample, ds, dev)
+    assert imgs.shape == (40, 3, 256, 256) and masks.shape == (40, 1, 256, 256)
+    imgs, masks = imgs.cpu().reshape(8, 5, 3, 256, 256), masks.cpu().reshape(8, 5, 1, 256, 256)
+    for s in (2, 5):
+        one = {k: v[s:s + 1] for k, v in sample.items()}
+        with torch.no_grad():
+            oi, om = fo.forward_hot_path(one["images"], one["cam_poses_cv2_canonicalized"], one["cam_extrinsics_cv2_canonicalized"],
+                                         one["K_cv2"], w, cfg, order_by_distance=True)
+        assert (imgs[s] - oi).abs().max().item() < 2e-3 and fo.psnr(imgs[s], oi) > 60.0, s
+        assert (masks[s] - om).abs().max().item() < 5e-4, s
+    worst = 0.0
+    for s in range(8):
+        one = {k: v[s:s + 1].contiguous() for k, v in sample.items()}
+        with torch.no_grad():
+            i1, m1 = model(one, ds, dev)
+        worst = max(worst, (i1.cpu() - imgs[s]).abs().max().item(), (m1.cpu() - masks[s]).abs().max().item())
+    # different M -> possibly different tile / split-K plans -> different fp32 summation orders: equality up to rounding, stated
+    assert worst < 2e-4, worst
+    monkeypatch.setenv("FORGE_CONV_TILE", "D")
+    monkeypatch.setenv("FORGE_CONV_KSPLIT", "1")
+    with torch.no_grad():
+        pi, pm = model(sample, ds, dev)
+        pi, pm = pi.reshape(8, 5, 3, 256, 256).clone(), pm.reshape(8, 5, 1, 256, 256).clone()
+        for s in range(8):
+            i1, m1 = model({k: v[s:s + 1].contiguous() for k, v in sample.items()}, ds, dev)
+            assert torch.equal(i1, pi[s]) and torch.equal(m1, pm[s]), s
+
+
+def test_config2_batch8_graph_replay_equals_eager(dev):
+    """The bench's launch mode at b = 8: hipGraph replay == eager launch, bit for bit."""
+    from forge_amd.graph import GraphedForward
+    from forge_amd.model import FORGE
+    model, _, _ = _model(FORGE, dev)
+    ds = syn.SyntheticDataset(1.5)
+    sample = {k: v.to(dev) for k, v in syn.make_sample(8, 5, 256, 1.5, seed=32).items()}
+    with torch.no_grad():
+        ei, em = model(sample, ds, dev)
+    g = GraphedForward(model, sample, ds, dev)
+    gi, gm = g(sample)
+    assert torch.equal(ei, gi) and torch.equal(em, gm)
+
+
+# ------------------------------------------------------------------------------------------------------------- 128^3-voxel configs
+def _grid64_inputs(t, seed, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(1, t, 128, 64, 64, 64, generator=g) * scale
+    jit = (torch.rand(10, 2, generator=g) - 0.5) * 0.3
+    poses, extr, _ = syn.orbit_cameras(10, 1.5, 12.0, jit)
+    return feats, poses, extr
+
+
+def test_config4_grid64_stages_vs_oracle_crops(dev):
+    """128^3-voxel path (models/rotate.py:115-117: 64^3 feature grid -> heads -> 128^3 render volume) stage by stage on synthetic
+    [1,3,128,64^3] feature volumes: rotate(D=64) vs the oracle on a channel slice; ConvGRU fusion at M = 262144 vs the oracle on a
+    40^3 crop (interior 16^3 is outside the crop's 12-voxel boundary influence: 2 + 2t conv layers); heads to 128^3 vs the oracle on a
+    32^3 crop; ray-march of the 128^3 x 17 volume (142.6 MB) vs the oracle; reconstruct() end to end equals the staged pieces."""
+    from forge_amd.model import FORGE, chose_selected, sequence_from_distance
+    model, w, cfg = _model(FORGE, dev)
+    t = 3
+    feats, poses, extr = _grid64_inputs(t, 5)
+    P = poses[None, :t].contiguous()
+    fd = feats.to(dev)
+    with torch.no_grad():
+        ft = model.rotate(voxels=fd, camPoses_cv2=P.to(dev), grid_size=64)
+        ref_rot = fo.rotate_world(feats[:, :, :8], P, 1.0)
+        assert (ft[:, :, :8].cpu() - ref_rot).abs().max().item() < 3e-5
+        idx = sequence_from_distance(P[:, :, :3, 3])
+        ft = chose_selected(ft, idx)
+        fused = model.encoder_3d.fuse(ft)
+        assert fused.shape == (1, 128, 64, 64, 64)
+        crop = ft[:, :, :, 8:48, 8:48, 8:48].cpu().contiguous()
+        ref_f = fo.fuse(crop, w)[:, :, 12:28, 12:28, 12:28]
+        got_f = fused[:, :, 20:36, 20:36, 20:36].cpu()
+        assert (got_f - ref_f).abs().max().item() < 2e-4 * max(1.0, ref_f.abs().max().item())
+        feat3, dens3 = model.encoder_3d.heads(fused)
+        assert feat3.shape == (1, 16, 128, 128, 128) and dens3.shape == (1, 1, 128, 128, 128)
+        zc = fused[:, :, 16:48, 16:48, 16:48].cpu().contiguous()
+        ref_d, ref_r = fo.density_head(zc, w)[..., 8:56, 8:56, 8:56], fo.render_features_head(zc, w)[..., 8:56, 8:56, 8:56]
+        assert (dens3[..., 40:88, 40:88, 40:88].cpu() - ref_d).abs().max().item() < 1e-4 * max(1.0, ref_d.abs().max().item())
+        assert (feat3[..., 40:88, 40:88, 40:88].cpu() - ref_r).abs().max().item() < 1e-4 * max(1.0, ref_r.abs().max().item())
+        # ray-march the 128^3 volume: two cameras, 128^2 rays x 64 samples
+        E = extr[[1, 7]]
+        K = syn.intrinsics(256)[None].repeat(2, 1, 1)
+        Kh = fo.halve_intrinsics(K)
+        ref_raw = fo.render_rays(feat3.cpu().repeat(2, 1, 1, 1, 1), dens3.cpu().repeat(2, 1, 1, 1, 1), E[:, :3, :3], E[:, :3, 3], Kh,
+                                 128, 128, 64, 0.5, 2.0, 1.0, False)
+        cam = torch.cat([E[:, :3, :3].reshape(2, 9), E[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1).to(dev)
+        h = fo.grid_half_extent(128, 1.0)
+        of, oo = ops.render_rays(feat3, dens3, cam, torch.zeros(2, dtype=torch.int32, device=dev), 128, 128, 64, 0.5, 2.0, (h, h, h), False)
+        got_raw = torch.cat([of, oo], dim=1).permute(0, 2, 3, 1).cpu()
+        assert (got_raw - ref_raw).abs().max().item() < 3e-5 * max(1.0, ref_raw.abs().max().item())
+        # end to end through reconstruct(): identical kernels, identical results
+        cams = geo_utils.camera_dict(E[None].to(dev), K[None].to(dev))
+        imgs, masks, _ = model.reconstruct(fd, P.to(dev), cams)
+        rgb_ref = model.render._conv_rgb_hip(of)
+        assert (imgs - rgb_ref).abs().max().item() < 1e-6 and torch.isfinite(imgs).all() and imgs.shape == (2, 3, 256, 256)
+
+
+def test_config4_grid64_batch_equals_single_scene(dev):
+    """Full-size property at the 64^3 feature grid: fuse + heads of a 2-scene batch (operands of 805 MB / 1.07 GB: batch-strided
+    addressing close to the kernels' 2 GiB buffer range, and chunked when MAX_OPERAND_BYTES is lowered) equal each scene run alone
+    up to fp32 summation order; the chunked launch equals the unchunked one bit for bit."""
+    from forge_amd import convops as co
+    from forge_amd.model import FORGE
+    model, _, _ = _model(FORGE, dev)
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(2, 2, 128, 64, 64, 64, generator=g) * 0.5).to(dev)
+    with torch.no_grad():
+        both = model.encoder_3d.fuse(x)
+        f_b, d_b = model.encoder_3d.heads(both)
+        for s in range(2):
+            one = model.encoder_3d.fuse(x[s:s + 1])
+            assert (one - both[s:s + 1]).abs().max().item() < 2e-4 * max(1.0, both.abs().max().item())
+            f1, d1 = model.encoder_3d.heads(both[s:s + 1])
+            assert (f1 - f_b[s:s + 1]).abs().max().item() < 1e-4 * max(1.0, f_b.abs().max().item())
+            assert (d1 - d_b[s:s + 1]).abs().max().item() < 1e-4 * max(1.0, d_b.abs().max().item())
+        old = co.MAX_OPERAND_BYTES
+        try:
+            co.MAX_OPERAND_BYTES = 700 << 20                     # forces one scene per launch for the [b,t,...] input and the heads' up tensor
+            chunked = model.encoder_3d.fuse(x)
+            f_c, d_c = model.encoder_3d.heads(both)
+        finally:
+            co.MAX_OPERAND_BYTES = old
+        assert torch.equal(chunked, both) and torch.equal(f_c, f_b) and torch.equal(d_c, d_b)
+
+
+def test_config3_grid64_training_step_vs_oracle_autograd(dev):
+    """BASELINE configs[3] shape of the TRAINING path at the 128^3-voxel grid: rotate -> fuse -> heads -> ray-march -> conv_rgb in
+    train mode (BatchNorm batch statistics) on a synthetic [1,2,128,64^3] feature volume, loss = 5 MSE(rgb) + MSE(mask), backward through
+    every HIP backward kernel at full size (rotate gather-adjoint at 64^3, ConvGRU dgrad/wgrad at M = 262144, transposed-conv and
+    narrow-layer backward at 128^3, ray-march backward into a 142.6 MB volume) vs autograd through the CPU oracle: loss and the
+    gradients of the input features and of parameters from every stage. Tolerance 1e-2 of each gradient's max (fp32 atomics)."""
+    from forge_amd.model import FORGE
+    model, w, cfg = _model(FORGE, dev, train=True)
+    t = 2
+    feats, poses, extr = _grid64_inputs(t, 13)
+    P = poses[None, :t].contiguous()
+    E = extr[None, [0, 3]].contiguous()
+    K = syn.intrinsics(256)[None, None].repeat(1, 2, 1, 1)
+    g = torch.Generator().manual_seed(3)
+    tgt_i, tgt_m = torch.rand(2, 3, 256, 256, generator=g), torch.rand(2, 1, 256, 256, generator=g)
+    fd = feats.to(dev).requires_grad_(True)
+    imgs, masks, _ = model.reconstruct(fd, P.to(dev), geo_utils.camera_dict(E.to(dev), K.to(dev)))
+    loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i.to(dev)) + torch.nn.functional.mse_loss(masks, tgt_m.to(dev))
+    loss.backward()
+    keys = ["encoder_3d.fusion_feature.cells.0.conv_gate.bias", "encoder_3d.fusion_feature.cells.0.out_gate.bias",
+            "encoder_3d.fusion_feature.fusion_conv.4.weight", "encoder_3d.fusion_feature.fusion_norm.weight", "encoder_3d.features_head.3.bias",
+            "encoder_3d.density_head.6.weight", "render.conv_rgb.3.weight"]
+    wo = {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in w.items()}
+    fr = feats.clone().requires_grad_(True)
+    oi, om = fo.reconstruct_from_features(fr, P, E, K, wo, cfg, training=True, order_by_distance=True)
+    lo = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item()))
+    named = dict(model.named_parameters())
+    gscale = max(wo[k].grad.abs().max().item() for k in keys)
+    for k in keys:
+        ref = wo[k].grad
+        err = (named[k].grad.cpu() - ref).abs().max().item()
+        assert err < 1e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
+    gf = fd.grad.cpu()
+    assert (gf - fr.grad).abs().max().item() < 1e-2 * fr.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------------------- f4
+def test_checkpoint_round_trip_reference_layout(dev, golden, tmp_path):
+    """f4: a checkpoint written in the reference's layout (utils/train_utils.py:167: {'epoch','state_dict' with DDP's `module.`
+    prefix,'optimizer','best_psnr'}) is read back with strict=True by resume_training (utils/exp_utils.py:152-182) and reproduces the
+    reference model's golden forward; load_encoder_pretrained (utils/exp_utils.py:185-216) hands the encoder_3d/rotate/render
+    sub-trees over to a joint FORGE model (strict per sub-module) which then renders the same views. The sample arrives as HOST
+    tensors: one pinned staging copy (forge_amd/staging.py)."""
+    from forge_amd import checkpoint as ck
+    from forge_amd.model import FORGE
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    g = golden("forward_pose3d")
+    src, w, cfg = _model(FORGE_poseEstimator3D, dev, seed=int(g["weight_seed"]))
+    opt = torch.optim.Adam(src.parameters(), lr=cfg.train.lr)
+    ck.save_checkpoint({"epoch": 7, "state_dict": {"module." + k: v for k, v in src.state_dict().items()}, "optimizer": opt.state_dict(),
+                        "best_psnr": 21.5}, str(tmp_path), "cpt_last.pth.tar")
+    fresh = FORGE_poseEstimator3D(cfg).to(dev).eval()
+    with torch.no_grad():
+        sample = syn.make_sample(1, 5, 256, 1.5, seed=int(g["sample_seed"]))
+        stale = fresh(sample, syn.SyntheticDataset(1.5), dev)[0].clone()          # populates the packed-weight caches with the random init
+    opt2 = torch.optim.Adam(fresh.parameters(), lr=cfg.train.lr)
+    fresh, opt2, epoch, best_psnr, best_rot = ck.resume_training(fresh, opt2, str(tmp_path), strict=True, device=dev)
+    assert epoch == 7 and best_psnr == 21.5 and best_rot == float("inf")
+    with torch.no_grad():
+        imgs, masks = fresh(sample, syn.SyntheticDataset(1.5), dev)               # host sample -> staged copy; caches must have been dropped
+    assert not torch.equal(imgs, stale)
+    assert (imgs.cpu()[:, :, ::4, ::4] - T(g["imgs_sub"])).abs().max().item() < 2e-3
+    assert (masks.cpu()[:, :, ::4, ::4] - T(g["masks_sub"])).abs().max().item() < 5e-4
+    assert fo.psnr(imgs.cpu()[:, :, ::4, ::4], T(g["imgs_sub"])) > 60.0
+    # stage hand-over into the joint model
+    joint = FORGE(syn.kubric_config()).to(dev).eval()
+    ck.load_encoder_pretrained(joint, str(tmp_path), strict=True, device=dev)
+    for name in ("encoder_3d", "rotate", "render"):
+        for (k, a), (_, b) in zip(getattr(joint, name).state_dict().items(), getattr(src, name).state_dict().items()):
+            assert torch.equal(a, b), (name, k)
+    with pytest.raises(RuntimeError):
+        ck.resume_training(joint, None, str(tmp_path), strict=True, device=dev)    # pose networks are missing from the GT-pose checkpoint
+
+
+def test_staged_sample_equals_device_resident_sample(dev):
+    """One pinned host->device copy per forward (f4): results identical to the device-resident sample; tensors of an earlier forward
+    are not overwritten by the next staging."""
+    from forge_amd.model import FORGE
+    from forge_amd.staging import stage_sample
+    model, _, _ = _model(FORGE, dev)
+    ds = syn.SyntheticDataset(1.5)
+    host = syn.make_sample(2, 5, 256, 1.5, seed=44)
+    st1 = stage_sample(host, dev)
+    keep = st1["images"].clone()
+    host2 = syn.make_sample(2, 5, 256, 1.5, seed=45)
+    st2 = stage_sample(host2, dev)
+    assert torch.equal(st1["images"], keep) and torch.equal(st1["images"].cpu(), host["images"])
+    assert st2["K_cv2"].data_ptr() % 256 == 0 and torch.equal(st2["cam_poses_rel_cv2"].cpu(), host2["cam_poses_rel_cv2"])
+    with torch.no_grad():
+        a = model(host, ds, dev)
+        b = model({k: v.to(dev) for k, v in host.items()}, ds, dev)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+# ------------------------------------------------------------------------------------------------------------- ADVICE r1 regressions
+def test_inference_mode_and_data_edit_invalidation(dev):
+    """(i) forward under torch.inference_mode() (inference tensors have no version counter: the old heads memo crashed);
+    (ii) a `.data` edit + forge_amd.invalidate_packed() changes the fused inference output exactly as it changes the autograd path."""
+    import forge_amd
+    from forge_amd.model import FORGE
+    model, _, _ = _model(FORGE, dev)
+    ds = syn.SyntheticDataset(1.5)
+    sample = {k: v.to(dev) for k, v in syn.make_sample(1, 5, 256, 1.5, seed=8).items()}
+    with torch.no_grad():
+        base = model(sample, ds, dev)[0].clone()
+    with torch.inference_mode():
+        inf = model(sample, ds, dev)[0]
+        assert torch.equal(inf, base)
+    p = model.encoder_3d.features_head[3].weight
+    p.data.mul_(1.5)
+    forge_amd.invalidate_packed(model)
+    with torch.no_grad():
+        edited = model(sample, ds, dev)[0]
+    assert not torch.equal(edited, base)
+    model.eval()                                                       # mode switches drop the caches too
+    p.data.div_(1.5)
+    model.eval()
+    with torch.no_grad():
+        back = model(sample, ds, dev)[0]
+    assert (back - base).abs().max().item() < 1e-5
+
+
+def test_single_head_getters_equal_merged_heads(dev):
+    """get_density3D / get_render_features (each head alone, N = 32 transposed conv) == heads() (merged N = 64 launch)."""
+    from forge_amd.encoder import Encoder3D
+    enc = Encoder3D(syn.kubric_config())
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in
+                         syn.seeded_state_dict({"encoder_3d." + k: v for k, v in enc.state_dict().items()}, 0).items()})
+    enc = enc.to(dev).eval()
+    z = torch.randn(2, 128, 8, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        f, d = enc.heads(z)
+        assert (enc.get_render_features(z) - f).abs().max().item() < 1e-5 and (enc.get_density3D(z) - d).abs().max().item() < 1e-5

@@ -160,3 +160,68 @@ def test_training_loss_and_gradients_golden():
         ref = torch.from_numpy(gold["grad__" + k])
         err = (wo[k].grad - ref).abs().max().item()
         assert err < 5e-3 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err)
+
+
+def _kat_inputs(case):
+    cam = case["cam"]
+    K = torch.tensor([[cam["fx"], 0.0, cam["cx"]], [0.0, cam["fy"], cam["cy"]], [0.0, 0.0, 1.0]], dtype=torch.float32)[None]
+    return (torch.from_numpy(case["feat"]).float()[None], torch.from_numpy(case["dens"]).float()[None, None],
+            torch.from_numpy(cam["R"]).float()[None], torch.from_numpy(cam["T"]).float()[None], K)
+
+
+def test_render_analytic_kats():
+    """a6 pinned by analytic known answers that use neither oracle/shims nor the oracle's closed form (tests/kat_render.py: uniform
+    slabs on cubic / anisotropic grids, single-voxel impulses under a rotated camera with fx != fy, cx != cy). Checked for the torch
+    oracle and the plain-C restatement; the GPU suite runs the same cases through forge_render_fwd."""
+    import c_oracle
+    import kat_render
+    for case in kat_render.cases():
+        feat, dens, R, Tt, K = _kat_inputs(case)
+        got = fo.render_rays(feat, dens, R, Tt, K, case["Hr"], case["Wr"], case["S"], case["zmin"], case["zmax"], case["vol"], True)[0]
+        kat_render.check(case, got.numpy())
+        D, H, W = case["dims"]
+        s = case["vol"] / D
+        half = (0.5 * (W - 1) * s, 0.5 * (H - 1) * s, 0.5 * (D - 1) * s)
+        raw = c_oracle.render(feat.numpy(), dens.numpy(), R.numpy(), Tt.numpy(), K.numpy(), case["Hr"], case["Wr"], case["S"],
+                              case["zmin"], case["zmax"], half)
+        kat_render.check(case, raw[0])
+
+
+def test_pose_estimators_reproduce_reference_predictions(golden):
+    """forge_amd/pose_estimator_{2d,3d}.py + pose_head + geo_utils (stock torch, CPU here) on the oracle's encoder features reproduce
+    the pose vectors / confidences the REFERENCE's FORGE (use_gt_pose=False) and FORGE_poseEstimator3D(use_gt_pose=False) predicted on
+    the same seeded sample and weights (tests/golden/forward_joint.npz, oracle/make_golden.py::joint_goldens), and the projected
+    origins of the predicted cameras."""
+    from forge_amd import geo_utils
+    from forge_amd.model import FORGE
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    g = golden("forward_joint")
+    sample = syn.make_sample(1, 10, 256, 1.5, seed=int(g["sample_seed"]))
+    ds = syn.SyntheticDataset(1.5)
+    for cls, tag, nviews in ((FORGE, "joint", 10), (FORGE_poseEstimator3D, "pose3d", 10)):
+        cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+        model = cls(cfg).eval()
+        w = syn.seeded_state_dict(model.state_dict(), int(g["weight_seed"]))
+        model.load_state_dict(w)
+        clips = sample["images"][:, :5]
+        with torch.no_grad():
+            f3 = fo.get_feat3D(clips.reshape(5, 3, 256, 256), w).reshape(1, 5, 128, 32, 32, 32)
+            if cls is FORGE:
+                pf = torch.cat([model.encoder_traj(f3, return_features=True), model.encoder_traj_2d(clips, return_features=True)], dim=-1)
+                pose, conf = model.pose_head(pf).split([model.encoder_traj.pose_dim, 1], dim=-1)
+            else:
+                pose, conf = model.encoder_traj(f3)
+            pose, poses, extr = geo_utils.predicted_camera_chain(pose, model.encoder_traj.toSE3, ds.get_canonical_pose_cv2(),
+                                                                 ds.get_canonical_extrinsics_cv2(), 1, 5)
+            oproj = model.render.proj_origin(geo_utils.camera_dict(extr, sample["K_cv2"][:, :5]), "cpu") * 2 / cfg.dataset.img_size
+        assert (pose - T(g[tag + "__pose_pred"])).abs().max().item() < 2e-4, tag
+        assert (conf - T(g[tag + "__conf"])).abs().max().item() < 2e-4, tag
+        ref_o = T(g[tag + "__origin_proj"])
+        sel = slice(0, 5) if cls is FORGE else slice(0, 5)          # first five rendered cameras are the predicted input cameras
+        if cls is FORGE:
+            assert (oproj - ref_o[:5]).abs().max().item() < 2e-3, tag
+            assert (oproj - T(g["joint_pose__origin_proj"])).abs().max().item() < 2e-3
+            gt = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][:, 1:5].reshape(4, 4, 4))
+            assert (gt - T(g["joint__pose_gt"])).abs().max().item() < 1e-5
+        else:
+            assert (oproj - ref_o[:5]).abs().max().item() < 2e-3 and (oproj - ref_o[5:]).abs().max().item() < 2e-3, tag

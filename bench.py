@@ -125,28 +125,41 @@ def time_kernel(fn, iters=20, warm=3):
     return a.elapsed_time(b) / iters
 
 
-def kernel_rooflines(dev, B):
-    """Hand-written kernels at the bench shapes: ALGORITHMIC bytes per launch / avg duration."""
+def kernel_rooflines(dev, B, D=32):
+    """Hand-written kernels at the bench shapes: ALGORITHMIC bytes per launch / avg duration. D = feature grid (32 -> 64^3 render
+    volume, 64 -> 128^3). The HBM-bound kernels cycle through NBUF distinct source/destination sets whose total exceeds the 256 MB
+    Infinity Cache, so `ms` is an HBM number as inside the real step (a re-launch on one 168 MB set is served from the MALL:
+    26.7 us vs 42 us in the step)."""
     lib = _lib.lib()
     st = _lib.current_stream()
     out = {}
-    # rotate: n = B*5 volumes of [32^3, 128]; 4 warped (read + write) + 1 copied per scene
-    C, D, n = 128, 32, B * T_IN
-    vox = torch.randn(n, D, D, D, C, device=dev)
-    dst = torch.empty_like(vox)
+    # rotate: n = B*5 volumes of [D^3, 128]; 4 warped (read + write) + 1 copied per scene
+    C, n = 128, B * T_IN
+    set_bytes = n * C * D ** 3 * 4 * 2
+    nbuf = max(2, min(8, -(-(768 << 20) // set_bytes)))
+    srcs = [torch.randn(n, D, D, D, C, device=dev) for _ in range(nbuf)]
+    dsts = [torch.empty_like(srcs[0]) for _ in range(nbuf)]
     xf = torch.tensor([1, 0, 0, 0.02, 0, 0.8, -0.6, 0, 0, 0.6, 0.8, 0.01], device=dev).repeat(n, 1).contiguous()
     mode = torch.ones(n, dtype=torch.int32, device=dev)
     mode[::T_IN] = 0
-    ms = time_kernel(lambda: _lib.check(lib.forge_rotate_fwd(_lib.ptr(vox), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(dst),
-                                                               n, C, D, D, D, st), "rotate"))
-    byts = n * C * D ** 3 * 4 * 2
-    out["rotate_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic("rotate_fwd_kernel")}
-    # render: B volumes 64^3 x (16+1), V = 5 views each, 128^2 rays, 64 samples
-    Dr, Cr, V = 64, 16, B * V_OUT
-    feat, dens = syn.blob_volumes(B, Dr, Cr, seed=0)
-    feat = feat.to(dev).permute(0, 2, 3, 4, 1).contiguous()
-    dens = dens.to(dev).contiguous()
+    it = [0]
+
+    def rot():
+        k = it[0] % nbuf
+        it[0] += 1
+        _lib.check(lib.forge_rotate_fwd(_lib.ptr(srcs[k]), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(dsts[k]), n, C, D, D, D, st), "rotate")
+    ms = time_kernel(rot, iters=4 * nbuf, warm=nbuf)
+    out["rotate_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": set_bytes, "achieved": set_bytes / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": set_bytes / ms / 1e6 / HBM_PEAK_GBS, "working_set_mb": nbuf * set_bytes / 2 ** 20,
+                                "traffic": pmc_traffic("rotate_fwd_kernel")}
+    del srcs, dsts
+    # render: B volumes (2D)^3 x (16+1), V = 5 views each, 128^2 rays, 64 samples
+    Dr, Cr, V = 2 * D, 16, B * V_OUT
+    vol_bytes = B * 17 * Dr ** 3 * 4
+    nbuf = max(1, min(8, -(-(512 << 20) // vol_bytes))) if D > 32 else 1        # 64^3: the volume was just written by the heads (MALL-warm in the step too)
+    feat0, dens0 = syn.blob_volumes(B, Dr, Cr, seed=0)
+    feats = [feat0.to(dev).permute(0, 2, 3, 4, 1).contiguous() for _ in range(nbuf)]
+    denss = [dens0.to(dev).contiguous() for _ in range(nbuf)]
     _, extr, _ = syn.orbit_cameras(V_OUT, 1.5, 10.0)
     K = syn.intrinsics(256) / 2.0
     cam = torch.cat([extr[:, :3, :3].reshape(V_OUT, 9), extr[:, :3, 3], K[0, 0].expand(V_OUT, 1), K[1, 1].expand(V_OUT, 1),
@@ -155,16 +168,22 @@ def kernel_rooflines(dev, B):
     of = torch.empty(V, 128, 128, Cr, device=dev)
     oo = torch.empty(V, 128, 128, device=dev)
     h = 0.5 * (Dr - 1) / Dr
-    ms = time_kernel(lambda: _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v),
-                                                               _lib.ptr(of), _lib.ptr(oo), None, V, B, Cr, Dr, Dr, Dr, 128, 128, 64,
-                                                               0.5, 2.0, h, h, h, st), "render"))
-    byts = B * 17 * Dr ** 3 * 4 + V * 17 * 128 * 128 * 4
+    it[0] = 0
+
+    def ren():
+        k = it[0] % nbuf
+        it[0] += 1
+        _lib.check(lib.forge_render_fwd(_lib.ptr(feats[k]), _lib.ptr(denss[k]), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(of), _lib.ptr(oo), None,
+                                        V, B, Cr, Dr, Dr, Dr, 128, 128, 64, 0.5, 2.0, h, h, h, st), "render")
+    ms = time_kernel(ren, iters=max(8, 4 * nbuf), warm=max(2, nbuf))
+    byts = vol_bytes + V * 17 * 128 * 128 * 4
     taps = V * 128 * 128 * 64 * 17 * 8
     out["render_fwd_kernel"] = {"bound": "hbm", "ms": ms, "bytes": byts, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS,
-                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS, "working_set_mb": nbuf * vol_bytes / 2 ** 20,
                                 "gather_Gtaps_per_s": taps / ms / 1e6, "views_per_s_kernel_only": V / ms * 1e3,
                                 "traffic": pmc_traffic("render_fwd_kernel")}
-    # dense stage: the fp32-MFMA implicit-GEMM conv at the three ConvGRU shapes (32^3 grid, 3x3x3 taps)
+    del feats, denss
+    # dense stage: the fp32-MFMA implicit-GEMM conv at the three ConvGRU shapes (D^3 grid, 3x3x3 taps)
     from forge_amd import convops as co
     M, Cc = B * D ** 3, 128
     x = torch.randn(M, Cc, device=dev)
@@ -186,16 +205,69 @@ def kernel_rooflines(dev, B):
     return out
 
 
-def cpu_baseline(sample, weights, cfg, budget_s=25.0):
-    """The oracle (reference semantics, torch-CPU fp32) on this box's host cores: 1 warm-up + as many
-    timed 5-in/5-out hot-path forwards of ONE scene as fit the budget (>= 1)."""
+def physical_cores():
+    """Physical cores this process may run on (unique (socket, core) pairs of /proc/cpuinfo, capped by the affinity mask)."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        n = len(pairs) or allowed
+    except Exception:
+        n = allowed
+    return max(1, min(n, allowed)), allowed
+
+
+def _cpu_forward_fn(seed, threads):
+    """(run, ref-holder) of one oracle hot-path forward of ONE seeded scene on `threads` torch-CPU threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import forge_oracle as fo
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    weights = syn.seeded_state_dict(FORGE(cfg).state_dict(), 0)
+    one = syn.make_sample(1, T_IN, 256, 1.5, seed=seed)
+    torch.set_num_threads(threads)
+
+    def run():
+        with torch.no_grad():
+            return fo.forward_hot_path(one["images"], one["cam_poses_cv2_canonicalized"], one["cam_extrinsics_cv2_canonicalized"],
+                                       one["K_cv2"], weights, cfg, order_by_distance=True)
+    return run
+
+
+def cpu_worker(threads, n_forward, seed):
+    """`bench.py --cpu-worker THREADS N SEED`: one process of the scene-parallel CPU baseline. Prints 'CPUWORKER t_start t_end n'."""
+    run = _cpu_forward_fn(seed, threads)
+    run()                                            # warm-up (allocator, oneDNN primitive caches)
+    print("CPUWORKER_READY", flush=True)
+    sys.stdin.readline()                             # start line from the parent: all workers begin their timed forwards together
+    t0 = time.time()
+    for _ in range(n_forward):
+        run()
+    print("CPUWORKER %.6f %.6f %d" % (t0, time.time(), n_forward), flush=True)
+
+
+def cpu_baseline(sample, weights, cfg):
+    """The oracle (reference semantics, torch-CPU fp32: the port of the reference's CPU path) on this box's host cores.
+      1. single process: every candidate thread count gets 1 warm-up + 1 timed forward (a count whose warm-up exceeds 10 s is
+         recorded as such and not timed again), then the fastest count gets 5 timed forwards;
+      2. scene-parallel: P processes x T threads = all physical cores, each process running its own scene (how a CPU deployment would
+         fill the box; torch-CPU convolutions do not scale past ~16-32 threads), 1 warm-up + 2 timed forwards each, started together.
+    `value` is the better of the two aggregates; both are reported."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import forge_oracle as fo
+    phys, hw = physical_cores()
     one = {k: v[:1].cpu() for k, v in sample.items()}
 
     def run():
@@ -203,30 +275,111 @@ def cpu_baseline(sample, weights, cfg, budget_s=25.0):
             return fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN],
                                        one["cam_extrinsics_cv2_canonicalized"][:, :T_IN], one["K_cv2"][:, :T_IN],
                                        weights, cfg, order_by_distance=True)
-    # torch-CPU does not scale to every hardware thread of a 2-socket box (256 threads ran 30x slower than 32):
-    # probe a few thread counts inside the time budget and report the fastest one.
-    cands = sorted({c for c in (8, 16, 32, 64, cores // 2) if 1 <= c <= cores})
-    best, ref, t_start = None, None, time.time()
+    cands = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= phys})
+    sweep, ref = {}, None
     for nt in cands:
         torch.set_num_threads(nt)
         t0 = time.time()
-        r = run()                                   # warm-up for this thread count
-        t1 = time.time()
-        if ref is None:
-            ref = r
-        if t1 - t0 > budget_s / 2 and best is not None:
-            continue
         r = run()
-        dt_nt = time.time() - t1
-        if best is None or dt_nt < best[0]:
-            best = (dt_nt, nt)
-        if time.time() - t_start > budget_s:
-            break
-    dt, nthreads = best
-    n = 1
-    return {"value": V_OUT / dt, "unit": "views/s", "cores": nthreads, "host_hw_threads": cores, "kind": "port",
-            "sample": "%d timed forward(s) of 1 scene (5x256^2 in, 32^3/64^3 grids, 5x128^2x64 rays out), torch-CPU fp32, "
-                      "best of thread counts %s: %d threads, %.2f s per forward" % (n, cands, nthreads, dt)}, ref
+        warm = time.time() - t0
+        ref = r if ref is None else ref
+        if warm > 10.0:
+            sweep[nt] = {"warmup_s": round(warm, 2), "timed_s": None}
+            continue
+        t1 = time.time()
+        run()
+        sweep[nt] = {"warmup_s": round(warm, 2), "timed_s": round(time.time() - t1, 3)}
+    best_nt = min((v["timed_s"] if v["timed_s"] is not None else v["warmup_s"], k) for k, v in sweep.items())[1]
+    torch.set_num_threads(best_nt)
+    run()
+    times = []
+    for _ in range(5):
+        t0 = time.time()
+        run()
+        times.append(time.time() - t0)
+    single = {"threads": best_nt, "timed_forwards": 5, "s_per_forward": sum(times) / 5, "views_per_s": V_OUT * 5 / sum(times)}
+    # scene-parallel over all physical cores
+    tpp = min(16, phys)
+    nproc = max(1, phys // tpp)
+    nfw = 2
+    par = None
+    try:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(tpp), str(nfw), str(2000 + i)],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS=str(tpp), MKL_NUM_THREADS=str(tpp))) for i in range(nproc)]
+        for p in procs:
+            while True:
+                line = p.stdout.readline()
+                if not line or line.startswith("CPUWORKER_READY"):
+                    break
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        spans = []
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            for line in out.splitlines():
+                if line.startswith("CPUWORKER "):
+                    a, b, n = line.split()[1:]
+                    spans.append((float(a), float(b), int(n)))
+        if len(spans) == nproc:
+            wall = max(b for _, b, _ in spans) - min(a for a, _, _ in spans)
+            par = {"processes": nproc, "threads_per_process": tpp, "timed_forwards": nproc * nfw, "wall_s": wall,
+                   "views_per_s": V_OUT * sum(n for _, _, n in spans) / wall}
+    except Exception as e:                                              # the single-process number stands
+        par = {"error": repr(e)}
+    use_par = bool(par) and par.get("views_per_s", 0.0) > single["views_per_s"]
+    value = par["views_per_s"] if use_par else single["views_per_s"]
+    cores = par["processes"] * par["threads_per_process"] if use_par else best_nt
+    lscpu = ""
+    try:
+        lscpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": value, "unit": "views/s", "cores": cores, "physical_cores": phys, "host_hw_threads": hw, "cpu_model": lscpu, "kind": "port",
+            "sample": "oracle hot path, 1 scene per forward (5x256^2 in, 32^3/64^3 grids, 5x128^2x64 rays out), torch-CPU fp32; "
+                      "thread sweep %s; single process: 1 warm-up + 5 timed forwards at %d threads; scene-parallel: %s"
+                      % (sorted(sweep), best_nt, ("%d processes x %d threads, 1 warm-up + %d timed forwards each" % (nproc, tpp, nfw))),
+            "thread_sweep": sweep, "single_process": single, "scene_parallel": par}, ref
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-exec under torch.distributed.run with N ranks on this node
+    (one process per GPU; rendezvous on 127.0.0.1). Returns only in the children / for N = 1."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """`--dry-run`: the launch / rendezvous / timing-reduction skeleton of this entry point on CPU over gloo, with a token CPU workload
+    instead of the HIP step (tests/test_dist_cpu.py runs `python bench.py --gpus 8 --dry-run` here, where there is no GPU)."""
+    fdist.init(backend="gloo")
+    fdist.barrier()
+    t0 = time.perf_counter()
+    acc = 0.0
+    for _ in range(args.steps):
+        acc += float(torch.ones(64, 64).sum())
+    fdist.barrier()
+    dt = fdist.all_reduce_scalars([time.perf_counter() - t0], "cpu", "max")[0]
+    units = fdist.all_reduce_scalars([float(args.scenes * V_OUT * args.steps)], "cpu", "sum")[0]
+    if rank == 0:
+        print(json.dumps({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "views_counted": units, "ms_per_step": dt / args.steps * 1e3,
+                          "scaling": "weak", "config": {"workload": "dry run: no HIP work, launch + rendezvous + reductions only"}}), flush=True)
+    fdist.barrier()
+    fdist.shutdown()
 
 
 def main():
@@ -234,20 +387,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step (BASELINE config 2: 1)")
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step (BASELINE configs[1]: 1, configs[2]: 8)")
+    ap.add_argument("--grid", type=int, default=32, choices=(32, 64),
+                    help="feature grid: 32 = the metric's configuration (64^3 render volume); 64 = BASELINE configs[3]/[4] 128^3-voxel "
+                         "scenes: synthetic [b,5,128,64^3] feature volumes through rotate -> fuse -> heads -> ray-march (the encoder cannot produce them)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--dump-conv", action="store_true", help="print every conv launch of one step (shape, ms, TFLOP/s) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank launch path (no HIP work)")
+    ap.add_argument("--cpu-worker", nargs=3, type=int, metavar=("THREADS", "N", "SEED"), help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(*args.cpu_worker)
+    self_launch(args)
 
-    rank, local_rank, world = fdist.init()
-    fdist.barrier()                                  # create the RCCL communicator before any graph capture
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank, local_rank, world = fdist.env_world()
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launch environment has WORLD_SIZE=%d (run `python bench.py --gpus N` and let it "
+                         "start its own ranks, or pass matching values to torch.distributed.run)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if world > ndev and os.environ.get("FORGE_BENCH_ALLOW_SHARED_GPUS") != "1":
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible - a scaling number from shared devices would be meaningless "
+                         "(set FORGE_BENCH_ALLOW_SHARED_GPUS=1 for a functional rehearsal)" % (world, ndev))
+    dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
     _lib.lib()
 
@@ -262,22 +429,37 @@ def main():
     sample = {k: v.to(dev) for k, v in sample_cpu.items()}      # inputs resident in HBM
     dataset = syn.SyntheticDataset(1.5)
 
-    def eager_step():
-        with torch.no_grad():
-            return model(sample, dataset, dev)
+    if args.grid == 32:
+        def eager_step():
+            with torch.no_grad():
+                return model(sample, dataset, dev)
+    else:
+        # 128^3-voxel scenes: per-view feature volumes [B,5,128,64^3] (671 MB per scene) resident in HBM, GT poses / cameras of the sample
+        from forge_amd import geo_utils
+        gen = torch.Generator(device=dev).manual_seed(77 + rank)
+        feats64 = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+        poses64 = sample["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
+        cams64 = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"][:, :V_OUT], sample["K_cv2"][:, :V_OUT])
 
+        def eager_step():
+            with torch.no_grad():
+                return model.reconstruct(feats64, poses64, cams64)[:2]
+
+    # hipGraph capture happens BEFORE the process group exists: no RCCL communicator / watchdog thread is alive while the stream is
+    # capturing, so the capture cannot be invalidated by collective-library activity; the barrier / all-reduce below never run inside it.
+    graphed = None
     if args.no_graph:
         step = eager_step
-    else:
+    elif args.grid == 32:
         from forge_amd.graph import GraphedForward
-        try:
-            graphed = GraphedForward(model, sample, dataset, dev)  # hipGraph of the whole step; replays do all the work
-            step = lambda: graphed(sample)                          # noqa: E731  (copies the resident inputs into the static buffers)
-        except RuntimeError as e:                                   # capture refused (e.g. by a collective library thread): same kernels, eager launch
-            print("bench.py: hipGraph capture failed on rank %d (%s); launching eagerly" % (rank, str(e).splitlines()[0]), file=sys.stderr)
-            args.no_graph = True
-            torch.cuda.synchronize()
-            step = eager_step
+        graphed = GraphedForward(model, sample, dataset, dev)      # hipGraph of the whole step; replays do all the work
+        step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the static buffers)
+    else:
+        from forge_amd.graph import GraphedCall
+        step = GraphedCall(eager_step, dev)
+
+    fdist.init()                                                    # RCCL (backend "nccl") over xGMI when world > 1
+    fdist.barrier()
 
     for _ in range(args.warmup):
         out = step()
@@ -292,13 +474,19 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
-    views = world * B * V_OUT * args.steps
+    # the one exchange of the inference path: (SSE to the target views, pixel count, views rendered) summed over ranks
+    # (RCCL all-reduce, 3 doubles) -> whole-job PSNR / view count
+    tgt_dev = sample["images"][:, :V_OUT].reshape(B * V_OUT, 3, 256, 256)
+    sse_local = float(((out[0] - tgt_dev) ** 2).sum())
+    sse, npix, views_per_step = fdist.all_reduce_scalars([sse_local, float(tgt_dev.numel()), float(B * V_OUT)], dev, "sum")
+    assert int(views_per_step) == world * B * V_OUT
+    views = int(views_per_step) * args.steps
 
     # ---- the same steps with the sample handed over as (pinned) HOST buffers, as a DataLoader would: PCIe-inclusive rate (never `value`)
     pcie_views_per_s = None
     if rank == 0 and world == 1:
         host = {k: v.pin_memory() for k, v in sample_cpu.items()}
-        feed = (lambda: graphed(host)) if not args.no_graph else None
+        feed = (lambda: graphed(host)) if graphed is not None else None
         if feed is not None:
             feed()
             torch.cuda.synchronize()
@@ -325,12 +513,13 @@ def main():
             for x in v:
                 ms = x[0].elapsed_time(x[1])
                 print("%-34s M=%-7d N=%-5d taps=%-3d Cin=%-5d %.4f ms  %.1f TF" % ((k,) + x[3] + (ms, x[2] / ms / 1e9)), file=sys.stderr)
-    stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages.get("encoder_resnet", 0.0)
+    if "encoder_total" in stages:
+        stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages.get("encoder_resnet", 0.0)
     stages["render_march(+cam pack)"] = stages.pop("render_total") - stages.get("conv_rgb", 0.0)
 
     result = None
     if rank == 0:
-        kern = {} if args.no_microbench else kernel_rooflines(dev, B)
+        kern = {} if args.no_microbench else kernel_rooflines(dev, B, args.grid)
         # dominant kernel of the step: conv_igemm_kernel<BM, BN, waves> - ONE kernel (csrc/conv_igemm.hip) whose tile shape is picked per
         # launch by the plan model, so rocprofv3 lists it under several instantiation names; together they are ~95 % of the step.
         # achieved = sum of the ALGORITHMIC FLOPs of all its launches in one step / sum of their HIP-event durations. The
@@ -352,20 +541,33 @@ def main():
                     "note": "durations are HIP events around each launch on the launch stream in an eager (non-graph) pass, so each includes "
                             "the host launch gap (and, for split-K launches, the reduction kernel); traffic is the PMC pass of the "
                             "ConvGRU-gates launch of the 128x128 instantiation"}
+        if args.grid == 32:
+            metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
+            workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
+                        "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
+                        "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
+                        "eval BN, random-init seeded weights" % (1 if B == 1 else 2, B))
+            gflop = B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB)
+        else:
+            metric = "rendered views/sec (5 views, 128^2 px, 128^3 voxel)"
+            workload = ("BASELINE configs[3]/[4] grid (synthetic up-scale, SURVEY.md 8d): %d scene(s)/GPU x 5 synthetic feature volumes "
+                        "[128,64^3] resident in HBM (the encoder cannot produce them from 256^2 images, models/encoder.py:49) -> HIP rotate at "
+                        "D=64 (1.07 GB/scene) -> ConvGRU fusion at M=262144 -> heads -> 128^3 x 17 render volume (142.6 MB) -> 5 views x "
+                        "128^2 rays x 64 samples -> conv_rgb -> 5 RGB 256^2; eval BN, random-init seeded weights" % B)
+            gflop = B * (8 * (GF_FUSE + GF_HEADS) + GF_CONVRGB)
         result = {
-            "metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": views / dt, "unit": "views/s",
+            "metric": metric, "value": views / dt, "unit": "views/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
-                                   "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
-                                   "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
-                                   "eval BN, random-init seeded weights" % B,
-                       "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "launch": "eager" if args.no_graph else "hipGraph replay", "parallelism": "dp%d (scene-sharded, no data-path collective)" % world},
+            "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
+                       "render_grid": 2 * args.grid, "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "parallelism": "dp%d (scene-sharded, no data-path collective; 3-scalar RCCL all-reduce of SSE/pixels/views for the PSNR report)" % world},
             "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
-            "gflop_per_step_algorithmic": B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB),
+            "gflop_per_step_algorithmic": gflop,
             "views_per_s_with_host_to_device_copy": pcie_views_per_s,
+            "psnr_to_target_db_all_ranks": fdist.psnr_from_sse(sse, npix),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.grid == 32:
             cb, ref = cpu_baseline(sample_cpu, weights, cfg)
             result["cpu_baseline"] = cb
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -49,6 +49,14 @@ def all_reduce_scalars(values, device, op="sum"):
     return t.tolist()
 
 
+def all_reduce_mean_(t):
+    """In-place mean over ranks of a small device tensor (loss terms / metrics); identity for a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= dist.get_world_size()
+    return t
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

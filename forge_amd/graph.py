@@ -44,6 +44,28 @@ class GraphedForward:
         return self.static_out
 
 
+class GraphedCall:
+    """hipGraph capture of an arbitrary fixed-shape, capture-safe inference callable `fn()` whose inputs are tensors the caller keeps
+    alive and overwrites in place between replays (e.g. FORGE.reconstruct on resident feature volumes). g = GraphedCall(fn, device);
+    out = g() replays and returns the static outputs."""
+
+    def __init__(self, fn, device, warmup=3):
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.static_out = fn()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.static_out
+
+
 class GraphedStep:
     """hipGraph capture of a whole fixed-shape optimisation step: `step_fn()` must run forward, loss, backward and the optimizer step on
     STATIC tensors (inputs that are overwritten in place between replays, parameters, a `capturable=True` optimizer) and return the

@@ -13,10 +13,13 @@ import torch.nn.functional as F
 
 
 def _publish(losses, terms):
-    """one D2H copy for all logged scalars"""
+    """Logged scalars: the loss terms of all ranks averaged by ONE all-reduce of the stacked vector (RCCL over xGMI when the job is
+    data-parallel; north_star "RCCL all-reduce of losses" - the reference logs rank 0's local values only), then one D2H copy.
+    The gradients are not touched: DDP averages those."""
     if terms:
-        vals = torch.stack([v.detach() for v in terms.values()]).cpu().tolist()
-        losses.update(dict(zip(terms.keys(), vals)))
+        from . import dist as fdist
+        vec = fdist.all_reduce_mean_(torch.stack([v.detach() for v in terms.values()]))
+        losses.update(dict(zip(terms.keys(), vec.cpu().tolist())))
     return losses
 
 

@@ -111,3 +111,49 @@ def test_ray_sharded_render_world2():
     for rank, errs, shapes in res:
         assert shapes == [(3, 4, 16, 16), (3, 1, 16, 16), (3, 1, 16, 16)]
         assert max(errs) < 1e-6
+
+
+def test_bench_entry_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 8` (no torchrun environment) must start 8 ranks itself and report n_gpus: 8 - here as the
+    CPU/gloo rehearsal of exactly that entry (`--dry-run`: launch, rendezvous on 127.0.0.1, barrier, MAX / SUM reductions, one JSON
+    line from rank 0) - and must FAIL when the launch environment's world size contradicts --gpus."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["views_counted"] == 8 * 2 * 5 * 3 and d["steps"] == 3
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def _loss_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from forge_amd import dist as fd, train
+    fd.init(backend="gloo")
+    terms = {"recon_img": torch.tensor(1.0 + rank), "recon_mask": torch.tensor(10.0 * (rank + 1))}
+    q.put((rank, train._publish({}, terms)))
+    fd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_logged_losses_are_all_reduced_world2():
+    """train._publish averages the loss terms over ranks with one all-reduce (north_star: all-reduce of losses)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r] == {"recon_img": pytest.approx(1.5), "recon_mask": pytest.approx(15.0)}

@@ -245,8 +245,38 @@ def _cpu_forward_fn(seed, threads):
     return run
 
 
+def core_sets(nsets, per_set):
+    """nsets disjoint sets of per_set logical CPUs, one hardware thread per physical core, consecutive cores of one socket together."""
+    cores, phys, core, proc = {}, None, None, None
+    try:
+        allowed = os.sched_getaffinity(0)
+        for line in list(open("/proc/cpuinfo")) + [""]:
+            if line.startswith("processor"):
+                proc = int(line.split(":")[1])
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+            elif not line.strip():
+                if proc is not None and proc in allowed and phys is not None:
+                    cores.setdefault((phys, core), proc)
+                phys = core = proc = None
+    except Exception:
+        return None
+    order = [cores[k] for k in sorted(cores)]
+    if len(order) < nsets * per_set:
+        return None
+    return [order[i * per_set:(i + 1) * per_set] for i in range(nsets)]
+
+
 def cpu_worker(threads, n_forward, seed):
-    """`bench.py --cpu-worker THREADS N SEED`: one process of the scene-parallel CPU baseline. Prints 'CPUWORKER t_start t_end n'."""
+    """`bench.py --cpu-worker THREADS N SEED`: one process of the scene-parallel CPU baseline (pinned to FORGE_CPU_SET, a comma list of
+    logical CPUs, when given). Prints 'CPUWORKER t_start t_end n'."""
+    if os.environ.get("FORGE_CPU_SET"):
+        try:
+            os.sched_setaffinity(0, {int(c) for c in os.environ["FORGE_CPU_SET"].split(",")})
+        except Exception:
+            pass
     run = _cpu_forward_fn(seed, threads)
     run()                                            # warm-up (allocator, oneDNN primitive caches)
     print("CPUWORKER_READY", flush=True)
@@ -304,9 +334,11 @@ def cpu_baseline(sample, weights, cfg):
     nfw = 2
     par = None
     try:
+        sets = core_sets(nproc, tpp)                 # each process pinned to its own 16 physical cores (one socket, no SMT siblings)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(tpp), str(nfw), str(2000 + i)],
                                   stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                                  env=dict(os.environ, OMP_NUM_THREADS=str(tpp), MKL_NUM_THREADS=str(tpp))) for i in range(nproc)]
+                                  env=dict(os.environ, OMP_NUM_THREADS=str(tpp), MKL_NUM_THREADS=str(tpp), OMP_PROC_BIND="close",
+                                           FORGE_CPU_SET=",".join(map(str, sets[i])) if sets else "")) for i in range(nproc)]
         for p in procs:
             while True:
                 line = p.stdout.readline()
@@ -324,7 +356,7 @@ def cpu_baseline(sample, weights, cfg):
                     spans.append((float(a), float(b), int(n)))
         if len(spans) == nproc:
             wall = max(b for _, b, _ in spans) - min(a for a, _, _ in spans)
-            par = {"processes": nproc, "threads_per_process": tpp, "timed_forwards": nproc * nfw, "wall_s": wall,
+            par = {"processes": nproc, "threads_per_process": tpp, "pinned": bool(sets), "timed_forwards": nproc * nfw, "wall_s": wall,
                    "views_per_s": V_OUT * sum(n for _, _, n in spans) / wall}
     except Exception as e:                                              # the single-process number stands
         par = {"error": repr(e)}

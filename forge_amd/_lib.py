@@ -26,16 +26,17 @@ SIGNATURES = {
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
-    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 10 + [_P, _LL, _P],
-    "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _P, _P],
+    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 11 + [_P, _LL, _P],
+    "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
     "forge_conv_wgrad": [_P, _I, _P, _I, _I, _LL, _P, _I, _I, _LL, _P] + [_I] * 9 + [_P, _I, _P],
     "forge_conv_direct_fwd": [_P, _I, _P, _P, _F, _P, _I] + [_I] * 6 + [_P, _I, _P],
     "forge_conv_direct_dgrad": [_P, _I, _P, _P, _I] + [_I] * 6 + [_P, _I, _P],
     "forge_conv_direct_wgrad": [_P, _I, _P, _I, _P] + [_I] * 6 + [_P, _I, _P],
     "forge_gru_gates_fwd": [_P, _P, _P, _P, _P, _LL, _I, _P],
     "forge_gru_state_fwd": [_P, _P, _P, _P, _LL, _I, _P],
-    "forge_gru_state_bwd": [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _P],
-    "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _LL, _I, _P],
+    "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P],
+    "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P],
+    "forge_affine_act_bwd": [_P, _I, _P, _I, _P, _F, _P, _I, _LL, _I, _P],
     "forge_im2col_nchw": [_P, _P] + [_I] * 9 + [_P],
     "forge_maxpool2d_nhwc": [_P, _P] + [_I] * 7 + [_P],
     "forge_ncdhw_to_ndhwc": [_P, _P, _I, _I, _LL, _P],

@@ -36,7 +36,7 @@ def resume_training(model, optimizer, output_dir, cpt_name="cpt_last.pth.tar", s
     ckpt, sd = _read(os.path.join(output_dir, cpt_name), device)
     missing = set(model.state_dict().keys()) - set(sd.keys())
     if missing:
-        warnings.warn("Missing keys ! : {}".format(sorted(missing)))
+        warnings.warn("checkpoint lacks %d of the model's tensors, e.g. %s" % (len(missing), sorted(missing)[:4]))
     model.load_state_dict(sd, strict=strict)
     if optimizer is not None and "optimizer" in ckpt:
         optimizer.load_state_dict(ckpt["optimizer"])

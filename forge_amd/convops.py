@@ -153,11 +153,30 @@ SPLITK_WS_BYTES = 128 << 20
 
 
 def _splitk_workspace(device):
-    """Per-device scratch for forge_conv_igemm's split-K mode (allocated once, outside any graph capture by the warm-up passes)."""
-    ws = _SPLITK_WS.get(device)
+    """Scratch for forge_conv_igemm's split-K mode, one per (device, stream): launches on different streams may run concurrently and
+    must not share partial-sum storage (allocated once per stream, outside any graph capture by the warm-up passes)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[device] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
+        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
     return ws
+
+
+_CU_BUDGET = [0]
+
+
+class cu_budget:
+    """`with convops.cu_budget(n):` - the conv launches inside plan for n CUs instead of the whole chip (they run concurrently with
+    launches on other streams; forge_conv_igemm's cu_budget argument)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev, _CU_BUDGET[0] = _CU_BUDGET[0], self.n
+
+    def __exit__(self, *exc):
+        _CU_BUDGET[0] = self.prev
 
 
 TILE_NAMES = {"A": "128, 128, 8", "B": "64, 128, 8", "C": "128, 64, 8", "D": "64, 64, 4", "E": "128, 32, 4"}
@@ -169,7 +188,7 @@ def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
     import ctypes
     tile, ks = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
-                                                ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
+                                                _CU_BUDGET[0], ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
     return chr(tile.value), ks.value
 
 
@@ -179,7 +198,7 @@ MAX_OPERAND_BYTES = (1 << 31) - 1       # 32-bit buffer offsets of the kernel's 
 @_lib.on_tensor_device
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
-               bs1=0, bs2=0, lift=0):
+               bs1=0, bs2=0, lift=0, out3=None):
     """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid).
     The kernel addresses its gathered operands through 32-bit buffer offsets (< 2 GiB per operand); batches whose inputs span more
     (e.g. 32 scenes of 64^3 x 64-channel head activations) are launched in batch chunks here."""
@@ -208,8 +227,9 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
         _lib.check(L.forge_conv_igemm(
             off(in1, s0 * b1 * ld1), C1, ld1, int(bs1), off(in2, s0 * b2 * ld2), C2, ld2, int(bs2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(scale),
             _lib.ptr(shift), float(slope), off(residual, orow * (Cout if lift else ldo)), off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
-            off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo, arr, len(taps), ostride,
-            phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st), "forge_conv_igemm")
+            off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
+            arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _CU_BUDGET[0], _lib.ptr(ws), SPLITK_WS_BYTES, st),
+            "forge_conv_igemm")
     return out
 
 
@@ -488,3 +508,31 @@ def conv2d_rows_any(x, weight, bias):
     else:
         raise ValueError("conv2d_rows_any: Cin=%d Cout=%d is not a narrow layer; use conv2d_rows" % (ci_, co_))
     return y.reshape(N, H, W, co_)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# frozen-weight data gradients (pose refinement): helpers shared by the heads / conv_rgb backward of the fused inference path
+# ------------------------------------------------------------------------------------------------------------------
+def narrow_dgrad(dy16, wT16, dx, grid, taps):
+    """Data gradient of a stride-1 'same' convolution with Cout <= 16 on the narrow-N kernel: dy16 [.., 16] (Cout zero-padded to the
+    16-wide K-step), wT16 [T][Cin][16] (transposed, padded packed weights), dx [.., ld] receives Cin columns in 16-column blocks."""
+    Cin = wT16.shape[1]
+    ntaps = [(-a, -b, -c) for a, b, c in taps]
+    n, D, H, W = grid
+    for j in range(0, Cin, 16):
+        nb = min(16, Cin - j)
+        conv_igemm(dy16, 16, 16, None, 0, 0, wT16[:, j:j + nb].contiguous(), None, None, None, 1.0, None, None, None, dx[..., j:], None,
+                   (n, D, H, W), (D, H, W), nb, dx.stride(-2), ntaps, epilogue=EPI_BIAS)
+    return dx
+
+
+def pad_last(w, k):
+    """zero-pad the last dim of a packed weight to k"""
+    return w if w.shape[-1] == k else torch.nn.functional.pad(w, (0, k - w.shape[-1]))
+
+
+def direct_dgrad(dy, wp, dx, grid, Cin, Cout, taps):
+    n, D, H, W = grid
+    _lib.check(_lib.lib().forge_conv_direct_dgrad(_lib.ptr(dy), Cout, _lib.ptr(wp), _lib.ptr(dx), Cin, n, D, H, W, Cin, Cout, _taps_array(taps), len(taps),
+                                                  _lib.current_stream()), "forge_conv_direct_dgrad")
+    return dx

@@ -51,7 +51,7 @@ struct ConvArgs {
     const float* bias;                     // [Cout] nullable
     const float* scale; const float* shift; float slope;
     const float* aux_h; const float* aux_z;
-    float* out; float* out2;
+    float* out; float* out2; float* out3;   // out3 (nullable): GRU gates -> reset gate r; GRU out -> cand = tanh(v)  (saved for a hand-written backward)
     int n, D, H, W;                        // GEMM-row grid (M = n D H W rows)
     int is, Di, Hi, Wi;                    // input voxel = (z is + dz, y is + dy, x is + dx) in an (n,Di,Hi,Wi) grid
     const float* residual; int ldr;        // EPI_AFFINE_ACT: added before the activation (nullable), [rows][ldr]
@@ -61,6 +61,7 @@ struct ConvArgs {
     int nphase, tpp;                       // > 1: all output phases of a stride-2 transposed conv in ONE launch: phase p = (pz,py,px) bits uses taps [p tpp, (p+1) tpp)
     int epi;
     int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
+    int prio;                              // 1: static wave priority by dispatch round, see conv_igemm_kernel
     float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
@@ -98,6 +99,18 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int ntile_n = (a.Cout + BN - 1) / BN;
+    // Static issue priority by dispatch round. The workgroups sharing a CU run the same instruction stream; with equal priority they
+    // alternate on each SIMD's matrix pipe, advance in lock-step and reach their per-K-step barriers TOGETHER - the pipe then idles for the
+    // barrier + LDS-read latency of every step (81 % MFMA-busy in round 1). Workgroups of consecutive dispatch rounds (blockIdx / 256:
+    // one per CU per round) get different priorities, so one races ahead while the other fills its stalls and the phases stay apart.
+    if (a.prio) {
+        switch ((blockIdx.x >> 8) & 3) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            default: break;
+        }
+    }
     const unsigned bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = (int)(bid_all % (unsigned)a.ksplit);           // K-slice of this workgroup (split-K for small M x N problems)
     unsigned bid = bid_all / (unsigned)a.ksplit;
@@ -129,13 +142,16 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
         ar[j] = (tid >> 3) + RPP * j;
-        long long v = m0 + ar[j];
-        aval[j] = v < M;
-        v = aval[j] ? v : 0;
-        ax[j] = (int)(v % a.W) * a.is; v /= a.W;
-        ay[j] = (int)(v % a.H) * a.is; v /= a.H;
-        az[j] = (int)(v % a.D) * a.is; v /= a.D;
-        an[j] = (int)v;
+        const long long vl = m0 + ar[j];
+        aval[j] = vl < M;
+        unsigned v = aval[j] ? (unsigned)vl : 0u;                // M < 2^31 (checked on the host): 32-bit divisions (64-bit ones are ~100 instructions each)
+        unsigned q = v / (unsigned)a.W;
+        ax[j] = (int)(v - q * (unsigned)a.W) * a.is; v = q;
+        q = v / (unsigned)a.H;
+        ay[j] = (int)(v - q * (unsigned)a.H) * a.is; v = q;
+        q = v / (unsigned)a.D;
+        az[j] = (int)(v - q * (unsigned)a.D) * a.is;
+        an[j] = (int)q;
         asrc[j] = (cp ^ ((ar[j] >> 1) & 7)) << 2;                // logical channel offset inside the 32-chunk
     }
     int br[BCH]; unsigned boff[BCH];
@@ -288,9 +304,34 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    // (fully unrolled per epilogue kind: the accumulators must stay in registers)
+    // The output-row mapping (identity, strided / phase remap of a transposed convolution, or the 2D->3D lift) is computed ONCE per
+    // tile row by one thread (32-bit divisions) into an LDS table; the fully unrolled per-accumulator code below (the accumulators
+    // must stay in registers) then holds no division and no remap branch. (Round 1 inlined three 64-bit divisions per accumulator
+    // element: 45-90 k instructions per instantiation, far beyond the instruction cache, which cost every workgroup a chain of
+    // instruction-fetch misses - the reason 2 us of MFMA work took 20 us per launch in the ResNet trunk.)
     const int Ch = a.Cout / 2;
     const bool remap = (a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W);
+    long long* s_row = reinterpret_cast<long long*>(smem);          // [BM] output row (or lifted base offset) of each tile row, -1 = beyond M
+    if (a.ksplit == 1 && tid < BM) {
+        const long long m = m0 + tid;
+        long long o = -1;
+        if (m < M) {
+            if (a.lift > 0) {                                        // row (n, hw) -> base of out[n][0][hw][0] in the [n][lift][HW][Cl] volume
+                const unsigned HW = (unsigned)(a.H * a.W), nn = (unsigned)m / HW, hw = (unsigned)m - nn * HW;
+                o = ((long long)nn * a.lift * HW + hw) * (a.Cout / a.lift);
+            } else if (remap) {
+                unsigned q = (unsigned)m, t2 = q / (unsigned)a.W;
+                const int x = (int)(q - t2 * (unsigned)a.W); q = t2; t2 = q / (unsigned)a.H;
+                const int y = (int)(q - t2 * (unsigned)a.H); q = t2; t2 = q / (unsigned)a.D;
+                const int z = (int)(q - t2 * (unsigned)a.D);
+                o = (((long long)t2 * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
+            } else {
+                o = m;
+            }
+        }
+        s_row[tid] = o;
+    }
+    __syncthreads();
     auto epilogue = [&](auto EPI_TAG) {
         constexpr int EPI = decltype(EPI_TAG)::value;
 #pragma unroll
@@ -301,45 +342,46 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             const float bias = a.bias ? a.bias[colc] : 0.f;
             float sc = 1.f, sh = 0.f;
             if ((EPI == EPI_AFFINE_ACT || (EPI == EPI_GRU_OUT && a.out2)) && a.scale) { sc = a.scale[colc]; sh = a.shift[colc]; }
+            long long liftoff = 0;
+            if (EPI == EPI_AFFINE_ACT && a.lift > 0) {               // column (z, c), c fastest -> + z HW Cl + c
+                const int Cl = a.Cout / a.lift, zc = colc / Cl;
+                liftoff = (long long)zc * a.H * a.W * Cl + (colc - zc * Cl);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long long m = m0 + wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int rl = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const long long orow = s_row[rl];
                     float v = acc[i][j][r] + bias;
-                    if (cok && m < M) {
-                        long long orow = m;
-                        if (remap) {
-                            long long q = m;
-                            const int x = (int)(q % a.W); q /= a.W;
-                            const int y = (int)(q % a.H); q /= a.H;
-                            const int z = (int)(q % a.D); q /= a.D;
-                            orow = ((q * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
-                        }
+                    if (cok && orow >= 0) {
                         if constexpr (EPI == EPI_BIAS) {
                             a.out[orow * a.ldo + col] = v;
                         } else if constexpr (EPI == EPI_AFFINE_ACT) {
                             v = fmaf(v, sc, sh);
-                            if (a.residual) v += a.residual[orow * a.ldr + col];
-                            v = v > 0.f ? v : v * a.slope;
                             if (a.lift > 0) {
-                                // columns are (z, c) with c fastest: row (n, hw), col z*Cl + c  ->  out[n][z][hw][c]
-                                const int Cl = a.Cout / a.lift, zc = col / Cl, cc = col - zc * Cl;
-                                const long long HW = (long long)a.H * a.W, nn = m / HW, hw = m - nn * HW;
-                                a.out[((nn * a.lift + zc) * HW + hw) * Cl + cc] = v;
+                                if (a.residual) v += a.residual[(m0 + rl) * a.ldr + col];      // residual rows are the un-lifted GEMM rows
+                                v = v > 0.f ? v : v * a.slope;
+                                a.out[orow + liftoff] = v;
                             } else {
+                                if (a.residual) v += a.residual[orow * a.ldr + col];
+                                v = v > 0.f ? v : v * a.slope;
                                 a.out[orow * a.ldo + col] = v;
                             }
                         } else if constexpr (EPI == EPI_GRU_GATES) {
                             const float g = 1.f / (1.f + __expf(-v));
                             if (col < Ch) a.out[orow * Ch + col] = g;
-                            else a.out2[orow * Ch + (col - Ch)] = a.aux_h[orow * Ch + (col - Ch)] * g;
+                            else {
+                                a.out2[orow * Ch + (col - Ch)] = a.aux_h[orow * Ch + (col - Ch)] * g;
+                                if (a.out3) a.out3[orow * Ch + (col - Ch)] = g;
+                            }
                         } else {   // EPI_GRU_OUT
                             const float cand = tanhf(v);
                             const float z = a.aux_z[orow * a.Cout + col], h = a.aux_h[orow * a.Cout + col];
                             const float hn = h * (1.f - z) + cand * z;
                             a.out[orow * a.ldo + col] = hn;
                             if (a.out2) a.out2[orow * a.ldo + col] = fmaf(hn, sc, sh);
+                            if (a.out3) a.out3[orow * a.ldo + col] = cand;
                         }
                     }
                 }
@@ -457,13 +499,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         ar[j] = (tid >> 2) + 128 * j;
-        long long v = m0 + ar[j];
-        aval[j] = v < M;
-        v = aval[j] ? v : 0;
-        ax[j] = (int)(v % a.W) * a.is; v /= a.W;
-        ay[j] = (int)(v % a.H) * a.is; v /= a.H;
-        az[j] = (int)(v % a.D) * a.is; v /= a.D;
-        an[j] = (int)v;
+        const long long vl = m0 + ar[j];
+        aval[j] = vl < M;
+        unsigned v = aval[j] ? (unsigned)vl : 0u;
+        unsigned q = v / (unsigned)a.W;
+        ax[j] = (int)(v - q * (unsigned)a.W) * a.is; v = q;
+        q = v / (unsigned)a.H;
+        ay[j] = (int)(v - q * (unsigned)a.H) * a.is; v = q;
+        q = v / (unsigned)a.D;
+        az[j] = (int)(v - q * (unsigned)a.D) * a.is;
+        an[j] = (int)q;
         asrc[j] = (cp ^ ((4 - ((ar[j] >> 2) & 3)) & 3)) << 2;
     }
     const int brow = tid >> 2;                                   // threads 0..63 stage the 16 x 16 weight tile
@@ -538,26 +583,38 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
     }
 
     // ---- epilogue (bias / folded-BN + LeakyReLU + residual only). 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+    // output rows through an LDS table (one 32-bit decomposition per tile row), as in conv_igemm_kernel
+    long long* s_row = reinterpret_cast<long long*>(smem);          // [BM16]
+    {
+        const bool remap = (a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W);
+        if (tid < BM16) {
+            const long long m = m0 + tid;
+            long long o = -1;
+            if (m < M) {
+                o = m;
+                if (remap) {
+                    unsigned q = (unsigned)m, t2 = q / (unsigned)a.W;
+                    const int x = (int)(q - t2 * (unsigned)a.W); q = t2; t2 = q / (unsigned)a.H;
+                    const int y = (int)(q - t2 * (unsigned)a.H); q = t2; t2 = q / (unsigned)a.D;
+                    const int z = (int)(q - t2 * (unsigned)a.D);
+                    o = (((long long)t2 * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
+                }
+            }
+            s_row[tid] = o;
+        }
+        __syncthreads();
+    }
     const int col = l15;
     if (col < a.Cout) {
         const float bias = a.bias ? a.bias[col] : 0.f;
         float sc = 1.f, sh = 0.f;
         if (a.epi == EPI_AFFINE_ACT) { sc = a.scale[col]; sh = a.shift[col]; }
-        const bool remap = (a.os != 1) || (a.Do != a.D) || (a.Ho != a.H) || (a.Wo != a.W);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long long m = m0 + wave * 32 + i * 16 + kq * 4 + r;
-                if (m < M) {
-                    long long orow = m;
-                    if (remap) {
-                        long long q = m;
-                        const int x = (int)(q % a.W); q /= a.W;
-                        const int y = (int)(q % a.H); q /= a.H;
-                        const int z = (int)(q % a.D); q /= a.D;
-                        orow = ((q * a.Do + (z * a.os + pz)) * a.Ho + (y * a.os + py)) * a.Wo + (x * a.os + px);
-                    }
+                const long long orow = s_row[wave * 32 + i * 16 + kq * 4 + r];
+                if (orow >= 0) {
                     float v = acc[i][r] + bias;
                     if (a.epi == EPI_AFFINE_ACT) {
                         v = fmaf(v, sc, sh);
@@ -585,7 +642,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 // per-shape best in total. FORGE_CONV_TILE=A..E / FORGE_CONV_KSPLIT=n override the model (that tool).
 struct ConvPlan { char tile; int ksplit; };
 
-static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes) {
+static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes, int cu_budget = 0) {
+    const long long CUS = (cu_budget > 0 && cu_budget < 256) ? cu_budget : 256;   // CUs this launch can count on (concurrent launches on other streams share the chip)
     struct Tile { char id; int bm, bn, occ; double eff, ov; };
     static const Tile tiles[5] = {{'A', 128, 128, 2, 1.000, 4.0}, {'B', 64, 128, 3, 0.983, 1.0}, {'C', 128, 64, 3, 0.969, 1.0},
                                   {'D', 64, 64, 5, 0.980, 1.0}, {'E', 128, 32, 4, 0.915, 1.0}};
@@ -605,20 +663,20 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
         for (int k : splits) {
             if (fk && atoi(fk) != k) continue;
             if (k > 1 && (!can_split || nsteps / k < 8 || (long long)k * M * Cout * 4 > ws_bytes)) continue;
-            const long long wgs = nb * k, slots = 256LL * t.occ;
+            const long long wgs = nb * k, slots = CUS * t.occ;
             const long long full = wgs / slots, rem = wgs - full * slots;
-            const double tile_us = (double)t.bm * t.bn * ((nsteps + k - 1) / k) / (8000.0 * t.eff);
+            const double tile_us = (double)t.bm * t.bn * ((nsteps + k - 1) / k) / (8000.0 * t.eff);     // per-CU rate: independent of the budget
             double us = (double)full * t.occ * tile_us;
             long long rounds = full;
             if (rem > 0) {
-                const long long r = (rem + 255) / 256;
+                const long long r = (rem + CUS - 1) / CUS;
                 us += (double)r * tile_us * g(t.occ) / g(r);
                 ++rounds;
             }
-            const double traffic_us = ((double)M * K * 4.0 * ntn + (double)Cout * K * 4.0 + (double)M * Cout * 4.0) / 4.0e6;
+            const double traffic_us = ((double)M * K * 4.0 * ntn + (double)Cout * K * 4.0 + (double)M * Cout * 4.0) / (4.0e6 * CUS / 256.0);
             if (us < traffic_us) us = traffic_us;
             us += (double)(rounds + 1) * t.ov * sqrt((double)t.bm * t.bn / 16384.0);
-            if (k > 1) us += 3.0 + (double)(k + 1) * M * Cout * 4.0 / 2.0e6;
+            if (k > 1) us += 3.0 + (double)(k + 1) * M * Cout * 4.0 / (2.0e6 * CUS / 256.0);
             if (us < best_us) { best_us = us; best = ConvPlan{t.id, k}; }
         }
     }
@@ -630,13 +688,13 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
 using namespace forge;
 
 extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
-                                     int* tile, int* ksplit) {
+                                     int cu_budget, int* tile, int* ksplit) {
     FORGE_REQUIRE(tile && ksplit && M > 0 && Cout > 0 && Cin > 0 && ntaps > 0 && (nphase == 1 || nphase == 4 || nphase == 8) && ntaps % nphase == 0,
                   FORGE_EINVAL, "forge_conv_igemm_plan: bad argument");
     if (Cout <= 16) { *tile = 'N'; *ksplit = 1; return 0; }                         // conv_igemm_n16_kernel
     const ConvPlan pl = plan_conv(M * nphase, Cout, Cin, ntaps / nphase,
                                   nphase == 1 && splitk_ws_bytes > 0 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
-                                  splitk_ws_bytes);
+                                  splitk_ws_bytes, cu_budget);
     *tile = pl.tile; *ksplit = pl.ksplit;
     return 0;
 }
@@ -645,10 +703,10 @@ extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, 
 extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
                                 const float* wp,
                                 const float* bias, const float* scale, const float* shift, float slope, const float* residual,
-                                const float* aux_h, const float* aux_z, float* out, float* out2,
+                                const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
+                                int epilogue, int lift, int cu_budget, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
@@ -672,9 +730,10 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
                   "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
-    a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
+    a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.out3 = out3; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     a.nphase = 1; a.tpp = ntaps;
+    { const char* pe = getenv("FORGE_CONV_PRIO"); a.prio = pe ? atoi(pe) : 0; }
     if (pz < 0) {   // all output phases of a stride-2 transposed convolution in one launch
         FORGE_REQUIRE(os == 2 && py < 0 && px < 0 && Ho == 2 * H && Wo == 2 * W && (Do == 2 * D || Do == D), FORGE_EINVAL,
                       "forge_conv_igemm: merged phases (pz = py = px = -1) need os = 2 and a doubled output grid");
@@ -688,6 +747,8 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         a.tap[t][3] = 0;
     }
     const long long M = (long long)n * D * H * W;
+    FORGE_REQUIRE(M < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: more than 2^31 GEMM rows; split the batch");
+    FORGE_REQUIRE(out3 == nullptr || epilogue == EPI_GRU_GATES || epilogue == EPI_GRU_OUT, FORGE_EINVAL, "forge_conv_igemm: out3 is a GRU-epilogue output");
     hipStream_t st = (hipStream_t)stream;
     if (Cout <= 16) {
         FORGE_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT, FORGE_EINVAL, "forge_conv_igemm: GRU epilogues need Cout > 16");
@@ -697,7 +758,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     } else {
         const ConvPlan pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp,
                                       a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
-                                      splitk_ws_bytes);
+                                      splitk_ws_bytes, cu_budget);
         const char tile = pl.tile;
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };

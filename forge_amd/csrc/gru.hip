@@ -44,11 +44,12 @@ __global__ __launch_bounds__(256) void gru_state_fwd_kernel(float* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void gru_state_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ h, const float* __restrict__ z,
+__global__ __launch_bounds__(256) void gru_state_bwd_kernel(const float* __restrict__ dhn, int ld_dhn, const float* __restrict__ h, const float* __restrict__ z,
                                                             const float* __restrict__ cand, float* __restrict__ dh, float* __restrict__ dz,
-                                                            float* __restrict__ dc, long long n4) {
+                                                            float* __restrict__ dc, long long n4, int C4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 g = reinterpret_cast<const float4*>(dhn)[i], hv = reinterpret_cast<const float4*>(h)[i];
+        const long long m = i / C4;
+        const float4 g = *reinterpret_cast<const float4*>(dhn + m * ld_dhn + ((i - m * C4) << 2)), hv = reinterpret_cast<const float4*>(h)[i];
         const float4 zv = reinterpret_cast<const float4*>(z)[i], t = reinterpret_cast<const float4*>(cand)[i];
         float4 a, b, c;
         a.x = g.x * (1.f - zv.x); a.y = g.y * (1.f - zv.y); a.z = g.z * (1.f - zv.z); a.w = g.w * (1.f - zv.w);
@@ -61,9 +62,9 @@ __global__ __launch_bounds__(256) void gru_state_bwd_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ dhr, int ld_dhr,
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ dz, const float* dhr /* may alias dh_out */, int ld_dhr,
                                                             const float* __restrict__ h, const float* __restrict__ z, const float* __restrict__ r,
-                                                            float* __restrict__ dg, float* __restrict__ dh, long long M, int C) {
+                                                            float* __restrict__ dg, const float* __restrict__ dh, float* dh_out, int ld_dh_out, long long M, int C) {
     const int C4 = C >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
@@ -78,7 +79,20 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restr
         dhv.x = fmaf(dhrv.x, rv.x, dhv.x); dhv.y = fmaf(dhrv.y, rv.y, dhv.y); dhv.z = fmaf(dhrv.z, rv.z, dhv.z); dhv.w = fmaf(dhrv.w, rv.w, dhv.w);
         *reinterpret_cast<float4*>(dg + m * 2 * C + c) = gz;
         *reinterpret_cast<float4*>(dg + m * 2 * C + C + c) = gr;
-        *reinterpret_cast<float4*>(dh + m * C + c) = dhv;
+        *reinterpret_cast<float4*>(dh_out + m * ld_dh_out + c) = dhv;
+    }
+}
+
+// dx = dy * (y > 0 ? 1 : slope) * scale[c]: backward of the folded eval-BatchNorm + LeakyReLU / ReLU epilogue (y = the forward OUTPUT;
+// its sign is the pre-activation's sign for slope >= 0). dy / dx rows may be strided; scale nullable (= 1).
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y,
+                                                             const float* __restrict__ scale, float slope, float* __restrict__ dx, int ld_dx,
+                                                             long long M, int C) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C; i += (long long)gridDim.x * 256) {
+        const long long m = i / C;
+        const int c = (int)(i - m * C);
+        const float g = dy[m * ld_dy + c] * (scale ? scale[c] : 1.f);
+        dx[m * ld_dx + c] = y[m * ld_y + c] > 0.f ? g : g * slope;
     }
 }
 
@@ -107,21 +121,34 @@ extern "C" int forge_gru_state_fwd(float* c_cand, const float* h, const float* z
     return 0;
 }
 
-extern "C" int forge_gru_state_bwd(const float* dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
+extern "C" int forge_gru_state_bwd(const float* dhn, int ld_dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
                                    long long M, int C, forge_stream_t stream) {
     FORGE_REQUIRE(dhn && h && z && cand && dh && dz && dc, FORGE_EINVAL, "forge_gru_state_bwd: null pointer argument");
-    FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0, FORGE_ESHAPE, "forge_gru_state_bwd: M=%lld C=%d (C must be a multiple of 4)", M, C);
-    hipLaunchKernelGGL(gru_state_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, h, z, cand, dh, dz, dc, M * (C / 4));
+    FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld_dhn >= C && ld_dhn % 4 == 0, FORGE_ESHAPE,
+                  "forge_gru_state_bwd: M=%lld C=%d ld_dhn=%d (multiples of 4, ld_dhn >= C)", M, C, ld_dhn);
+    hipLaunchKernelGGL(gru_state_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ld_dhn, h, z, cand, dh, dz, dc,
+                       M * (C / 4), C / 4);
     FORGE_LAUNCH_CHECK("forge_gru_state_bwd");
     return 0;
 }
 
 extern "C" int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
-                                   float* dg, float* dh, long long M, int C, forge_stream_t stream) {
+                                   float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, forge_stream_t stream) {
     FORGE_REQUIRE(dz && dhr && h && z && r && dg && dh, FORGE_EINVAL, "forge_gru_gates_bwd: null pointer argument");
     FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld_dhr >= C && ld_dhr % 4 == 0, FORGE_ESHAPE,
                   "forge_gru_gates_bwd: M=%lld C=%d ld_dhr=%d (multiples of 4, ld_dhr >= C)", M, C, ld_dhr);
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dz, dhr, ld_dhr, h, z, r, dg, dh, M, C);
+    FORGE_REQUIRE(dh_out == nullptr || (ld_dh_out >= C && ld_dh_out % 4 == 0), FORGE_ESHAPE, "forge_gru_gates_bwd: bad ld_dh_out=%d", ld_dh_out);
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dz, dhr, ld_dhr, h, z, r, dg, dh,
+                       dh_out ? dh_out : dh, dh_out ? ld_dh_out : C, M, C);
     FORGE_LAUNCH_CHECK("forge_gru_gates_bwd");
+    return 0;
+}
+
+extern "C" int forge_affine_act_bwd(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale, float slope, float* dx, int ld_dx,
+                                    long long M, int C, forge_stream_t stream) {
+    FORGE_REQUIRE(dy && y && dx, FORGE_EINVAL, "forge_affine_act_bwd: null pointer argument");
+    FORGE_REQUIRE(M > 0 && C > 0 && ld_dy >= C && ld_y >= C && ld_dx >= C, FORGE_ESHAPE, "forge_affine_act_bwd: M=%lld C=%d ld=%d/%d/%d", M, C, ld_dy, ld_y, ld_dx);
+    hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(ew_grid((M * C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, ld_dy, y, ld_y, scale, slope, dx, ld_dx, M, C);
+    FORGE_LAUNCH_CHECK("forge_affine_act_bwd");
     return 0;
 }

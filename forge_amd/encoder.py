@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, convops as co
-from .fusion import ConvGRU_3D, hip_inference, require_hip_input
+from .fusion import ConvGRU_3D, affine_act_bwd, frozen_eval, hip_inference, require_hip_input
 
 
 class _Bottleneck(nn.Module):
@@ -91,6 +91,52 @@ def load_imagenet_trunk(feature_extraction, state_dict, strict=True):
     return feature_extraction.load_state_dict(out, strict=strict)
 
 
+class _HeadsFrozen(torch.autograd.Function):
+    """Both heads (models/encoder.py:16-34) for frozen weights under autograd (pose refinement): forward = the fused inference launches
+    of Encoder3D._heads_hip (merged transposed convolutions, BatchNorm / activations in the epilogues) keeping the two intermediate
+    activations; backward = data gradients only - activation / BatchNorm-scale masks (forge_affine_act_bwd), the narrow layers on the
+    narrow-N and direct kernels, the transposed convolutions as ONE stride-2 gather GEMM over their 64 taps."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, z, enc):
+        feat, dens, up, d8 = enc._heads_hip(z, "both", keep=True)
+        ctx.enc, ctx.saved, ctx.zshape = enc, (up, d8, dens), z.shape
+        return feat, dens
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dfeat, ddens):
+        enc = ctx.enc
+        up, d8, dens = ctx.saved
+        n, C, D, H, W = ctx.zshape
+        p = enc._heads_packed_T()
+        dev = up.device
+        D2, H2, W2 = 2 * D, 2 * H, 2 * W
+        g2 = (n, D2, H2, W2)
+        M2 = n * D2 * H2 * W2
+        rows = lambda t_: (lambda r_: r_ if r_.is_contiguous() else r_.contiguous())(t_.permute(0, 2, 3, 4, 1))
+        dup = torch.empty(n, D2, H2, W2, 64, dtype=torch.float32, device=dev)
+        # features head: Conv3d(32,16)+BN  (no activation)
+        gf = affine_act_bwd(rows(dfeat), rows(dfeat), p["f4_scale"], 1.0)
+        co.narrow_dgrad(gf, p["f3_wT"], dup[..., :32], g2, co.TAPS_3x3x3)
+        # density head: Conv3d(8,1)+ReLU <- Conv3d(32,8)+BN+LReLU
+        drows, densr = rows(ddens), dens.permute(0, 2, 3, 4, 1)
+        gd = affine_act_bwd(drows, densr, None, 0.0)
+        dd8 = torch.empty(n, D2, H2, W2, 8, dtype=torch.float32, device=dev)
+        co.direct_dgrad(gd, p["d6_w"], dd8, g2, 8, 1, co.TAPS_3x3x3)
+        gd16 = torch.zeros(n, D2, H2, W2, 16, dtype=torch.float32, device=dev)
+        affine_act_bwd(dd8, d8, p["d4_scale"], 0.01, out=gd16[..., :8])
+        co.narrow_dgrad(gd16, p["d3_wT"], dup[..., 32:], g2, co.TAPS_3x3x3)
+        # both transposed convolutions (+BN+LReLU) at once: dz[v] = sum_k g[2v - 1 + k] W[:, :, k]
+        gu = affine_act_bwd(dup, up, p["ct_scale"], 0.01)
+        dz = torch.empty(n, D, H, W, C, dtype=torch.float32, device=dev)
+        co.conv_igemm(gu, 64, 64, None, 0, 0, p["ct_wT"], None, None, None, 1.0, None, None, None, dz, None, (n, D, H, W), (D2, H2, W2), C, C,
+                      p["ct_taps"], istride=2, epilogue=co.EPI_BIAS)
+        ctx.saved = None
+        return dz.permute(0, 4, 1, 2, 3), None
+
+
 class Encoder3D(co.PackedModule):
     """models/encoder.py:8-68."""
 
@@ -155,6 +201,8 @@ class Encoder3D(co.PackedModule):
         ONE N = 64 launch; nothing is memoised between calls (the model classes call this instead of the two getters)."""
         if hip_inference(self, z_3d):
             return self._heads_hip(z_3d, "both")
+        if frozen_eval(self, z_3d):
+            return _HeadsFrozen.apply(z_3d, self)                        # refinement: fused forward, data-gradient-only backward
         return self.get_render_features(z_3d), self.get_density3D(z_3d)
 
     def fuse(self, x):
@@ -162,7 +210,9 @@ class Encoder3D(co.PackedModule):
         if hip_inference(self, x):
             return self.fusion_feature.fuse_hip(x)
         require_hip_input("Encoder3D.fuse", x)
-        return self.fusion_feature.fuse_autograd_hip(x)                 # training / refinement: HIP convs with autograd
+        if frozen_eval(self.fusion_feature, x) and self.fusion_feature.n_layers == 1:
+            return self.fusion_feature.fuse_frozen_hip(x)               # refinement: fused forward, data-gradient-only backward
+        return self.fusion_feature.fuse_autograd_hip(x)                 # training: HIP convs with autograd
 
     def fuse_groups(self, x, groups):
         """[self.fuse(x[:, g]) for g in groups], sharing the per-view work between the groups where that pays: with an autograd graph on
@@ -275,12 +325,68 @@ class Encoder3D(co.PackedModule):
             return blocks
         return self._trunk_cache.get(src, build)
 
+    TRUNK_STREAMS = 1             # concurrent image groups of a small batch (one scene = 5 views): see _trunk_hip
+    TRUNK_SPLIT_MAX_ROWS = 16384  # batches with more (H/8 x W/8) rows than this fill the chip with one launch per layer
+
+    @staticmethod
+    def _trunk_out_hw(H, W):
+        f = lambda v, k, s, p: (v + 2 * p - k) // s + 1
+        return tuple(f(f(f(v, 7, 2, 3), 3, 2, 1), 3, 2, 1) for v in (H, W))        # stem conv, max-pool, layer2's stride-2 3x3
+
+    def _side_streams(self, device, n):
+        pool = self.__dict__.setdefault("_trunk_stream_pool", {})
+        lst = pool.setdefault(device, [])
+        while len(lst) < n:
+            lst.append(torch.cuda.Stream(device=device))
+        return lst[:n]
+
     @_lib.on_tensor_device
     def _trunk_hip(self, img):
         """The whole ResNet-50 trunk on the fp32 matrix cores: stem (patch gather + GEMM, max-pool kernel), layers 1-4 as
         im2col-free implicit GEMMs (1x1 = plain GEMM, 3x3 = 9 taps, strides via the input-stride argument), BN folded, ReLU
         and the residual add in the epilogue, activations NHWC, the 2D->3D lift fused into the last store.
-        img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1)."""
+        img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1).
+
+        Small batches (one scene = 5 views: M = 5120 GEMM rows in layers 2-4, 53 dependent launches of 15-60 us whose fixed costs -
+        launch, prologue, pipeline fill, epilogue, end-of-kernel cache write-back - dominate) are split into up to TRUNK_STREAMS image
+        groups that run the trunk CONCURRENTLY on side streams (parallel branches of the captured hipGraph): the images are
+        independent until conv1, so one group's fixed costs overlap another group's MFMA work. Each launch plans for its share of
+        the CUs (convops.cu_budget). Same kernels, same per-row arithmetic; only the tile / split-K plan (fp32 summation order) can
+        differ from the single-launch schedule."""
+        import os
+        N, _, H, W = img.shape
+        Ho, Wo = self._trunk_out_hw(H, W)
+        out = torch.empty(N, self.LIFT_Z, Ho, Wo, self.LIFT_C, dtype=torch.float32, device=img.device)
+        self._stem_packed()                 # packed weights are (re)built on the launch stream BEFORE the side streams read them
+        self._trunk_packed()
+        ng = min(N, int(os.environ.get("FORGE_TRUNK_STREAMS", self.TRUNK_STREAMS)))
+        if ng <= 1 or N * Ho * Wo > self.TRUNK_SPLIT_MAX_ROWS:
+            self._trunk_hip_group(img, out)
+            return out
+        bounds = [(N * g) // ng for g in range(ng + 1)]
+        main = torch.cuda.current_stream(img.device)
+        streams = self._side_streams(img.device, ng)
+        with co.cu_budget(max(256 // ng, 32)):
+            for g, st in enumerate(streams):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    self._trunk_hip_group(img[bounds[g]:bounds[g + 1]], out[bounds[g]:bounds[g + 1]])
+        for st in streams:
+            main.wait_stream(st)
+        return out
+
+    def _stem_packed(self):
+        conv0, bn0 = self.feature_extraction[0], self.feature_extraction[1]
+        kh, kw = conv0.kernel_size
+        Kp = ((kh * kw * conv0.in_channels + 31) // 32) * 32
+
+        def build_stem():
+            w = conv0.weight.detach().permute(0, 2, 3, 1).reshape(conv0.out_channels, -1)          # [Cout][(ky,kx,c)]
+            return (co.pad_cin(w[None].contiguous(), Kp),) + co.bn_affine(bn0)
+        return self._stem_cache.get([conv0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var], build_stem)
+
+    def _trunk_hip_group(self, img, dst):
+        """One group of images through the trunk (see _trunk_hip); the last GEMM stores the lifted volume into dst [n,32,H/8,W/8,64]."""
         fe = self.feature_extraction
         dev = img.device
         T1 = [(0, 0, 0)]
@@ -288,11 +394,7 @@ class Encoder3D(co.PackedModule):
         conv0, bn0, pool = fe[0], fe[1], fe[3]
         kh, kw = conv0.kernel_size
         Kp = ((kh * kw * conv0.in_channels + 31) // 32) * 32
-
-        def build_stem():
-            w = conv0.weight.detach().permute(0, 2, 3, 1).reshape(conv0.out_channels, -1)          # [Cout][(ky,kx,c)]
-            return (co.pad_cin(w[None].contiguous(), Kp),) + co.bn_affine(bn0)
-        w0, sc0, sh0 = self._stem_cache.get([conv0.weight, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var], build_stem)
+        w0, sc0, sh0 = self._stem_packed()
         N, Ci, Hi, Wi = img.shape
         s0, p0 = conv0.stride[0], conv0.padding[0]
         Hc, Wc = (Hi + 2 * p0 - kh) // s0 + 1, (Wi + 2 * p0 - kw) // s0 + 1
@@ -327,7 +429,8 @@ class Encoder3D(co.PackedModule):
             else:
                 idn = xr
             if last:
-                out = torch.empty(N, self.LIFT_Z, Ho, Wo, self.LIFT_C, dtype=torch.float32, device=dev)
+                assert dst.shape == (N, self.LIFT_Z, Ho, Wo, self.LIFT_C) and dst.is_contiguous()
+                out = dst
             else:
                 out = torch.empty(N, Ho, Wo, 4 * P, dtype=torch.float32, device=dev)
             co.conv_igemm(y2, P, P, None, 0, 0, b["w3"], None, b["a3"][0], b["a3"][1], 0.0, idn, None, None, out, None,
@@ -347,11 +450,21 @@ class Encoder3D(co.PackedModule):
                       (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
         return out.permute(0, 4, 1, 2, 3)
 
-    def _heads_hip(self, z, which="both"):
-        """The heads (models/encoder.py:16-34) on a fused volume, returns (features | None, density | None).
-        which = "both": the two ConvTranspose3d(128,32,4,s2,p1)+BN+LReLU run as ONE N=64 launch covering the 8 output phases x 8
-        taps, then Conv3d(32,16)+BN and Conv3d(32,8)+BN+LReLU read their 32-channel halves of the shared [..,64] tensor in place, then
-        Conv3d(8,1)+ReLU. which = "features" / "density": that head alone (N=32 transposed convolution), as the reference computes it."""
+    def _heads_packed_T(self):
+        """Transposed / padded packed head weights and BatchNorm scales for _HeadsFrozen.backward (cached with the forward pack)."""
+        self._heads_hip_pack()
+        p = self._heads_cache.val
+        if "ct_wT" not in p:
+            fh, dh = self.features_head, self.density_head
+            wct = torch.cat([fh[0].weight, dh[0].weight], dim=1).detach()                      # [128, 64, 4, 4, 4]
+            tr16 = lambda w: co.pad_last(w.transpose(1, 2).contiguous(), 16)                   # [27][Cin][Cout -> 16]
+            p.update({"ct_wT": wct.reshape(wct.shape[0], 64, 64).permute(2, 0, 1).contiguous(),        # [k][Cin=128][Cout=64]
+                      "ct_taps": [(kz - 1, ky - 1, kx - 1) for kz in range(4) for ky in range(4) for kx in range(4)],
+                      "ct_scale": p["ct_aff"][0], "f4_scale": p["f4"][0], "d4_scale": p["d4"][0],
+                      "f3_wT": tr16(p["f3_w"]), "d3_wT": tr16(p["d3_w"])})
+        return p
+
+    def _heads_hip_pack(self):
         fh, dh = self.features_head, self.density_head
         src = [fh[0].weight, fh[0].bias, dh[0].weight, dh[0].bias, fh[3].weight, fh[3].bias, dh[3].weight, dh[3].bias,
                dh[6].weight, dh[6].bias] + [t for bn in (fh[1], dh[1], fh[4], dh[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
@@ -365,7 +478,15 @@ class Encoder3D(co.PackedModule):
                     "f3_w": co.pack_conv3d_weight(fh[3].weight), "f3_b": fh[3].bias.detach().contiguous(), "f4": co.bn_affine(fh[4]),
                     "d3_w": co.pack_conv3d_weight(dh[3].weight), "d3_b": dh[3].bias.detach().contiguous(), "d4": co.bn_affine(dh[4]),
                     "d6_w": w6, "d6_b": dh[6].bias.detach().contiguous()}
-        p = self._heads_cache.get(src, build)
+        return self._heads_cache.get(src, build)
+
+    def _heads_hip(self, z, which="both", keep=False):
+        """The heads (models/encoder.py:16-34) on a fused volume, returns (features | None, density | None).
+        which = "both": the two ConvTranspose3d(128,32,4,s2,p1)+BN+LReLU run as ONE N=64 launch covering the 8 output phases x 8
+        taps, then Conv3d(32,16)+BN and Conv3d(32,8)+BN+LReLU read their 32-channel halves of the shared [..,64] tensor in place, then
+        Conv3d(8,1)+ReLU. which = "features" / "density": that head alone (N=32 transposed convolution), as the reference computes it.
+        keep: also return the intermediate activations (up, d8) for the hand-written backward of _HeadsFrozen."""
+        p = self._heads_hip_pack()
         n, C, D, H, W = z.shape
         D2, H2, W2 = 2 * D, 2 * H, 2 * W
         dev = z.device
@@ -396,6 +517,8 @@ class Encoder3D(co.PackedModule):
             dens = torch.empty(n, D2, H2, W2, 1, dtype=torch.float32, device=dev)
             co.conv_direct(d8, 8, p["d6_w"], p["d6_b"], 0.0, dens, g2, 8, 1, co.TAPS_3x3x3)   # Conv3d(8, 1) + ReLU: 216 MACs per voxel
             dens = dens.permute(0, 4, 1, 2, 3)
+        if keep:
+            return feat, dens, up, d8
         return feat, dens
 
     def forward(self, x):

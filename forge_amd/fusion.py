@@ -19,6 +19,24 @@ def hip_inference(module, x):
     return x.is_cuda and x.dtype == torch.float32 and not module.training and not torch.is_grad_enabled()
 
 
+def frozen_eval(module, x):
+    """Eval mode with an autograd graph but NO trainable parameter below `module` (test-time pose refinement, kubric_eval.py:412-530:
+    gradients flow only to the poses): forward runs the fused inference epilogues, backward is hand-written data-gradient only."""
+    return (x.is_cuda and x.dtype == torch.float32 and not module.training and torch.is_grad_enabled()
+            and not any(p.requires_grad for p in module.parameters()))
+
+
+def affine_act_bwd(dy, y, scale, slope, out=None):
+    """dx = dy * scale[c] * (y > 0 ? 1 : slope) on rows [..., C] (last-dim stride 1, row stride arbitrary)."""
+    C = dy.shape[-1]
+    M = dy.numel() // C
+    if out is None:
+        out = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().forge_affine_act_bwd(_lib.ptr(dy), dy.stride(-2), _lib.ptr(y), y.stride(-2), _lib.ptr(scale), float(slope), _lib.ptr(out),
+                                               out.stride(-2), M, C, _lib.current_stream()), "forge_affine_act_bwd")
+    return out
+
+
 def require_hip_input(what, x, channels=None):
     """The product has ONE implementation per op - the HIP kernels. Anything they cannot take is an error, never a silent stock-PyTorch
     detour (north_star: no dual code paths)."""
@@ -73,7 +91,7 @@ class _GRUCellRows(torch.autograd.Function):
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
         dh, dz, dc = new(C), new(C), new(C)
-        _lib.check(L.forge_gru_state_bwd(p(dhn), p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
+        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
         # candidate conv: c = conv([x | h r], wo)
         dxh = new(2 * C)                                                                   # (dx | d(h r))
         co.conv_igemm(dc, C, C, None, 0, 0, wo.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh, None, grid, ig,
@@ -86,7 +104,7 @@ class _GRUCellRows(torch.autograd.Function):
             dbo = dc.reshape(M, C).sum(dim=0)
         # gates: g = conv([x | h], wg); z = sigmoid(g[:C]), r = sigmoid(g[C:]), hr = h r
         dg = new(2 * C)
-        _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), M, C, st()), "forge_gru_gates_bwd")
+        _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
         dxh2 = new(2 * C)
         co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, wg.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh2, None, grid, ig,
                       2 * C, 2 * C, ntaps, epilogue=co.EPI_BIAS)
@@ -146,7 +164,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
         dh, dz, dc = new(C), new(C), new(C)
-        _lib.check(L.forge_gru_state_bwd(p(dhn), p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
+        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
         dhr = new(C)
         co.conv_igemm(dc, C, C, None, 0, 0, wo.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dhr, None, grid, ig, C, C, ntaps,
                       epilogue=co.EPI_BIAS)
@@ -157,7 +175,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         if ctx.has_bias[1] and ctx.needs_input_grad[6]:
             dbo = dc.reshape(M, C).sum(dim=0)
         dg = new(2 * C)
-        _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), M, C, st()), "forge_gru_gates_bwd")
+        _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
         dh_total = new(C)                                          # dh (state + reset paths) + conv^T(dg, Wg_h), added in the GEMM epilogue
         co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, wg.transpose(1, 2).contiguous(), None, one, zero, 1.0, dh, None, None, dh_total, None, grid, ig,
                       C, C, ntaps, epilogue=co.EPI_AFFINE_ACT)
@@ -167,6 +185,89 @@ class _GRUCellPreRows(torch.autograd.Function):
         if ctx.has_bias[0] and ctx.needs_input_grad[4]:
             dbg = dg.reshape(M, 2 * C).sum(dim=0)
         return (dg if ctx.needs_input_grad[0] else None), (dc if ctx.needs_input_grad[1] else None), dh_total, dwg, dbg, dwo, dbo
+
+
+class _FuseFrozen(torch.autograd.Function):
+    """Encoder3D.fuse for frozen weights (eval mode, gradients only w.r.t. the input views): forward = ConvGRU_3D.fuse_hip - the fused
+    conv + BN + LeakyReLU launches of fusion_conv and TWO launches per view (gates: cat / conv / sigmoid / h*r; state: cat / conv /
+    tanh / lerp, final BatchNorm folded) - with the reset gate and the candidate additionally stored (forge_conv_igemm out3); backward
+    = per view: state half (one kernel), data-gradient GEMM of the candidate conv, gate half (one kernel, its dh sum written beside
+    the x-gradient half), data-gradient GEMM of the gate conv with that buffer as residual -> (dx_t | dh) in one tensor; no weight
+    gradients, no generic element-wise kernels."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, gru):
+        b, t, C, D, H, W = x.shape
+        xr = x.permute(0, 1, 3, 4, 5, 2)
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        p = gru._packed()
+        dev, M, vol = x.device, b * D * H * W, D * H * W
+        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        mean = xr.mean(dim=1).reshape(M, C)
+        t0, h = new(), new()
+        co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, grid, ig, C, C, taps,
+                      epilogue=co.EPI_AFFINE_ACT)
+        co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, grid, ig, C, C, taps,
+                      epilogue=co.EPI_AFFINE_ACT)
+        steps, out = [], new()
+        for ti in range(t):
+            xt = xr[:, ti]
+            z, hr, r, hn, cand = new(), new(), new(), new(), new()
+            co.conv_igemm(xt, C, C, h, C, C, p["gate_w"], p["gate_b"], None, None, 1.0, None, h, None, z, hr, grid, ig, 2 * C, C, taps,
+                          epilogue=co.EPI_GRU_GATES, bs1=t * vol, out3=r)
+            co.conv_igemm(xt, C, C, hr, C, C, p["out_w"], p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, hn, out if ti == t - 1 else None,
+                          grid, ig, C, C, taps, epilogue=co.EPI_GRU_OUT, bs1=t * vol, out3=cand)
+            steps.append((h, z, r, cand))
+            h = hn
+        ctx.gru, ctx.shape = gru, (b, t, C, D, H, W)
+        ctx.steps, ctx.h0 = steps, (t0, steps[0][0])
+        return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dout):
+        gru = ctx.gru
+        b, t, C, D, H, W = ctx.shape
+        p = gru._packed_T()
+        dev, M = dout.device, b * D * H * W
+        grid, ig = (b, D, H, W), (D, H, W)
+        ntaps = [(-a, -b_, -c) for a, b_, c in co.TAPS_3x3x3]
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        L, ptr, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        one, zero = p["one"], p["zero"]
+        dr = dout.permute(0, 2, 3, 4, 1)
+        dr = (dr if dr.is_contiguous() else dr.contiguous()).reshape(M, C)
+        dhn = dr * p["norm_scale"]                                           # out = fusion_norm(h_T) = h_T * scale + shift
+        ld_dhn = C
+        dx = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
+        for ti in reversed(range(t)):
+            h, z, r, cand = ctx.steps[ti]
+            dh, dz, dc, dg = new(), new(), new(), new(2 * C)
+            _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, st()), "forge_gru_state_bwd")
+            dxh = new(2 * C)                                                 # (d x_t | d (h r)) of the candidate conv
+            co.conv_igemm(dc, C, C, None, 0, 0, p["out_wT"], None, None, None, 1.0, None, None, None, dxh, None, grid, ig, 2 * C, 2 * C, ntaps,
+                          epilogue=co.EPI_BIAS)
+            # dg = gate pre-activation gradients; dh + d(hr) r lands in dxh's right half (over d(hr)): dxh = (dx_t part 1 | dh partial)
+            _lib.check(L.forge_gru_gates_bwd(ptr(dz), ptr(dxh[:, C:]), 2 * C, ptr(h), ptr(z), ptr(r), ptr(dg), ptr(dh), ptr(dxh[:, C:]), 2 * C, M, C,
+                                             st()), "forge_gru_gates_bwd")
+            tot = new(2 * C)                                                 # conv^T(dg, Wg) + dxh = (d x_t | d h_{t-1})
+            co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, p["gate_wT"], None, one, zero, 1.0, dxh, None, None, tot, None, grid, ig, 2 * C, 2 * C, ntaps,
+                          epilogue=co.EPI_AFFINE_ACT)
+            dx[:, ti] = tot.view(b, D, H, W, 2 * C)[..., :C]
+            dhn, ld_dhn = tot[:, C:], 2 * C
+        # h0 = lrelu(bn4(conv(lrelu(bn1(conv(mean_t x))))))
+        t0, h0 = ctx.h0
+        g = torch.empty(M, C, dtype=torch.float32, device=dev)
+        affine_act_bwd(dhn, h0, p["bn4_scale"], 0.01, out=g)
+        g2 = new()
+        co.conv_igemm(g, C, C, None, 0, 0, p["fc3_wT"], None, None, None, 1.0, None, None, None, g2, None, grid, ig, C, C, ntaps, epilogue=co.EPI_BIAS)
+        affine_act_bwd(g2, t0, p["bn1_scale"], 0.01, out=g)
+        co.conv_igemm(g, C, C, None, 0, 0, p["fc0_wT"], None, None, None, 1.0, None, None, None, g2, None, grid, ig, C, C, ntaps, epilogue=co.EPI_BIAS)
+        dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
+        ctx.steps = ctx.h0 = None
+        return dx.permute(0, 1, 5, 2, 3, 4), None
 
 
 def gru_cell_rows(x, h, gate_weight, gate_bias, out_weight, out_bias):
@@ -234,6 +335,24 @@ class ConvGRU_3D(co.PackedModule):
                 "bn1": co.bn_affine(fc[1]), "bn4": co.bn_affine(fc[4]), "norm": co.bn_affine(self.fusion_norm),
             }
         return self._pack_cache.get(src, build)
+
+    def _packed_T(self):
+        """Transposed packed weights ([tap][Cin][Cout]) and BatchNorm scales for the hand-written data-gradient path (_FuseFrozen)."""
+        p = self._packed()
+        if "gate_wT" not in p:
+            tr = lambda w: w.transpose(1, 2).contiguous()
+            dev = p["gate_w"].device
+            C2 = p["gate_w"].shape[1]
+            p.update({"gate_wT": tr(p["gate_w"]), "out_wT": tr(p["out_w"]), "fc0_wT": tr(p["fc0_w"]), "fc3_wT": tr(p["fc3_w"]),
+                      "norm_scale": p["norm"][0], "bn1_scale": p["bn1"][0], "bn4_scale": p["bn4"][0],
+                      "one": torch.ones(C2, device=dev), "zero": torch.zeros(C2, device=dev)})
+        return p
+
+    def fuse_frozen_hip(self, x):
+        """Encoder3D.fuse with frozen weights under autograd (pose refinement): fused forward, hand-written data-gradient backward."""
+        assert self.n_layers == 1 and self.input_size == self.hidden_size
+        require_hip_input("ConvGRU_3D.fuse_frozen_hip", x, x.shape[2])
+        return _FuseFrozen.apply(x, self)
 
     def fuse_hip(self, x, h0=None):
         """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs (or the caller's h0

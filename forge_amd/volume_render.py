@@ -17,8 +17,46 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import convops as co, ops
-from .fusion import hip_inference
+from . import _lib, convops as co, ops
+from .fusion import affine_act_bwd, frozen_eval, hip_inference
+
+
+class _ConvRgbFrozen(torch.autograd.Function):
+    """conv_rgb + ReLU (models/volume_render.py:29-37,73) for frozen weights under autograd (pose refinement): forward = the fused
+    inference launches of VolRender._conv_rgb_hip keeping the two intermediate activations; backward = data gradients only."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, vr):
+        rgb, up, mid = vr._conv_rgb_hip(x, keep=True)
+        ctx.vr, ctx.saved, ctx.xshape = vr, (up, mid, rgb), x.shape
+        return rgb
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, drgb):
+        vr = ctx.vr
+        up, mid, rgb = ctx.saved
+        V, C, Hr, Wr = ctx.xshape
+        p = vr._conv_rgb_packed_T()
+        dev = up.device
+        H2, W2 = 2 * Hr, 2 * Wr
+        g2 = (V, 1, H2, W2)
+        dr = drgb.permute(0, 2, 3, 1)
+        dr = dr if dr.is_contiguous() else dr.contiguous()
+        g = affine_act_bwd(dr, rgb.permute(0, 2, 3, 1), None, 0.0)                        # trailing ReLU
+        dmid = torch.empty(V, H2, W2, 8, dtype=torch.float32, device=dev)
+        co.direct_dgrad(g.reshape(V, 1, H2, W2, 3), p["w6"], dmid.reshape(V, 1, H2, W2, 8), g2, 8, 3, p["taps6"])
+        g16 = torch.zeros(V, 1, H2, W2, 16, dtype=torch.float32, device=dev)
+        affine_act_bwd(dmid.reshape(V, 1, H2, W2, 8), mid.reshape(V, 1, H2, W2, 8), p["bn4_scale"], 0.01, out=g16[..., :8])
+        dup = torch.empty(V, 1, H2, W2, 16, dtype=torch.float32, device=dev)
+        co.narrow_dgrad(g16, p["w3T"], dup, g2, p["taps3"])
+        gu = affine_act_bwd(dup, up.reshape(V, 1, H2, W2, 16), p["bn1_scale"], 0.01)
+        dx = torch.empty(V, 1, Hr, Wr, C, dtype=torch.float32, device=dev)
+        co.conv_igemm(gu, 16, 16, None, 0, 0, p["ctT"], None, None, None, 1.0, None, None, None, dx, None, (V, 1, Hr, Wr), (1, H2, W2), C, C,
+                      p["ct_taps"], istride=2, epilogue=co.EPI_BIAS)
+        ctx.saved = None
+        return dx.reshape(V, Hr, Wr, C).permute(0, 3, 1, 2), None
 
 
 class VolRender(co.PackedModule):
@@ -82,6 +120,8 @@ class VolRender(co.PackedModule):
                                self.min_depth, self.max_depth, half, want_depth=render_depth)
         if hip_inference(self, outs[0]):
             rendered_imgs = self._conv_rgb_hip(outs[0])
+        elif frozen_eval(self, outs[0]):
+            rendered_imgs = _ConvRgbFrozen.apply(outs[0], self)      # refinement: fused forward, data-gradient-only backward
         else:
             rendered_imgs = self._conv_rgb_autograd_hip(outs[0])      # ops.render_rays has already refused non-HIP tensors
         rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
@@ -92,7 +132,18 @@ class VolRender(co.PackedModule):
             result.append(self._origin_proj(T, K))
         return tuple(result)
 
-    def _conv_rgb_hip(self, x):
+    def _conv_rgb_packed_T(self):
+        p = self._rgb_cache.val
+        if "ctT" not in p:
+            cr = self.conv_rgb
+            k, pad = cr[0].weight.shape[-1], self.pad_size
+            w0 = cr[0].weight.detach()                                                       # ConvTranspose2d weight [Cin, Cout, k, k]
+            p.update({"ctT": w0.reshape(w0.shape[0], w0.shape[1], k * k).permute(2, 0, 1).contiguous(),      # [k*k][Cin][Cout]
+                      "ct_taps": [(0, ky - pad, kx - pad) for ky in range(k) for kx in range(k)],
+                      "w3T": co.pad_last(p["w3"].transpose(1, 2).contiguous(), 16), "bn1_scale": p["bn1"][0], "bn4_scale": p["bn4"][0]})
+        return p
+
+    def _conv_rgb_hip(self, x, keep=False):
         """conv_rgb + ReLU (models/volume_render.py:29-37,73) on the MFMA GEMM kernel: ConvTranspose2d(16,16,k+1,s2,p) as its 4
         output phases in one launch + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
         channels-last memory (what the ray-marcher writes) -> [V,3,2Hr,2Wr] (channels-last memory)."""
@@ -122,6 +173,8 @@ class VolRender(co.PackedModule):
                       g2, ig2, 8, 8, p["taps3"], epilogue=co.EPI_AFFINE_ACT)
         rgb = torch.empty(V, H2, W2, 3, dtype=torch.float32, device=dev)
         co.conv_direct(mid, 8, p["w6"], p["b6"], 0.0, rgb, g2, 8, 3, p["taps6"])              # Conv2d(8, 3, k) + ReLU on the vector ALUs
+        if keep:
+            return rgb.permute(0, 3, 1, 2), up, mid
         return rgb.permute(0, 3, 1, 2)
 
     def _conv_rgb_autograd_hip(self, x):

@@ -139,6 +139,9 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *                                        out2[m][c] = aux_h[m][c] * sigmoid(v_{Ch+c})  (h * reset)
  *            3  GRU state: hn = aux_h (1 - aux_z) + tanh(v) aux_z; out = hn;
  *                          out2 (nullable) = hn * scale + shift          (fusion_norm on the last step)
+ *   out3 (nullable, epilogues 2 / 3 only): what a hand-written backward of the fused cell needs besides out / out2 -
+ *            epilogue 2: the reset gate sigmoid(v_{Ch+c}) [M][Ch]; epilogue 3: the candidate tanh(v) [M][Cout]
+ *            (pose refinement with frozen weights runs the fused epilogues in forward, forge_amd/fusion.py).
  * bias/scale/shift [Cout]; bias nullable.
  *   lift > 0 (epilogue 1, 2-D conv i.e. D = 1): fuses the 2D->3D feature lift of models/encoder.py:49 into the store —
  *            GEMM column j = z*(Cout/lift) + c of row (n, h, w) is written to out[n][z][h][w][c] (a channels-last
@@ -147,14 +150,19 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
  *            per tile; raw partial tiles go to splitk_ws[slice][M][Cout] and a second kernel sums them in a fixed order and
  *            applies the epilogue (epilogues 0 and 1 only). NULL disables it. Results are deterministic either way.
+ *   cu_budget (0 = the whole chip, 256): the number of CUs the launch plan should count on. Launches that run CONCURRENTLY on
+ *            several streams (the per-view ResNet trunks of one scene, forge_amd/encoder.py) pass 256 / streams so that the plan
+ *            neither over-splits K nor picks tiles for a chip it does not own. Affects speed only, never results' validity
+ *            (tile / split-K choice changes the fp32 summation order).
+ *   M = n D H W must be < 2^31.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
                      const float* wp,
                      const float* bias, const float* scale, const float* shift, float slope, const float* residual,
-                     const float* aux_h, const float* aux_z, float* out, float* out2,
+                     const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
+                     int epilogue, int lift, int cu_budget, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
 
 /* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
  * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
@@ -162,7 +170,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
  * taps per phase). Pure host arithmetic (a makespan model of the 256-CU chip), no launch; lets a
  * caller size the split-K workspace (ksplit * M * Cout floats) and lets profilers attribute launches to kernel instantiations. */
 int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
-                          int* tile, int* ksplit);
+                          int cu_budget, int* tile, int* ksplit);
 
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
  *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)
@@ -198,15 +206,23 @@ int forge_conv_direct_wgrad(const float* dy, int ld_dy, const float* x, int ld_x
  * cell is one kernel per direction. All arrays are channels-last rows [M][C] fp32, C % 4 == 0, g / dg are [M][2C] (update | reset).
  *   gates fwd: z = sigmoid(g[:, :C]), r = sigmoid(g[:, C:]), hr = h * r
  *   state fwd: cand = tanh(c) (written over c), hn = h (1 - z) + cand z
- *   state bwd: dh = dhn (1 - z), dz = dhn (cand - h), dc = dhn z (1 - cand^2)
- *   gates bwd: dg = (dz z (1 - z) | dhr h r (1 - r)), dh += dhr r      (dhr rows may be strided: ld_dhr floats)
+ *   state bwd: dh = dhn (1 - z), dz = dhn (cand - h), dc = dhn z (1 - cand^2)        (dhn rows may be strided: ld_dhn floats)
+ *   gates bwd: dg = (dz z (1 - z) | dhr h r (1 - r)), dh_out = dh + dhr r  (dhr rows may be strided: ld_dhr floats; dh_out NULL = in
+ *              place over dh, else rows of stride ld_dh_out - it may alias dhr, which lets the sum land beside the x-gradient half)
  */
 int forge_gru_gates_fwd(const float* g, const float* h, float* z, float* r, float* hr, long long M, int C, forge_stream_t stream);
 int forge_gru_state_fwd(float* c_cand, const float* h, const float* z, float* hn, long long M, int C, forge_stream_t stream);
-int forge_gru_state_bwd(const float* dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
+int forge_gru_state_bwd(const float* dhn, int ld_dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
                         long long M, int C, forge_stream_t stream);
 int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
-                        float* dg, float* dh, long long M, int C, forge_stream_t stream);
+                        float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, forge_stream_t stream);
+
+/* Backward of forge_conv_igemm's epilogue 1 (folded eval-BatchNorm + LeakyReLU / ReLU) for frozen-weight optimisation loops (pose
+ * refinement, kubric_eval.py:412-530): dx[m][c] = dy[m][c] * scale[c] * (y[m][c] > 0 ? 1 : slope), y = the forward OUTPUT (its sign
+ * is the pre-activation's for slope >= 0). Rows may be strided (ld_* floats); scale nullable (= 1). The data gradient of the
+ * convolution itself is forge_conv_igemm on dx with negated taps and transposed weights. */
+int forge_affine_act_bwd(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale, float slope, float* dx, int ld_dx,
+                         long long M, int C, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a1  ResNet stem helpers (torchvision conv1/bn1/relu/maxpool behind models/encoder.py:71-73).

@@ -272,8 +272,11 @@ def test_config3_grid64_training_step_vs_oracle_autograd(dev):
         ref = wo[k].grad
         err = (named[k].grad.cpu() - ref).abs().max().item()
         assert err < 1e-2 * max(ref.abs().max().item(), 1e-1 * gscale), (k, err, ref.abs().max().item())
+    # input-feature gradient: relative L2 (a max-norm bound is meaningless here - where a LeakyReLU pre-activation sits within fp32
+    # noise of 0 the two implementations pick different slopes (1 vs 0.01) and the gradient of a few isolated voxels differs by O(1))
     gf = fd.grad.cpu()
-    assert (gf - fr.grad).abs().max().item() < 1e-2 * fr.grad.abs().max().item()
+    assert (gf - fr.grad).norm().item() < 5e-3 * fr.grad.norm().item()
+    assert ((gf - fr.grad).abs() > 1e-2 * fr.grad.abs().max()).float().mean().item() < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------------------- f4
@@ -373,3 +376,45 @@ def test_single_head_getters_equal_merged_heads(dev):
     with torch.no_grad():
         f, d = enc.heads(z)
         assert (enc.get_render_features(z) - f).abs().max().item() < 1e-5 and (enc.get_density3D(z) - d).abs().max().item() < 1e-5
+
+
+def test_frozen_eval_paths_equal_autograd_paths(dev):
+    """Row f2 (pose refinement, frozen weights): the fused-forward / hand-written-backward paths (_FuseFrozen, _HeadsFrozen,
+    _ConvRgbFrozen - taken when no parameter requires grad) give the same outputs and the same input gradients as the generic
+    autograd paths on the same module (taken when a parameter requires grad). Outputs: 2e-4 of the max. Gradients: relative L2 1e-3 and
+    at most 1e-4 of the elements off by more than 1 % of the max - NOT a max-norm bound: the two paths sum in different orders, so a
+    LeakyReLU pre-activation within fp32 noise of 0 takes slope 1 in one and 0.01 in the other and isolated gradient elements differ
+    (tools/debug/heads_bwd_full.py: every stage agrees to 1e-6 with torch except at those sign flips; the float64 oracle comparison is
+    test_refinement_pose_gradient_vs_oracle_autograd)."""
+    from forge_amd.model import FORGE
+    model, _, _ = _model(FORGE, dev)
+    g = torch.Generator().manual_seed(17)
+    x0 = (torch.randn(1, 3, 128, 16, 16, 16, generator=g) * 0.5).to(dev)
+    r0 = torch.randn(2, 16, 24, 24, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-6)
+
+    def run(frozen):
+        for p in model.parameters():
+            p.requires_grad_(not frozen)
+        x = x0.clone().requires_grad_(True)
+        fused = model.encoder_3d.fuse(x)
+        feat, dens = model.encoder_3d.heads(fused)
+        wf, wd = torch.linspace(-1, 1, feat.numel(), device=dev).reshape(feat.shape), torch.linspace(1, -1, dens.numel(), device=dev).reshape(dens.shape)
+        ((feat * wf).sum() + (dens * wd).sum() + fused.square().sum() * 1e-3).backward()
+        r = r0.clone().requires_grad_(True)
+        if frozen:
+            from forge_amd.volume_render import _ConvRgbFrozen
+            rgb = _ConvRgbFrozen.apply(r, model.render)
+        else:
+            rgb = model.render._conv_rgb_autograd_hip(r)
+        (rgb * torch.linspace(-1, 1, rgb.numel(), device=dev).reshape(rgb.shape)).sum().backward()
+        return [t.detach().clone() for t in (fused, feat, dens, x.grad, rgb, r.grad)]
+    a, b = run(True), run(False)
+    for p in model.parameters():
+        p.requires_grad_(True)
+    for name, u, v in zip(("fused", "feat", "dens", "dx", "rgb", "dr"), a, b):
+        if name in ("dx", "dr"):
+            assert (u - v).norm().item() < 1e-3 * v.norm().item(), (name, (u - v).norm().item() / v.norm().item())
+            assert ((u - v).abs() > 1e-2 * v.abs().max()).float().mean().item() < 1e-4, name
+        else:
+            assert rel(u, v) < 2e-4, (name, rel(u, v))

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libforge_hip.so")
+LIB_PATH = os.environ.get("FORGE_AMD_LIB") or os.path.join(_HERE, "libforge_hip.so")     # override: instrumented debug builds (tools/debug)
 _lib = None
 
 _P = ctypes.c_void_p
@@ -22,12 +22,13 @@ SIGNATURES = {
     "forge_version": [],
     "forge_last_error": [],
     "forge_rotate_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_rotate_fwd_slots": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_rotate_xf_from_poses": [_P, _P, _P, _I, _I, _F, _P],
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
-    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 11 + [_P, _LL, _P],
-    "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _I, _P, _P],
+    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 10 + [_P, _LL, _P],
+    "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _P, _P],
     "forge_conv_wgrad": [_P, _I, _P, _I, _I, _LL, _P, _I, _I, _LL, _P] + [_I] * 9 + [_P, _I, _P],
     "forge_conv_direct_fwd": [_P, _I, _P, _P, _F, _P, _I] + [_I] * 6 + [_P, _I, _P],
     "forge_conv_direct_dgrad": [_P, _I, _P, _P, _I] + [_I] * 6 + [_P, _I, _P],
@@ -37,6 +38,9 @@ SIGNATURES = {
     "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P],
     "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P],
     "forge_affine_act_bwd": [_P, _I, _P, _I, _P, _F, _P, _I, _LL, _I, _P],
+    "forge_sse_groups_blocks": [],
+    "forge_sse_groups_fwd": [_P, _LL, _LL, _LL, _LL, _P, _P] + [_I] * 7 + [_P],
+    "forge_sse_groups_bwd": [_P, _LL, _LL, _LL, _LL, _P, _P, _P] + [_I] * 7 + [_P],
     "forge_im2col_nchw": [_P, _P] + [_I] * 9 + [_P],
     "forge_maxpool2d_nhwc": [_P, _P] + [_I] * 7 + [_P],
     "forge_ncdhw_to_ndhwc": [_P, _P, _I, _I, _LL, _P],

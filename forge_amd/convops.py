@@ -162,24 +162,7 @@ def _splitk_workspace(device):
     return ws
 
 
-_CU_BUDGET = [0]
-
-
-class cu_budget:
-    """`with convops.cu_budget(n):` - the conv launches inside plan for n CUs instead of the whole chip (they run concurrently with
-    launches on other streams; forge_conv_igemm's cu_budget argument)."""
-
-    def __init__(self, n):
-        self.n = int(n)
-
-    def __enter__(self):
-        self.prev, _CU_BUDGET[0] = _CU_BUDGET[0], self.n
-
-    def __exit__(self, *exc):
-        _CU_BUDGET[0] = self.prev
-
-
-TILE_NAMES = {"A": "128, 128, 8", "B": "64, 128, 8", "C": "128, 64, 8", "D": "64, 64, 4", "E": "128, 32, 4"}
+TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
 
 def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
@@ -188,7 +171,7 @@ def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
     import ctypes
     tile, ks = ctypes.c_int(0), ctypes.c_int(0)
     _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
-                                                _CU_BUDGET[0], ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
+                                                ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
     return chr(tile.value), ks.value
 
 
@@ -228,7 +211,7 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
             off(in1, s0 * b1 * ld1), C1, ld1, int(bs1), off(in2, s0 * b2 * ld2), C2, ld2, int(bs2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(scale),
             _lib.ptr(shift), float(slope), off(residual, orow * (Cout if lift else ldo)), off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
             off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
-            arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _CU_BUDGET[0], _lib.ptr(ws), SPLITK_WS_BYTES, st),
+            arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st),
             "forge_conv_igemm")
     return out
 

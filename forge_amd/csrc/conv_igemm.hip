@@ -61,12 +61,21 @@ struct ConvArgs {
     int nphase, tpp;                       // > 1: all output phases of a stride-2 transposed conv in ONE launch: phase p = (pz,py,px) bits uses taps [p tpp, (p+1) tpp)
     int epi;
     int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
-    int prio;                              // 1: static wave priority by dispatch round, see conv_igemm_kernel
     float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
 
 constexpr int BK = 32, NTHREADS = 512;
+
+#ifdef FORGE_CONV_TIMING   // debug build (tools/debug/conv_timing.py): per-workgroup clock stamps at entry / first barrier / loop end / exit
+__device__ long long g_conv_stamp[8192 * 4];
+#define FORGE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_conv_stamp[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+extern "C" int forge_debug_conv_stamps(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_stamp), (size_t)n * 4 * sizeof(long long));
+}
+#else
+#define FORGE_STAMP(k) do { } while (0)
+#endif
 
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
 constexpr unsigned OOB = 0x80000000u;      // byte offset beyond any buffer (< 2 GiB spans enforced on the host side)
@@ -95,22 +104,11 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     static_assert(ACH >= 1 && BCH >= 1, "tile too small for the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
 
+    FORGE_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int ntile_n = (a.Cout + BN - 1) / BN;
-    // Static issue priority by dispatch round. The workgroups sharing a CU run the same instruction stream; with equal priority they
-    // alternate on each SIMD's matrix pipe, advance in lock-step and reach their per-K-step barriers TOGETHER - the pipe then idles for the
-    // barrier + LDS-read latency of every step (81 % MFMA-busy in round 1). Workgroups of consecutive dispatch rounds (blockIdx / 256:
-    // one per CU per round) get different priorities, so one races ahead while the other fills its stalls and the phases stay apart.
-    if (a.prio) {
-        switch ((blockIdx.x >> 8) & 3) {
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            case 3: __builtin_amdgcn_s_setprio(3); break;
-            default: break;
-        }
-    }
     const unsigned bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = (int)(bid_all % (unsigned)a.ksplit);           // K-slice of this workgroup (split-K for small M x N problems)
     unsigned bid = bid_all / (unsigned)a.ksplit;
@@ -258,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     load_step(t, kc);
     store_step(0);
     __syncthreads();
+    FORGE_STAMP(1);
     // One K-step = 4 MFMA groups of 8 k-values. (A/B in round 1: issuing the next tile's global loads after group 0 and its LDS
     // writes after group 2, pinned with sched_barrier, changed nothing: 127.3 vs 126.3 TF on the ConvGRU gates shape.)
     auto mfma_group = [&](const float* sa, const float* sb, int g) {
@@ -303,6 +302,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
+    FORGE_STAMP(2);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     // The output-row mapping (identity, strided / phase remap of a transposed convolution, or the 2D->3D lift) is computed ONCE per
     // tile row by one thread (32-bit divisions) into an LDS table; the fully unrolled per-accumulator code below (the accumulators
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         case EPI_GRU_GATES: epilogue(std::integral_constant<int, EPI_GRU_GATES>{}); break;
         default: epilogue(std::integral_constant<int, EPI_GRU_OUT>{}); break;
     }
+    FORGE_STAMP(3);
 }
 
 
@@ -642,8 +643,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 // per-shape best in total. FORGE_CONV_TILE=A..E / FORGE_CONV_KSPLIT=n override the model (that tool).
 struct ConvPlan { char tile; int ksplit; };
 
-static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes, int cu_budget = 0) {
-    const long long CUS = (cu_budget > 0 && cu_budget < 256) ? cu_budget : 256;   // CUs this launch can count on (concurrent launches on other streams share the chip)
+static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes) {
     struct Tile { char id; int bm, bn, occ; double eff, ov; };
     static const Tile tiles[5] = {{'A', 128, 128, 2, 1.000, 4.0}, {'B', 64, 128, 3, 0.983, 1.0}, {'C', 128, 64, 3, 0.969, 1.0},
                                   {'D', 64, 64, 5, 0.980, 1.0}, {'E', 128, 32, 4, 0.915, 1.0}};
@@ -663,20 +663,20 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
         for (int k : splits) {
             if (fk && atoi(fk) != k) continue;
             if (k > 1 && (!can_split || nsteps / k < 8 || (long long)k * M * Cout * 4 > ws_bytes)) continue;
-            const long long wgs = nb * k, slots = CUS * t.occ;
+            const long long wgs = nb * k, slots = 256LL * t.occ;
             const long long full = wgs / slots, rem = wgs - full * slots;
-            const double tile_us = (double)t.bm * t.bn * ((nsteps + k - 1) / k) / (8000.0 * t.eff);     // per-CU rate: independent of the budget
+            const double tile_us = (double)t.bm * t.bn * ((nsteps + k - 1) / k) / (8000.0 * t.eff);
             double us = (double)full * t.occ * tile_us;
             long long rounds = full;
             if (rem > 0) {
-                const long long r = (rem + CUS - 1) / CUS;
+                const long long r = (rem + 255) / 256;
                 us += (double)r * tile_us * g(t.occ) / g(r);
                 ++rounds;
             }
-            const double traffic_us = ((double)M * K * 4.0 * ntn + (double)Cout * K * 4.0 + (double)M * Cout * 4.0) / (4.0e6 * CUS / 256.0);
+            const double traffic_us = ((double)M * K * 4.0 * ntn + (double)Cout * K * 4.0 + (double)M * Cout * 4.0) / 4.0e6;
             if (us < traffic_us) us = traffic_us;
             us += (double)(rounds + 1) * t.ov * sqrt((double)t.bm * t.bn / 16384.0);
-            if (k > 1) us += 3.0 + (double)(k + 1) * M * Cout * 4.0 / (2.0e6 * CUS / 256.0);
+            if (k > 1) us += 3.0 + (double)(k + 1) * M * Cout * 4.0 / 2.0e6;
             if (us < best_us) { best_us = us; best = ConvPlan{t.id, k}; }
         }
     }
@@ -688,13 +688,13 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
 using namespace forge;
 
 extern "C" int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
-                                     int cu_budget, int* tile, int* ksplit) {
+                                     int* tile, int* ksplit) {
     FORGE_REQUIRE(tile && ksplit && M > 0 && Cout > 0 && Cin > 0 && ntaps > 0 && (nphase == 1 || nphase == 4 || nphase == 8) && ntaps % nphase == 0,
                   FORGE_EINVAL, "forge_conv_igemm_plan: bad argument");
     if (Cout <= 16) { *tile = 'N'; *ksplit = 1; return 0; }                         // conv_igemm_n16_kernel
     const ConvPlan pl = plan_conv(M * nphase, Cout, Cin, ntaps / nphase,
                                   nphase == 1 && splitk_ws_bytes > 0 && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
-                                  splitk_ws_bytes, cu_budget);
+                                  splitk_ws_bytes);
     *tile = pl.tile; *ksplit = pl.ksplit;
     return 0;
 }
@@ -706,7 +706,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, int lift, int cu_budget, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
+                                int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
@@ -733,7 +733,6 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.out3 = out3; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     a.nphase = 1; a.tpp = ntaps;
-    { const char* pe = getenv("FORGE_CONV_PRIO"); a.prio = pe ? atoi(pe) : 0; }
     if (pz < 0) {   // all output phases of a stride-2 transposed convolution in one launch
         FORGE_REQUIRE(os == 2 && py < 0 && px < 0 && Ho == 2 * H && Wo == 2 * W && (Do == 2 * D || Do == D), FORGE_EINVAL,
                       "forge_conv_igemm: merged phases (pz = py = px = -1) need os = 2 and a doubled output grid");
@@ -758,7 +757,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     } else {
         const ConvPlan pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp,
                                       a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
-                                      splitk_ws_bytes, cu_budget);
+                                      splitk_ws_bytes);
         const char tile = pl.tile;
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };

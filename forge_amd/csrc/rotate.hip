@@ -65,7 +65,7 @@ __device__ __forceinline__ void voxel_of(unsigned v, int W, int H, int D, int& x
 // (a volume holds < 2^31 float4 elements; checked on the host side).
 template <int NQ>
 __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restrict__ vox, const float* __restrict__ xf,
-                                                         const int* __restrict__ mode, float4* __restrict__ out,
+                                                         const int* __restrict__ mode, const int* __restrict__ dst_slot, float4* __restrict__ out,
                                                          int C4, int D, int H, int W, unsigned per_vol /* D*H*W*C4 */,
                                                          unsigned blocks_per_vol) {
     // grid = n * blocks_per_vol; a workgroup never straddles two volumes
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
     const unsigned t = (bid % blocks_per_vol) * 256u + threadIdx.x;  // (voxel in tile order, channel group)
     if (t >= per_vol / NQ) return;
     const float4* src = vox + (size_t)n * per_vol;
-    float4* dst = out + (size_t)n * per_vol;
+    float4* dst = out + (size_t)(dst_slot ? (unsigned)dst_slot[n] : n) * per_vol;   // output volume index (view ordering fused into the store)
     const unsigned c4 = t % CQ;
     int x, y, z;
     voxel_of(t / CQ, W, H, D, x, y, z);
@@ -340,8 +340,8 @@ static int check_rotate_args(const void* a, const void* b, const void* c, const 
 
 using namespace forge;
 
-extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
-                                int n, int C, int D, int H, int W, forge_stream_t stream) {
+static int rotate_fwd_launch(const float* vox, const float* xf, const int* mode, const int* dst_slot, float* out,
+                             int n, int C, int D, int H, int W, forge_stream_t stream) {
     if (int rc = check_rotate_args(vox, xf, mode, out, n, C, D, H, W)) return rc;
     const int C4 = C / 4;
     const long long per_vol = (long long)D * H * W * C4;
@@ -351,12 +351,23 @@ extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mo
     FORGE_REQUIRE((long long)bpv * n < (1ll << 31), FORGE_ESHAPE, "forge_rotate_fwd: grid too large");
     if (nq == 2)
         hipLaunchKernelGGL(rotate_fwd_kernel<2>, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
+                           (const float4*)vox, xf, mode, dst_slot, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
     else
         hipLaunchKernelGGL(rotate_fwd_kernel<1>, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)vox, xf, mode, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
+                           (const float4*)vox, xf, mode, dst_slot, (float4*)out, C4, D, H, W, (unsigned)per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_fwd");
     return 0;
+}
+
+extern "C" int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
+                                int n, int C, int D, int H, int W, forge_stream_t stream) {
+    return rotate_fwd_launch(vox, xf, mode, nullptr, out, n, C, D, H, W, stream);
+}
+
+extern "C" int forge_rotate_fwd_slots(const float* vox, const float* xf, const int* mode, const int* dst_slot, float* out,
+                                      int n, int C, int D, int H, int W, forge_stream_t stream) {
+    FORGE_REQUIRE(dst_slot, FORGE_EINVAL, "forge_rotate_fwd_slots: null dst_slot");
+    return rotate_fwd_launch(vox, xf, mode, dst_slot, out, n, C, D, H, W, stream);
 }
 
 extern "C" int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, int t, float half_extent,

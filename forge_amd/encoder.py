@@ -325,20 +325,10 @@ class Encoder3D(co.PackedModule):
             return blocks
         return self._trunk_cache.get(src, build)
 
-    TRUNK_STREAMS = 1             # concurrent image groups of a small batch (one scene = 5 views): see _trunk_hip
-    TRUNK_SPLIT_MAX_ROWS = 16384  # batches with more (H/8 x W/8) rows than this fill the chip with one launch per layer
-
     @staticmethod
     def _trunk_out_hw(H, W):
         f = lambda v, k, s, p: (v + 2 * p - k) // s + 1
         return tuple(f(f(f(v, 7, 2, 3), 3, 2, 1), 3, 2, 1) for v in (H, W))        # stem conv, max-pool, layer2's stride-2 3x3
-
-    def _side_streams(self, device, n):
-        pool = self.__dict__.setdefault("_trunk_stream_pool", {})
-        lst = pool.setdefault(device, [])
-        while len(lst) < n:
-            lst.append(torch.cuda.Stream(device=device))
-        return lst[:n]
 
     @_lib.on_tensor_device
     def _trunk_hip(self, img):
@@ -346,33 +336,13 @@ class Encoder3D(co.PackedModule):
         im2col-free implicit GEMMs (1x1 = plain GEMM, 3x3 = 9 taps, strides via the input-stride argument), BN folded, ReLU
         and the residual add in the epilogue, activations NHWC, the 2D->3D lift fused into the last store.
         img [N,3,H,W] -> lifted volume rows [N,32,H/8,W/8,64] (input of conv1).
-
-        Small batches (one scene = 5 views: M = 5120 GEMM rows in layers 2-4, 53 dependent launches of 15-60 us whose fixed costs -
-        launch, prologue, pipeline fill, epilogue, end-of-kernel cache write-back - dominate) are split into up to TRUNK_STREAMS image
-        groups that run the trunk CONCURRENTLY on side streams (parallel branches of the captured hipGraph): the images are
-        independent until conv1, so one group's fixed costs overlap another group's MFMA work. Each launch plans for its share of
-        the CUs (convops.cu_budget). Same kernels, same per-row arithmetic; only the tile / split-K plan (fp32 summation order) can
-        differ from the single-launch schedule."""
-        import os
+        (Round 2 A/B: running the views of one scene as concurrent image groups on side streams / parallel hipGraph branches made the
+        step SLOWER - 12.09 -> 12.32 ms with 2 groups, 14.37 ms with 5: the branches do not overlap on this runtime and every extra
+        kernel costs its ~8 us; DESIGN.md tuning log.)"""
         N, _, H, W = img.shape
         Ho, Wo = self._trunk_out_hw(H, W)
         out = torch.empty(N, self.LIFT_Z, Ho, Wo, self.LIFT_C, dtype=torch.float32, device=img.device)
-        self._stem_packed()                 # packed weights are (re)built on the launch stream BEFORE the side streams read them
-        self._trunk_packed()
-        ng = min(N, int(os.environ.get("FORGE_TRUNK_STREAMS", self.TRUNK_STREAMS)))
-        if ng <= 1 or N * Ho * Wo > self.TRUNK_SPLIT_MAX_ROWS:
-            self._trunk_hip_group(img, out)
-            return out
-        bounds = [(N * g) // ng for g in range(ng + 1)]
-        main = torch.cuda.current_stream(img.device)
-        streams = self._side_streams(img.device, ng)
-        with co.cu_budget(max(256 // ng, 32)):
-            for g, st in enumerate(streams):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    self._trunk_hip_group(img[bounds[g]:bounds[g + 1]], out[bounds[g]:bounds[g + 1]])
-        for st in streams:
-            main.wait_stream(st)
+        self._trunk_hip_group(img, out)
         return out
 
     def _stem_packed(self):

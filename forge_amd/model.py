@@ -68,8 +68,7 @@ class FORGE(nn.Module):
         device = features_raw.device
         if idxs is None:
             idxs = sequence_from_distance(camPoses_cv2[:, :, :3, 3])
-        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D)
-        features_transformed = chose_selected(features_transformed, idxs)
+        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D, order=idxs)   # warp + chose_selected
         features_mv, densities_mv = self.encoder_3d.heads(self.encoder_3d.fuse(features_transformed))
         if self.config.dataset.name == "omniobject3d":
             densities_mv = densities_mv.clamp(min=0.0, max=1.0)

@@ -43,8 +43,10 @@ class Rotate_world(nn.Module):
         return pose_0 @ geo_utils.inverse_affine(pose_1)        # poses are affine (last row 0 0 0 1): closed form, no host sync
 
     @_lib.on_tensor_device
-    def forward(self, voxels, camPoses_cv2, grid_size=32):
-        """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged)."""
+    def forward(self, voxels, camPoses_cv2, grid_size=32, order=None):
+        """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged).
+        order (extension, inference only): the view permutation of models/model.py:127-128 ([B,t] indices, out[:, j] = warped[:, order[:, j]])
+        applied by the kernel's store instead of a gather copy afterwards; ignored (None) by the reference's callers."""
         B, t, C, D, H, W = voxels.shape
         if grid_size not in _SUPPORTED:
             raise ValueError("Rotate_world: grid_size %r not in %s (models/rotate.py:109-123)" % (grid_size, _SUPPORTED))
@@ -60,8 +62,17 @@ class Rotate_world(nn.Module):
             mode = torch.empty(B * t, dtype=torch.int32, device=device)
             _lib.check(_lib.lib().forge_rotate_xf_from_poses(_lib.ptr(poses.contiguous()), _lib.ptr(xf), _lib.ptr(mode), B, t, e,
                                                              _lib.current_stream()), "forge_rotate_xf_from_poses")
+            if order is not None and not voxels.requires_grad:
+                inv = torch.argsort(order.to(device), dim=1)                                # slot of view i in the ordered stack
+                slot = (inv + torch.arange(B, device=device)[:, None] * t).to(torch.int32).reshape(B * t).contiguous()
+                vox_cl = ops.to_channels_last_3d(voxels.reshape(B * t, C, D, H, W))
+                out = ops._empty_like_cl(vox_cl)
+                _lib.check(_lib.lib().forge_rotate_fwd_slots(_lib.ptr(vox_cl), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(slot), _lib.ptr(out),
+                                                             B * t, C, D, H, W, _lib.current_stream()), "forge_rotate_fwd_slots")
+                return out.reshape(B, t, C, D, H, W)
             out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode)
-            return out.reshape(B, t, C, D, H, W)
+            out = out.reshape(B, t, C, D, H, W)
+            return out if order is None else out[torch.arange(B, device=device)[:, None], order.to(device)]
         if t > 1:
             T = self.get_transformation(poses)                                                  # [B(t-1),4,4]
             xf_w = torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(B, t - 1, 12)
@@ -71,5 +82,5 @@ class Rotate_world(nn.Module):
             xf = torch.zeros(B, 12, dtype=torch.float32, device=device)
         mode = torch.ones(B, t, dtype=torch.int32, device=device)
         mode[:, 0] = 0
-        out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode.reshape(B * t))
-        return out.reshape(B, t, C, D, H, W)
+        out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode.reshape(B * t)).reshape(B, t, C, D, H, W)
+        return out if order is None else out[torch.arange(B, device=device)[:, None], order.to(device)]

@@ -23,21 +23,73 @@ def _publish(losses, terms):
     return losses
 
 
+class _SseGroups(torch.autograd.Function):
+    """Per-group sums of squared errors of rendered maps against their target views in one HIP launch (csrc/loss.hip);
+    pred [B,Vp,C,H,W] any strides, target [B,Vt,C,H,W] -> [Vp / gsize] sums. Backward = one launch in pred's memory layout."""
+
+    @staticmethod
+    def forward(ctx, pred, target, gsize):
+        from . import _lib
+        B, Vp, C, H, W = pred.shape
+        Vt = target.shape[1]
+        target = target.contiguous()
+        if pred.stride(0) != Vp * pred.stride(1):
+            pred = pred.contiguous()
+        L = _lib.lib()
+        nb = L.forge_sse_groups_blocks()
+        G = Vp // gsize
+        partial = torch.empty(nb, G, dtype=torch.float32, device=pred.device)
+        with torch.cuda.device(pred.device):
+            _lib.check(L.forge_sse_groups_fwd(_lib.ptr(pred), pred.stride(1), pred.stride(2), pred.stride(3), pred.stride(4), _lib.ptr(target),
+                                              _lib.ptr(partial), B, Vp, Vt, gsize, C, H, W, _lib.current_stream()), "forge_sse_groups_fwd")
+        ctx.save_for_backward(pred, target)
+        ctx.gsize = gsize
+        return partial.sum(dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        pred, target = ctx.saved_tensors
+        B, Vp, C, H, W = pred.shape
+        dpred = torch.empty_strided(pred.shape, pred.stride(), dtype=torch.float32, device=pred.device)
+        coef = (2.0 * g).to(torch.float32).contiguous()
+        with torch.cuda.device(pred.device):
+            _lib.check(_lib.lib().forge_sse_groups_bwd(_lib.ptr(pred), pred.stride(1), pred.stride(2), pred.stride(3), pred.stride(4), _lib.ptr(target),
+                                                       _lib.ptr(coef), _lib.ptr(dpred), B, Vp, target.shape[1], ctx.gsize, C, H, W,
+                                                       _lib.current_stream()), "forge_sse_groups_bwd")
+        return dpred, None, None
+
+
+def grouped_mse(pred, target, gsize):
+    """[F.mse_loss(pred[:, g*gsize:(g+1)*gsize], target[:, (g*gsize) % Vt ...]) for g] as ONE pass (f1: the four MSE terms of a training
+    iteration are two calls - rgb and mask). pred [B,Vp,C,H,W], target [B,Vt,C,H,W] on the MI355X."""
+    B, Vp, C, H, W = pred.shape
+    sse = _SseGroups.apply(pred, target, int(gsize))
+    return sse / float(B * gsize * C * H * W)
+
+
 def compute_reconstruction_loss(config, epoch, sample, dataset, model, losses, device, perceptual_loss=None):
     """GT-pose training (kubric_train_pose_3D.py): model returns 2t views per scene = [3v/2v cross views | all-view fusion]."""
     rendered_imgs, rendered_masks = model(sample, dataset, device)
     clips = sample["images"].to(device)
     masks = sample["fg_probabilities"].to(device)
     b, t, c, h, w = clips.shape
-    target_imgs, target_masks = clips.reshape(b * t, c, h, w), masks.reshape(b * t, 1, h, w)
+    target_imgs = clips.reshape(b * t, c, h, w)
     rendered_imgs = rendered_imgs.reshape(b, 2 * t, c, h, w)
     rendered_masks = rendered_masks.reshape(b, 2 * t, 1, h, w)
-    terms = {
-        "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
-        "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
-        "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
-        "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
-    }
+    if rendered_imgs.is_cuda:
+        # the four MSE terms (:26-29) as two fused passes over the rendered maps: no slicing / reshaping copies, one backward launch each
+        mi, mm = grouped_mse(rendered_imgs, clips, t), grouped_mse(rendered_masks, masks, t)
+        terms = {"recon_img_sv": config.loss.recon_rgb * mi[0], "recon_mask_sv": config.loss.recon_mask * mm[0],
+                 "recon_img_mv": config.loss.recon_rgb * mi[1], "recon_mask_mv": config.loss.recon_mask * mm[1]}
+    else:
+        target_masks = masks.reshape(b * t, 1, h, w)
+        terms = {
+            "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
+            "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
+            "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
+            "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
+        }
     if config.loss.perceptual_img > 0:
         tgt = target_imgs.reshape(b, t, c, h, w).repeat(1, 2, 1, 1, 1).reshape(b * 2 * t, c, h, w)
         terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
@@ -54,14 +106,19 @@ def compute_all_loss_nvs(config, epoch, sample, dataset, model, losses, device, 
     t_all = t + clips_nvs.shape[1]
     rendered_imgs = rendered_imgs.reshape(b, t_all, c, h, w)
     rendered_masks = rendered_masks.reshape(b, t_all, 1, h, w)
-    terms = {
-        "recon_img": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t], clips),
-        "recon_mask": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t], masks),
-        "recon_img_nvs": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:], clips_nvs),
-        "recon_mask_nvs": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:], masks_nvs),
-        "pose": F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]),
-        "trans": F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]),
-    }
+    if rendered_imgs.is_cuda and t_all == 2 * t:
+        mi = grouped_mse(rendered_imgs, sample["images"].to(device), t)          # (input views, novel views) in one pass each
+        mm = grouped_mse(rendered_masks, sample["fg_probabilities"].to(device), t)
+        recon = {"recon_img": config.loss.recon_rgb * mi[0], "recon_mask": config.loss.recon_mask * mm[0],
+                 "recon_img_nvs": config.loss.recon_rgb * mi[1], "recon_mask_nvs": config.loss.recon_mask * mm[1]}
+    else:
+        recon = {
+            "recon_img": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t], clips),
+            "recon_mask": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t], masks),
+            "recon_img_nvs": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:], clips_nvs),
+            "recon_mask_nvs": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:], masks_nvs),
+        }
+    terms = dict(recon, pose=F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]), trans=F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]))
     if config.loss.perceptual_img > 0:
         tgt = torch.cat([clips, clips_nvs], dim=1).reshape(b * t_all, c, h, w)
         terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()

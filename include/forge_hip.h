@@ -55,6 +55,12 @@ const char* forge_last_error(void);
 int forge_rotate_fwd(const float* vox, const float* xf, const int* mode, float* out,
                      int n, int C, int D, int H, int W, forge_stream_t stream);
 
+/* forge_rotate_fwd with the view ordering of models/model.py:127-128 (`chose_selected(features_transformed, idxs)`) fused into the
+ * store: input volume i is written to output volume dst_slot[i] (a permutation of 0..n-1 on the device) instead of i - saves the
+ * gather copy of all warped volumes (84 MB read + written per 5-view scene). Inference only (no backward counterpart). */
+int forge_rotate_fwd_slots(const float* vox, const float* xf, const int* mode, const int* dst_slot, float* out,
+                           int n, int C, int D, int H, int W, forge_stream_t stream);
+
 /* models/rotate.py:64-89,132-135 on the device: poses [B][t][4][4] (row-major camera poses, view 0 = reference) ->
  * xf [B*t][12] = [R_T | t_T / half_extent] with T = P_0 P_i^-1 (general 4x4 inverse), mode [B*t] = (0,1,1,...).
  * Feeds forge_rotate_fwd without any host round trip. (Gradients w.r.t. poses go through the host-side torch
@@ -150,10 +156,6 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
  *            per tile; raw partial tiles go to splitk_ws[slice][M][Cout] and a second kernel sums them in a fixed order and
  *            applies the epilogue (epilogues 0 and 1 only). NULL disables it. Results are deterministic either way.
- *   cu_budget (0 = the whole chip, 256): the number of CUs the launch plan should count on. Launches that run CONCURRENTLY on
- *            several streams (the per-view ResNet trunks of one scene, forge_amd/encoder.py) pass 256 / streams so that the plan
- *            neither over-splits K nor picks tiles for a chip it does not own. Affects speed only, never results' validity
- *            (tile / split-K choice changes the fp32 summation order).
  *   M = n D H W must be < 2^31.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
@@ -162,7 +164,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, int lift, int cu_budget, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
+                     int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
 
 /* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
  * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
@@ -170,7 +172,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
  * taps per phase). Pure host arithmetic (a makespan model of the 256-CU chip), no launch; lets a
  * caller size the split-K workspace (ksplit * M * Cout floats) and lets profilers attribute launches to kernel instantiations. */
 int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
-                          int cu_budget, int* tile, int* ksplit);
+                          int* tile, int* ksplit);
 
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
  *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)
@@ -235,6 +237,23 @@ int forge_im2col_nchw(const float* img, float* out, int N, int C, int H, int W, 
                       int Kpad, forge_stream_t stream);
 int forge_maxpool2d_nhwc(const float* in, float* out, int N, int H, int W, int C, int k, int stride, int pad,
                          forge_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * f1  squared-error sums of the reconstruction losses (scripts/kubric_compute_loss.py:26-29, 136-139: four F.mse_loss terms on
+ * reshaped / repeated tensors) in one pass over the rendered maps, and their backward.
+ *   pred    [B][Vp][C][H][W] addressed with element strides (sn per view, sc, sh, sw): the rgb maps are channels-last memory behind
+ *           an NCHW view (conv_rgb's output), the masks plain NCHW
+ *   target  [B][Vt][C][H][W] contiguous; rendered view v of scene b is compared with target view v % Vt and counted in group
+ *           v / gsize (GT-pose model: Vp = 2t, Vt = gsize = t; joint model: Vp = Vt = 2t, gsize = t); at most 4 groups
+ *   fwd     partial [forge_sse_groups_blocks()][G]: per-workgroup sums of (pred - target)^2 (fixed reduction tree; the caller adds
+ *           the rows in a fixed order: deterministic, no atomics)
+ *   bwd     dpred (same layout as pred) = coef[group] * (pred - target)
+ */
+int forge_sse_groups_blocks(void);
+int forge_sse_groups_fwd(const float* pred, long long sn, long long sc, long long sh, long long sw, const float* target,
+                         float* partial, int B, int Vp, int Vt, int gsize, int C, int H, int W, forge_stream_t stream);
+int forge_sse_groups_bwd(const float* pred, long long sn, long long sc, long long sh, long long sw, const float* target,
+                         const float* coef, float* dpred, int B, int Vp, int Vt, int gsize, int C, int H, int W, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.

@@ -81,7 +81,7 @@ def test_module_surface_names():
     import inspect
     assert list(inspect.signature(m.render.forward).parameters)[:5] == [
         "camera_params", "feature_3d", "density_3d", "render_depth", "return_origin_proj"]
-    assert list(inspect.signature(m.rotate.forward).parameters) == ["voxels", "camPoses_cv2", "grid_size"]
+    assert list(inspect.signature(m.rotate.forward).parameters)[:3] == ["voxels", "camPoses_cv2", "grid_size"]     # + optional `order` extension
     assert list(inspect.signature(m.forward).parameters) == ["sample", "dataset", "device"]
 
 

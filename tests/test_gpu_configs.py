@@ -265,7 +265,7 @@ def test_config3_grid64_training_step_vs_oracle_autograd(dev):
     oi, om = fo.reconstruct_from_features(fr, P, E, K, wo, cfg, training=True, order_by_distance=True)
     lo = 5.0 * torch.nn.functional.mse_loss(oi, tgt_i) + torch.nn.functional.mse_loss(om, tgt_m)
     lo.backward()
-    assert abs(loss.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item()))
+    assert abs(loss.item() - lo.item()) < 1e-4 * max(1.0, abs(lo.item())), (loss.item(), lo.item())
     named = dict(model.named_parameters())
     gscale = max(wo[k].grad.abs().max().item() for k in keys)
     for k in keys:
@@ -273,10 +273,14 @@ def test_config3_grid64_training_step_vs_oracle_autograd(dev):
         err = (named[k].grad.cpu() - ref).abs().max().item()
         assert err < 1e-2 * max(ref.abs().max().item(), 1e-1 * gscale), (k, err, ref.abs().max().item())
     # input-feature gradient: relative L2 (a max-norm bound is meaningless here - where a LeakyReLU pre-activation sits within fp32
-    # noise of 0 the two implementations pick different slopes (1 vs 0.01) and the gradient of a few isolated voxels differs by O(1))
+    # noise of 0 the two implementations pick different slopes (1 vs 0.01) and the gradient of a few isolated voxels differs by O(1)).
+    # This quantity is ill-conditioned in fp32 at this size (train-mode BatchNorm over 262144 voxels): tools/debug/config3_f64.py measured
+    # fp32 oracle vs float64 oracle 1.0e-2, HIP vs float64 oracle 1.4e-2, HIP vs fp32 oracle 1.0e-2 - the bound is 3 x the oracle's own error.
     gf = fd.grad.cpu()
-    assert (gf - fr.grad).norm().item() < 5e-3 * fr.grad.norm().item()
-    assert ((gf - fr.grad).abs() > 1e-2 * fr.grad.abs().max()).float().mean().item() < 1e-4
+    l2 = (gf - fr.grad).norm().item() / fr.grad.norm().item()
+    frac = ((gf - fr.grad).abs() > 1e-2 * fr.grad.abs().max()).float().mean().item()
+    per_view = [((gf[:, v] - fr.grad[:, v]).norm() / fr.grad[:, v].norm().clamp_min(1e-30)).item() for v in range(t)]
+    assert l2 < 3e-2 and frac < 3e-4, (l2, frac, per_view)
 
 
 # ------------------------------------------------------------------------------------------------------------- f4
@@ -418,3 +422,28 @@ def test_frozen_eval_paths_equal_autograd_paths(dev):
             assert ((u - v).abs() > 1e-2 * v.abs().max()).float().mean().item() < 1e-4, name
         else:
             assert rel(u, v) < 2e-4, (name, rel(u, v))
+
+
+def test_grouped_mse_equals_four_mse_losses(dev):
+    """f1: the fused squared-error pass (csrc/loss.hip) == the reference's four F.mse_loss terms (scripts/kubric_compute_loss.py:26-29),
+    values and gradients, for the channels-last rgb layout conv_rgb produces and the plain-NCHW mask layout; both view-group mappings
+    (GT-pose model: 2t rendered views vs t targets; joint model: t + t rendered vs t + t targets)."""
+    import torch.nn.functional as F
+    from forge_amd.train import grouped_mse
+    g = torch.Generator().manual_seed(12)
+    b, t, h, w = 2, 5, 24, 40
+    for c, cl in ((3, True), (1, False)):
+        for Vt in (t, 2 * t):
+            base = torch.rand(b * 2 * t, c, h, w, generator=g).to(dev)
+            if cl:
+                base = base.contiguous(memory_format=torch.channels_last)
+            tgt = torch.rand(b, Vt, c, h, w, generator=g).to(dev)
+            p1 = base.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            p2 = base.clone(memory_format=torch.preserve_format).requires_grad_(True)
+            m = grouped_mse(p1.reshape(b, 2 * t, c, h, w), tgt, t)
+            r = p2.reshape(b, 2 * t, c, h, w)
+            ref = torch.stack([F.mse_loss(r[:, :t], tgt[:, :t]), F.mse_loss(r[:, t:], tgt[:, :t] if Vt == t else tgt[:, t:])])
+            assert (m - ref).abs().max().item() < 1e-6 * max(1.0, ref.abs().max().item())
+            (5.0 * m[0] + 0.3 * m[1]).backward()
+            (5.0 * ref[0] + 0.3 * ref[1]).backward()
+            assert (p1.grad - p2.grad).abs().max().item() < 1e-6 * p2.grad.abs().max().item() + 1e-9

@@ -209,7 +209,8 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
         o_ld = gate_w if epilogue == EPI_GRU_GATES else ldo
         _lib.check(L.forge_conv_igemm(
             off(in1, s0 * b1 * ld1), C1, ld1, int(bs1), off(in2, s0 * b2 * ld2), C2, ld2, int(bs2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(scale),
-            _lib.ptr(shift), float(slope), off(residual, orow * (Cout if lift else ldo)), off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
+            _lib.ptr(shift), float(slope), off(residual, orow * (Cout if (lift or epilogue in (EPI_GRU_GATES, EPI_GRU_OUT)) else ldo)),
+            off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
             off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
             arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st),
             "forge_conv_igemm")
@@ -222,12 +223,24 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
 # ------------------------------------------------------------------------------------------------------------------
 @_lib.on_tensor_device
 def conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, in_grid, Cout, taps, istride=1, bs1=0, bs2=0):
+    """dwp += weight gradient (forge_conv_wgrad; dwp zero-filled by the caller, accumulated with atomics). Batches whose operands span
+    2 GiB or more (32-bit buffer offsets in the kernel) are accumulated in batch chunks, as conv_igemm launches them."""
     n, D, H, W = grid
     Di, Hi, Wi = in_grid
-    p = _lib.ptr
-    _lib.check(_lib.lib().forge_conv_wgrad(p(dy), dy.shape[-1], p(x1), C1, x1.shape[-1], int(bs1), p(x2), C2, 0 if x2 is None else x2.shape[-1],
-                                           int(bs2), p(dwp), n, D, H, W, istride, Di, Hi, Wi, Cout, _taps_array(taps), len(taps),
-                                           _lib.current_stream()), "forge_conv_wgrad")
+    in_rows, out_rows = Di * Hi * Wi, D * H * W
+    ldy, ld1, ld2 = dy.shape[-1], x1.shape[-1], (0 if x2 is None else x2.shape[-1])
+    b1, b2 = (int(bs1) or in_rows), (int(bs2) or in_rows)
+    span = lambda k, br, ld, rows: ((k - 1) * br + rows) * ld * 4
+    nc = n
+    while nc > 1 and (span(nc, out_rows, ldy, out_rows) > MAX_OPERAND_BYTES or span(nc, b1, ld1, in_rows) > MAX_OPERAND_BYTES
+                      or (x2 is not None and span(nc, b2, ld2, in_rows) > MAX_OPERAND_BYTES)):
+        nc = (nc + 1) // 2
+    off = lambda t, floats: None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * floats)
+    for s0 in range(0, n, nc):
+        k = min(nc, n - s0)
+        _lib.check(_lib.lib().forge_conv_wgrad(off(dy, s0 * out_rows * ldy), ldy, off(x1, s0 * b1 * ld1), C1, ld1, int(bs1), off(x2, s0 * b2 * ld2), C2, ld2,
+                                               int(bs2), _lib.ptr(dwp), k, D, H, W, istride, Di, Hi, Wi, Cout, _taps_array(taps), len(taps),
+                                               _lib.current_stream()), "forge_conv_wgrad")
     return dwp
 
 

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                                 a.out[orow * a.ldo + col] = v;
                             }
                         } else if constexpr (EPI == EPI_GRU_GATES) {
+                            if (a.residual) v += a.residual[orow * a.ldr + col];       // precomputed input half conv(x, W_x) (shared across fusions)
                             const float g = 1.f / (1.f + __expf(-v));
                             if (col < Ch) a.out[orow * Ch + col] = g;
                             else {
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                                 if (a.out3) a.out3[orow * Ch + (col - Ch)] = g;
                             }
                         } else {   // EPI_GRU_OUT
+                            if (a.residual) v += a.residual[orow * a.ldr + col];
                             const float cand = tanhf(v);
                             const float z = a.aux_z[orow * a.Cout + col], h = a.aux_h[orow * a.Cout + col];
                             const float hn = h * (1.f - z) + cand * z;
@@ -729,7 +731,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
     a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
-                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = lift > 0 ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = (lift > 0 || epilogue == EPI_GRU_GATES || epilogue == EPI_GRU_OUT) ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.out3 = out3; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     a.nphase = 1; a.tpp = ntaps;

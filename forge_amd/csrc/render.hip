@@ -202,8 +202,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
 // transmittance is an inclusive prefix product across the sample lanes (shuffle-up by 4, 8, 16, 32 lanes), the chunk-to-chunk carry is
 // the last lane's product, and a chunk is skipped / the march ends when every lane's transmittance is exactly 0 (wave-uniform test).
 // Same early-out rules as render_fwd_kernel (ray/AABB sample interval, T == 0); the summation is a per-lane partial sum + a tree, so
-// results agree with the sequential march to fp32 rounding, not bit for bit. Selected with FORGE_RENDER_WAVE=1 (tools/render_probe.py);
-// measured in round 2: see the numbers there for which one is the default.
+// results agree with the sequential march to fp32 rounding, not bit for bit. Selected with FORGE_RENDER_WAVE=1 (tools/render_probe.py,
+// tools/pmc_render.sh). Measured in round 2: 0.147 vs 0.097 ms for 5 views of a 64^3 volume, 0.176 vs 0.130 ms at 128^3, 1.01 vs 0.71 ms for
+// 28 views at 128^3, with 1.4-2.4x the L2 fills (samples along one ray share no voxel rows; the quads of neighbouring rays do) - the
+// sequential quad march stays the default.
 __global__ __launch_bounds__(256) void render_fwd_wave_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
                                                               const float* __restrict__ cams, const int* __restrict__ view2vol,
                                                               float* __restrict__ out_feat, float* __restrict__ out_opac,
@@ -253,7 +255,8 @@ __global__ __launch_bounds__(256) void render_fwd_wave_kernel(const float4* __re
             const float q = __shfl_up(p, off, 64);
             if (lane >= off) p *= q;
         }
-        const float Texcl = Tin * (sl == 0 ? 1.f : __shfl_up(p, 4, 64));   // transmittance in front of this sample
+        const float pprev = __shfl_up(p, 4, 64);                            // executed by ALL lanes (a divergent shuffle reads inactive lanes)
+        const float Texcl = Tin * (sl == 0 ? 1.f : pprev);                  // transmittance in front of this sample
         const float wgt = d * Texcl;
         acc = f4_fma(wgt, f, acc);
         depth = fmaf(wgt, z, depth);
@@ -614,7 +617,8 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
                                 float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
     if (int rc = check_render_args("forge_render_fwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
     FORGE_REQUIRE(out_feat && out_opac, FORGE_EINVAL, "forge_render_fwd: null output pointer");
-    static const int wave_variant = getenv("FORGE_RENDER_WAVE") ? atoi(getenv("FORGE_RENDER_WAVE")) : 0;      // A/B: one wave per ray, lanes = samples
+    const char* wv = getenv("FORGE_RENDER_WAVE");                       // A/B switch, read per call: one wave per ray, lanes = samples
+    const int wave_variant = wv ? atoi(wv) : 0;
     if (wave_variant && C == 16) {
         dim3 grid((Wr + 1) / 2, (Hr + 1) / 2, V);
         hipLaunchKernelGGL(render_fwd_wave_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam, view2vol, out_feat,
@@ -625,7 +629,8 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
         dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
-        static const int xcd_order = getenv("FORGE_RENDER_XCD_ORDER") ? atoi(getenv("FORGE_RENDER_XCD_ORDER")) : 0;   // 1: XCD-contiguous tiles (A/B)
+        const char* xo = getenv("FORGE_RENDER_XCD_ORDER");               // A/B switch, read per call: 1 = XCD-contiguous tiles
+        const int xcd_order = xo ? atoi(xo) : 0;
         hipLaunchKernelGGL(render_fwd_kernel<C4>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam,
                            view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, xcd_order);
     });

@@ -215,12 +215,21 @@ class Encoder3D(co.PackedModule):
         return self.fusion_feature.fuse_autograd_hip(x)                 # training: HIP convs with autograd
 
     def fuse_groups(self, x, groups):
-        """[self.fuse(x[:, g]) for g in groups], sharing the per-view work between the groups where that pays: with an autograd graph on
-        the MI355X the input halves of the GRU convolutions are computed once per view (ConvGRU_3D.fuse_groups_autograd_hip)."""
-        if (not hip_inference(self, x)) and self.fusion_feature.n_layers == 1 and len(groups) > 1:
+        """[self.fuse(x[:, g]) for g in groups], sharing the per-view work between the groups: the input halves of the GRU convolutions
+        are computed once per view (ConvGRU_3D.fuse_groups_hip in inference, fuse_groups_autograd_hip in training)."""
+        if self.fusion_feature.n_layers == 1 and len(groups) > 1:
             require_hip_input("Encoder3D.fuse_groups", x)
-            return self.fusion_feature.fuse_groups_autograd_hip(x, groups)
-        return [self.fuse(x[:, list(g)]) for g in groups]
+            if hip_inference(self, x):
+                return self.fusion_feature.fuse_groups_hip(x, groups)
+            if not frozen_eval(self.fusion_feature, x):
+                return self.fusion_feature.fuse_groups_autograd_hip(x, groups)
+        return [self.fuse(self._views(x, g)) for g in groups]
+
+    @staticmethod
+    def _views(x, g):
+        """x[:, g] for a list of view indices - as a slice when they form a run (no index tensor: capturable into a hipGraph)."""
+        g = list(g)
+        return x[:, g[0]:g[0] + len(g)] if g == list(range(g[0], g[0] + len(g))) else x[:, g]
 
     @staticmethod
     def _bn2d_rows(bn, rows, relu=True):

@@ -389,6 +389,55 @@ class ConvGRU_3D(co.PackedModule):
             h, h2 = h2, h
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
+    def fuse_groups_hip(self, x, groups):
+        """Several fusions over subsets of the SAME views in inference (FORGE_poseEstimator3D fuses views (0,1,2), (3,4) and (0..4) of
+        the same rotated features, models/model_single_pose_estimator.py:108-120): conv([x, h], W) = conv(x, W_x) + conv(h, W_h), so the
+        input halves of both GRU convolutions are computed ONCE per view (two launches per view) and every (group, view) step then runs
+        the hidden-state halves only, the input half entering the fused GRU epilogues as a residual - 25 % fewer GRU FLOPs for the
+        three fusions. Same arithmetic as fuse_hip up to the order of the fp32 additions. Returns one fused volume per group."""
+        assert self.n_layers == 1 and self.input_size == self.hidden_size
+        require_hip_input("ConvGRU_3D.fuse_groups_hip", x, x.shape[2])
+        b, t, C, D, H, W = x.shape
+        xr = x.permute(0, 1, 3, 4, 5, 2)
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        p = self._packed()
+        if "gate_wx" not in p:                                         # W = (W_x | W_h) along Cin
+            p.update({"gate_wx": p["gate_w"][:, :, :C].contiguous(), "gate_wh": p["gate_w"][:, :, C:].contiguous(),
+                      "out_wx": p["out_w"][:, :, :C].contiguous(), "out_wh": p["out_w"][:, :, C:].contiguous()})
+        dev, M, vol = x.device, b * D * H * W, D * H * W
+        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        used = sorted({ti for g in groups for ti in g})
+        gx, cx = {}, {}
+        for ti in used:                                                # input halves, once per view (no bias: added with the hidden half)
+            gx[ti], cx[ti] = new(2 * C), new()
+            co.conv_igemm(xr[:, ti], C, C, None, 0, 0, p["gate_wx"], None, None, None, 1.0, None, None, None, gx[ti], None, grid, ig, 2 * C, 2 * C, taps,
+                          epilogue=co.EPI_BIAS, bs1=t * vol)
+            co.conv_igemm(xr[:, ti], C, C, None, 0, 0, p["out_wx"], None, None, None, 1.0, None, None, None, cx[ti], None, grid, ig, C, C, taps,
+                          epilogue=co.EPI_BIAS, bs1=t * vol)
+        outs = []
+        for grp in groups:
+            grp = list(grp)
+            if grp == list(range(grp[0], grp[0] + len(grp))):          # a run of views: a slice (no index tensor: capturable into a hipGraph)
+                mean = xr[:, grp[0]:grp[0] + len(grp)].mean(dim=1).reshape(M, C)
+            else:
+                mean = torch.stack([xr[:, ti] for ti in grp], dim=1).mean(dim=1).reshape(M, C)
+            t0, h = new(), new()
+            co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, grid, ig, C, C, taps,
+                          epilogue=co.EPI_AFFINE_ACT)
+            co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, grid, ig, C, C, taps,
+                          epilogue=co.EPI_AFFINE_ACT)
+            z, hr, h2, out = new(), new(), t0, new()
+            for k, ti in enumerate(grp):
+                co.conv_igemm(h, C, C, None, 0, 0, p["gate_wh"], p["gate_b"], None, None, 1.0, gx[ti], h, None, z, hr, grid, ig, 2 * C, C, taps,
+                              epilogue=co.EPI_GRU_GATES)
+                last = k == len(grp) - 1
+                co.conv_igemm(hr, C, C, None, 0, 0, p["out_wh"], p["out_b"], p["norm"][0], p["norm"][1], 1.0, cx[ti], h, z, h2, out if last else None,
+                              grid, ig, C, C, taps, epilogue=co.EPI_GRU_OUT)
+                h, h2 = h2, h
+            outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
+        return outs
+
     # ---------------------------------------------------------------- HIP training / autograd path
     @staticmethod
     def _bn_rows(bn, rows, act=None):

@@ -32,6 +32,39 @@ class FORGE_poseEstimator3D(nn.Module):
         self.rotate = Rotate_world(config)
         self.encoder_traj = PoseEstimator3D(config)
 
+    def reconstruct(self, features_raw, camPoses_cv2, cameras):
+        """a2..a7 of models/model_single_pose_estimator.py:101-133 on given per-view feature volumes features_raw [b,t,C,D,D,D]: pose warp,
+        the three fusions (first 3 views, last 2 views, all views), both heads on the three fused volumes, ray-march of the 2t cameras of
+        `cameras` (scene-major: 3 cameras on the 2-view volume, 2 on the 3-view volume, t on the all-view volume) and conv_rgb.
+        D = 32 is what the encoder produces; D = 64 is the reference's large grid (models/rotate.py:115-117 -> 128^3 render volume,
+        BASELINE configs[3]), fed with synthetic feature volumes by tools/train_step_probe.py TRAIN_GRID=64.
+        Returns (rgb [b*2t,3,img,img], masks [b*2t,1,img,img], origin_proj [b*2t,2])."""
+        b, t, C, D = features_raw.shape[:4]
+        device = features_raw.device
+        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D)
+
+        # three fusions: first 3 views, last 2 views, all views (:108-109, :120)
+        features_3v, features_2v, features_mv = self.encoder_3d.fuse_groups(
+            features_transformed, [list(range(min(3, t))), list(range(max(t - 2, 0), t)), list(range(t))])
+        if self.encoder_3d.training:
+            # BatchNorm batch statistics (and the running-stat updates) follow the reference's call structure: the heads run on
+            # cat([3v, 2v]) (:110-111) and on the all-view volume (:121-122) SEPARATELY - one 3b batch would normalise differently
+            f32 = torch.cat([features_3v, features_2v], dim=0)
+            r32, d32 = self.encoder_3d.heads(f32)
+            rm, dm = self.encoder_3d.heads(features_mv)
+            densities, features = torch.cat([d32, dm], dim=0), torch.cat([r32, rm], dim=0)
+        else:
+            fused = torch.cat([features_3v, features_2v, features_mv], dim=0)          # eval BN: one [3b,128,D,H,W] batch is the same arithmetic
+            features, densities = self.encoder_3d.heads(fused)                         # [3b,16,2D,..], [3b,1,2D,..]
+        if self.config.dataset.name == "omniobject3d":
+            densities = densities.clamp(min=0.0, max=1.0)
+
+        # view order per scene (:112-129): 2v volume x3 cams, 3v volume x2 cams, mv volume x t cams
+        scene = torch.arange(b, device=device, dtype=torch.int32)[:, None]
+        per_scene = torch.cat([(b + scene).expand(b, 3), scene.expand(b, 2), (2 * b + scene).expand(b, t)], dim=1)
+        view2vol = per_scene.reshape(b * 2 * t).contiguous()
+        return self.render(cameras, features, densities, return_origin_proj=True, view2vol=view2vol)
+
     def forward(self, sample, dataset, device):
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
         clips = sample["images"]
@@ -60,31 +93,7 @@ class FORGE_poseEstimator3D(nn.Module):
             origin_proj = self.render.proj_origin(cameras, device)
             return camPose_return, 2 * origin_proj / self.config.dataset.img_size
 
-        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2[:, :t], grid_size=D)
-
-        # three fusions: first 3 views, last 2 views, all views (:108-109, :120)
-        features_3v, features_2v, features_mv = self.encoder_3d.fuse_groups(
-            features_transformed, [list(range(min(3, t))), list(range(max(t - 2, 0), t)), list(range(t))])
-        if self.encoder_3d.training:
-            # BatchNorm batch statistics (and the running-stat updates) follow the reference's call structure: the heads run on
-            # cat([3v, 2v]) (:110-111) and on the all-view volume (:121-122) SEPARATELY - one 3b batch would normalise differently
-            f32 = torch.cat([features_3v, features_2v], dim=0)
-            r32, d32 = self.encoder_3d.heads(f32)
-            rm, dm = self.encoder_3d.heads(features_mv)
-            densities, features = torch.cat([d32, dm], dim=0), torch.cat([r32, rm], dim=0)
-        else:
-            fused = torch.cat([features_3v, features_2v, features_mv], dim=0)          # eval BN: one [3b,128,D,H,W] batch is the same arithmetic
-            features, densities = self.encoder_3d.heads(fused)                         # [3b,16,2D,..], [3b,1,2D,..]
-        if self.config.dataset.name == "omniobject3d":
-            densities = densities.clamp(min=0.0, max=1.0)
-
-        # view order per scene (:112-129): 2v volume x3 cams, 3v volume x2 cams, mv volume x t cams
-        scene = torch.arange(b, device=device, dtype=torch.int32)[:, None]
-        per_scene = torch.cat([(b + scene).expand(b, 3), scene.expand(b, 2), (2 * b + scene).expand(b, t)], dim=1)
-        view2vol = per_scene.reshape(b * 2 * t).contiguous()
-
-        rendered_imgs, rendered_masks, origin_proj = self.render(cameras, features, densities,
-                                                                 return_origin_proj=True, view2vol=view2vol)
+        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras)
         if self.config.train.use_gt_pose:
             return rendered_imgs, rendered_masks
         return rendered_imgs, rendered_masks, 2 * origin_proj / self.config.dataset.img_size, camPose_return

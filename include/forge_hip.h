@@ -145,6 +145,8 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *                                        out2[m][c] = aux_h[m][c] * sigmoid(v_{Ch+c})  (h * reset)
  *            3  GRU state: hn = aux_h (1 - aux_z) + tanh(v) aux_z; out = hn;
  *                          out2 (nullable) = hn * scale + shift          (fusion_norm on the last step)
+ *            epilogues 2 / 3 add `residual` [rows][Cout] (nullable) to the pre-activation: the input half conv(x, W_x) of
+ *            conv([x, h], W) = conv(x, W_x) + conv(h, W_h), computed once per view when several fusions share views.
  *   out3 (nullable, epilogues 2 / 3 only): what a hand-written backward of the fused cell needs besides out / out2 -
  *            epilogue 2: the reset gate sigmoid(v_{Ch+c}) [M][Ch]; epilogue 3: the candidate tanh(v) [M][Cout]
  *            (pose refinement with frozen weights runs the fused epilogues in forward, forge_amd/fusion.py).

@@ -447,3 +447,79 @@ def test_grouped_mse_equals_four_mse_losses(dev):
             (5.0 * m[0] + 0.3 * m[1]).backward()
             (5.0 * ref[0] + 0.3 * ref[1]).backward()
             assert (p1.grad - p2.grad).abs().max().item() < 1e-6 * p2.grad.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("env", [{"FORGE_RENDER_WAVE": "1"}, {"FORGE_RENDER_XCD_ORDER": "1"}])
+def test_render_ab_variants_match_default(dev, env, monkeypatch):
+    """The two ray-march A/B variants kept behind environment switches (wave-per-ray with a shuffle prefix product; XCD-contiguous
+    tile order) render the same images as the default kernel: XCD order bit for bit (placement only), wave-per-ray to fp32 rounding
+    (tree vs sequential products / sums) - plus the analytic KATs through the wave variant."""
+    feat, dens = syn.blob_volumes(2, 32, 16, seed=4)
+    _, extr, _ = syn.orbit_cameras(6, 1.5, 15.0)
+    E = extr[[0, 2, 3, 5]]
+    Kh = fo.halve_intrinsics(syn.intrinsics(128)[None].repeat(4, 1, 1))
+    cam = torch.cat([E[:, :3, :3].reshape(4, 9), E[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1).to(dev)
+    v2v = torch.tensor([0, 1, 1, 0], dtype=torch.int32, device=dev)
+    h = fo.grid_half_extent(32, 1.0)
+    args = (feat.to(dev), dens.to(dev), cam, v2v, 64, 64, 64, 0.5, 2.0, (h, h, h), True)
+    base = [o.clone() for o in ops.render_rays(*args)]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = ops.render_rays(*args)
+    for a, b in zip(got, base):
+        if "FORGE_RENDER_XCD_ORDER" in env:
+            assert torch.equal(a, b)
+        else:
+            assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item())
+    if "FORGE_RENDER_WAVE" in env:
+        case = [c for c in kat_render.cases() if c["name"] == "slab_cubic"][0]
+        cam_k = case["cam"]
+        f16 = torch.from_numpy(case["feat"]).float().repeat(4, 1, 1, 1)[None].to(dev)                      # 16 channels: the variant's shape
+        d = torch.from_numpy(case["dens"]).float()[None, None].to(dev)
+        c16 = torch.tensor(list(cam_k["R"].reshape(9)) + list(cam_k["T"]) + [cam_k["fx"], cam_k["fy"], cam_k["cx"], cam_k["cy"]], dtype=torch.float32)[None]
+        hk = 0.5 * 15 / 16
+        of, oo, od = ops.render_rays(f16, d, c16.to(dev), torch.zeros(1, dtype=torch.int32, device=dev), case["Hr"], case["Wr"], case["S"],
+                                     case["zmin"], case["zmax"], (hk, hk, hk), True)
+        kat_render.check(case, torch.cat([of[:, :4], oo, od], dim=1)[0].permute(1, 2, 0).cpu().numpy())
+
+
+def test_fuse_groups_inference_shares_input_halves(dev):
+    """FORGE_poseEstimator3D's three fusions in INFERENCE with the input halves of the GRU convolutions computed once per view
+    (ConvGRU_3D.fuse_groups_hip: residual operand of the fused GRU epilogues) against three independent fuse_hip calls and the oracle:
+    2e-4 of the max (fp32 summation order: conv(x, W_x) + conv(h, W_h) vs conv([x, h], W))."""
+    from forge_amd.model import FORGE
+    model, w, _ = _model(FORGE, dev)
+    x = (torch.randn(2, 5, 128, 8, 8, 8, generator=torch.Generator().manual_seed(21)) * 0.5)
+    groups = [[0, 1, 2], [3, 4], [0, 1, 2, 3, 4]]
+    with torch.no_grad():
+        shared = model.encoder_3d.fuse_groups(x.to(dev), groups)
+        for g, s in zip(groups, shared):
+            sep = model.encoder_3d.fuse(x[:, g].to(dev))
+            ref = fo.fuse(x[:, g], w)
+            scale = max(1.0, ref.abs().max().item())
+            assert (s - sep).abs().max().item() < 2e-4 * scale and (s.cpu() - ref).abs().max().item() < 2e-4 * scale
+
+
+def test_conv_wgrad_batch_chunking(dev, monkeypatch):
+    """convops.conv_wgrad accumulates batches whose operands exceed the kernel's 2 GiB buffer range in batch chunks (needed by the
+    128^3-voxel training step at 4 scenes per GPU): with the limit lowered so that 5 volumes split 2 + 2 + 1, the weight gradient equals
+    the single launch (fp32 atomics: 1e-5 of the max) - two-input form with a batch-strided first operand."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(6)
+    n, D, C = 5, 8, 128
+    xs = torch.randn(n, 2, D, D, D, C, generator=g).to(dev)                    # views stacked: x1 = xs[:, 1] has a batch stride
+    x1, h = xs[:, 1], torch.randn(n, D, D, D, C, generator=g).to(dev)
+    dy = torch.randn(n, D, D, D, 2 * C, generator=g).to(dev)
+    bs1 = co._batch_stride_rows(x1)
+
+    def run():
+        dw = torch.zeros(27, 2 * C, 2 * C, device=dev)
+        co.conv_wgrad(dy, x1, C, h, C, dw, (n, D, D, D), (D, D, D), 2 * C, co.TAPS_3x3x3, bs1=bs1)
+        return dw
+    ref = run()
+    monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 2 * D ** 3 * 2 * C * 4 + 1)     # two volumes of dy per launch
+    got = run()
+    assert (got - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+    want = torch.nn.grad.conv3d_weight(torch.cat([x1, h], dim=-1).permute(0, 4, 1, 2, 3).contiguous(), (2 * C, 2 * C, 3, 3, 3),
+                                       dy.permute(0, 4, 1, 2, 3).contiguous(), padding=1)
+    assert (got.permute(1, 2, 0).reshape(2 * C, 2 * C, 3, 3, 3) - want).abs().max().item() < 1e-3 * want.abs().max().item()

@@ -1,0 +1,8 @@
+set -x
+python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -k "render_ab or fuse_groups or forward_pose3d or pose3d_predicted or graphed" 2>&1 | tail -4
+python tools/pose3d_probe.py 2>&1 | grep -v amdgpu
+TRAIN_GRID=64 TRAIN_SCENES=1 TRAIN_STEPS=3 python tools/train_step_probe.py 2>&1 | tail -2
+TRAIN_GRID=64 TRAIN_SCENES=4 TRAIN_STEPS=2 python tools/train_step_probe.py 2>&1 | tail -2
+TRAIN_SCENES=4 TRAIN_STEPS=3 python tools/train_step_probe.py 2>&1 | tail -1
+TRAIN_SCENES=1 TRAIN_GRAPH=1 TRAIN_STEPS=5 python tools/train_step_probe.py 2>&1 | tail -1
+python tools/refine_probe.py 2>&1 | tail -1

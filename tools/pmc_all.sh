@@ -1,0 +1,53 @@
+# Round-2 PMC passes over tools/probe_kernels.py (rotate / ray-march / ConvGRU gates + state launches at the b=1 bench shapes), each counter
+# group in its own rocprofv3 run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised into
+# gpurun_out/r02_pmc_summary.json (copied to profiles/ by hand; bench.py reads profiles/*pmc_summary.json for roofline.traffic).
+cd /tmp && export TMPDIR=/tmp
+run() { timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcall_$1 -o p -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py > /dev/null 2>&1; }
+run FETCH FETCH_SIZE
+run WRITE WRITE_SIZE
+run SQ "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"
+cd $GRAFT_REPO_ROOT
+python - <<'PY'
+import csv, glob, json, collections
+def load(tag):
+    f = glob.glob("gpurun_out/pmcall_%s/**/*counter_collection.csv" % tag, recursive=True)
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f: return out
+    for r in csv.DictReader(open(f[0])):
+        out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+F, W, S = load("FETCH"), load("WRITE"), load("SQ")
+mean = lambda v: sum(v) / len(v) if v else None
+def pick(d, sub):
+    for k in d:
+        if sub in k: return k
+    return None
+summary = {"source": "tools/pmc_all.sh: separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ+GRBM) over tools/probe_kernels.py, 5 launches "
+                     "per kernel at the one-scene bench shapes; FETCH_SIZE / WRITE_SIZE are KiB; hbm_bytes_corrected = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                     "(gfx950 counts wide loads at half, MI355X_MICROARCH.md - these are L2->fabric bytes, Infinity-Cache hits included)"}
+alg = {"rotate_fwd_kernel": 5 * 128 * 32 ** 3 * 4 * 2, "render_fwd_kernel": 17 * 64 ** 3 * 4 + 5 * 17 * 128 * 128 * 4,
+       "conv_igemm_kernel<128, 128": 74280000.0, "conv_igemm_kernel<64, 64": 87100000.0}
+names = {"rotate_fwd_kernel": "rotate_fwd_kernel", "render_fwd_kernel": "render_fwd_kernel<4>",
+         "conv_igemm_kernel<128, 128": "conv_igemm_kernel<128, 128, 8> (ConvGRU gates, M=32768 N=256 K=6912)",
+         "conv_igemm_kernel<64, 64": "conv_igemm_kernel<64, 64, 4> (ConvGRU state, M=32768 N=128 K=6912)"}
+for sub, label in names.items():
+    e = {}
+    kf, kw, ks = pick(F, sub), pick(W, sub), pick(S, sub)
+    if kf: e["fetch_kib_raw"] = mean(F[kf]["FETCH_SIZE"])
+    if kw: e["write_kib"] = mean(W[kw]["WRITE_SIZE"])
+    if "fetch_kib_raw" in e and "write_kib" in e:
+        e["hbm_bytes_corrected"] = (2 * e["fetch_kib_raw"] + e["write_kib"]) * 1024
+    e["algorithmic_bytes"] = alg[sub]
+    if ks:
+        c = {k: mean(v) for k, v in S[ks].items()}
+        e.update({"mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"), "grbm_gui_active": c.get("GRBM_GUI_ACTIVE"), "sq_wave_cycles": c.get("SQ_WAVE_CYCLES"),
+                  "sq_wait_any": c.get("SQ_WAIT_ANY"), "lds_bank_conflict": c.get("SQ_LDS_BANK_CONFLICT")})
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+            e["mfma_util_in_kernel"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
+            e["wait_any_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    summary[label] = e
+json.dump(summary, open("gpurun_out/r02_pmc_summary.json", "w"), indent=1)
+print(json.dumps(summary, indent=1))
+PY
+rm -rf gpurun_out/pmcall_FETCH gpurun_out/pmcall_WRITE gpurun_out/pmcall_SQ

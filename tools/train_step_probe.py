@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Time one GT-pose training step (BASELINE configs[3] shape per GPU: FORGE_poseEstimator3D, b scenes x 5 views -> 10 rendered
-views/scene, MSE rgb+mask, grad-clip 10, Adam — scripts/kubric_trainer.py:51-59) on one MI355X."""
+views/scene, MSE rgb+mask (the fused squared-error pass of forge_amd.train), grad-clip 10, Adam - scripts/kubric_trainer.py:51-59) on one MI355X.
+TRAIN_GRID=64: the 128^3-voxel scenes of configs[3] - synthetic [b,5,128,64^3] feature volumes (the encoder cannot produce them from
+256^2 images) through FORGE_poseEstimator3D.reconstruct: rotate(D=64), three fusions, heads to 128^3, 10 ray-marched views, backward, Adam."""
 import os
 import sys
 import time
@@ -23,13 +25,26 @@ use_graph = os.environ.get("TRAIN_GRAPH", "0") == "1"       # capture fwd + bwd 
 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=use_graph)
 sample = {k: v.to(dev) for k, v in syn.make_sample(b, 5, 256, 1.5, seed=3).items()}
 ds = syn.SyntheticDataset(1.5)
-tgt_i = sample["images"].repeat(1, 2, 1, 1, 1).reshape(-1, 3, 256, 256)
-tgt_m = sample["fg_probabilities"].repeat(1, 2, 1, 1, 1).reshape(-1, 1, 256, 256)
+from forge_amd import geo_utils  # noqa: E402
+from forge_amd.train import grouped_mse  # noqa: E402
+grid = int(os.environ.get("TRAIN_GRID", "32"))
+if grid == 64:
+    feats = (torch.randn(b, 5, 128, 64, 64, 64, device=dev) * 0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+    cams = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"].repeat(1, 2, 1, 1), sample["K_cv2"].repeat(1, 2, 1, 1))
+    run_model = lambda: model.reconstruct(feats, sample["cam_poses_cv2_canonicalized"], cams)[:2]
+else:
+    run_model = lambda: model(sample, ds, dev)
+
+
+def loss_of(imgs, masks):
+    mi = grouped_mse(imgs.reshape(b, 10, 3, 256, 256), sample["images"], 5)
+    mm = grouped_mse(masks.reshape(b, 10, 1, 256, 256), sample["fg_probabilities"], 5)
+    return 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
 
 
 def step():
-    imgs, masks = model(sample, ds, dev)
-    loss = 5.0 * F.mse_loss(imgs, tgt_i) + F.mse_loss(masks, tgt_m)
+    imgs, masks = run_model()
+    loss = loss_of(imgs, masks)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
@@ -41,8 +56,8 @@ if use_graph:
     from forge_amd.graph import GraphedStep
 
     def graph_fn():
-        imgs, masks = model(sample, ds, dev)
-        loss = 5.0 * F.mse_loss(imgs, tgt_i) + F.mse_loss(masks, tgt_m)
+        imgs, masks = run_model()
+        loss = loss_of(imgs, masks)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
@@ -56,8 +71,8 @@ for _ in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("train step b=%d%s: %.1f ms/step, %.1f rendered views/s (fwd+bwd+Adam), loss %.5f, peak mem %.1f GB"
-      % (b, " (hipGraph replay)" if use_graph else "", dt * 1e3, b * 10 / dt, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
+print("train step grid=%d^3 b=%d%s: %.1f ms/step, %.1f rendered views/s (fwd+bwd+Adam), loss %.5f, peak mem %.1f GB"
+      % (2 * grid, b, " (hipGraph replay)" if use_graph else "", dt * 1e3, b * 10 / dt, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
 
 if os.environ.get("TRAIN_PROFILE"):
     # per-launch HIP-event timing of every conv GEMM / wgrad launch of one step, grouped by shape

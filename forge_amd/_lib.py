@@ -23,8 +23,9 @@ SIGNATURES = {
     "forge_last_error": [],
     "forge_rotate_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_rotate_fwd_slots": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "forge_rotate_xf_from_poses": [_P, _P, _P, _I, _I, _F, _P],
+    "forge_rotate_xf_from_poses": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_pack_cameras": [_P, _LL, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _LL, _P, _P, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 10 + [_P, _LL, _P],

@@ -288,12 +288,32 @@ __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __
 
 // poses [B][t][16] row-major camera poses -> xf [B*t][12], mode [B*t]: T = P_0 P_i^-1 (models/rotate.py:64-89, general
 // 4x4 inverse by cofactors — the reference calls torch.inverse), xf = [R_T | t_T / e] (rotate.py:132-135). One thread per view.
-__global__ void pose_xf_kernel(const float* __restrict__ poses, float* __restrict__ xf, int* __restrict__ mode, int B, int t, float e) {
+__global__ void pose_xf_kernel(const float* __restrict__ poses, float* __restrict__ xf, int* __restrict__ mode, int* __restrict__ slot,
+                               const float* __restrict__ dist_in, int B, int t, float e) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * t) return;
     const int v = i % t;
     float* o = xf + i * 12;
     mode[i] = v == 0 ? 0 : 1;
+    if (slot) {
+        // view order of models/model.py:152-158 (sort by squared distance of the camera position to view 0's): slot = rank of this view
+        // (ties: lower view index first), offset by the scene's first volume - the warp then stores view i at volume slot[i]
+        // keys: the caller's distances when given (torch's own reduction: near-ties of symmetric camera rigs must rank exactly as
+        // sequence_from_distance ranks them), else computed here without fused multiply-adds
+        const float* pb = poses + (long long)(i - v) * 16;
+        auto dist = [&](int j) {
+            if (dist_in) return dist_in[(i - v) + j];
+            const float dx = pb[j * 16 + 3] - pb[3], dy = pb[j * 16 + 7] - pb[7], dz = pb[j * 16 + 11] - pb[11];
+            return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        };
+        const float di = dist(v);
+        int rank = 0;
+        for (int j = 0; j < t; ++j) {
+            const float dj = dist(j);
+            rank += (dj < di || (dj == di && j < v)) ? 1 : 0;
+        }
+        slot[i] = (i - v) + rank;
+    }
     if (v == 0) {
 #pragma unroll
         for (int k = 0; k < 12; ++k) o[k] = 0.f;
@@ -325,6 +345,28 @@ __global__ void pose_xf_kernel(const float* __restrict__ poses, float* __restric
             for (int k = 0; k < 4; ++k) acc = fmaf(p0[r * 4 + k], inv[k * 4 + c], acc);
             o[r * 4 + c] = c == 3 ? acc / e : acc;
         }
+    }
+}
+
+// cameras_from_opencv_projection's inputs -> the ray-marcher's packed cameras (models/volume_render.py:40-51: K / 2 with K[2][2] = 1 on a
+// copy) and, optionally, the projected world origin (models/volume_render.py:77-79). One thread per camera; inputs may be strided views.
+__global__ void pack_cameras_kernel(const float* __restrict__ R, long long r0, long long r1, long long r2, const float* __restrict__ T, long long t0,
+                                    long long t1, const float* __restrict__ K, long long k0, long long k1, long long k2, float* __restrict__ cam,
+                                    float* __restrict__ origin, int V) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float* c = cam + v * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = R[v * r0 + i * r1 + j * r2];
+    const float tx = T[v * t0], ty = T[v * t0 + t1], tz = T[v * t0 + 2 * t1];
+    c[9] = tx; c[10] = ty; c[11] = tz;
+    const float fx = K[v * k0] / 2.0f, fy = K[v * k0 + k1 + k2] / 2.0f, cx = K[v * k0 + 2 * k2] / 2.0f, cy = K[v * k0 + k1 + 2 * k2] / 2.0f;
+    c[12] = fx; c[13] = fy; c[14] = cx; c[15] = cy;
+    if (origin) {
+        origin[v * 2] = fx * tx / tz + cx;
+        origin[v * 2 + 1] = fy * ty / tz + cy;
     }
 }
 
@@ -370,13 +412,21 @@ extern "C" int forge_rotate_fwd_slots(const float* vox, const float* xf, const i
     return rotate_fwd_launch(vox, xf, mode, dst_slot, out, n, C, D, H, W, stream);
 }
 
-extern "C" int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, int t, float half_extent,
-                                         forge_stream_t stream) {
+extern "C" int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int* slot, const float* dist, int B, int t,
+                                         float half_extent, forge_stream_t stream) {
     FORGE_REQUIRE(poses && xf && mode, FORGE_EINVAL, "forge_rotate_xf_from_poses: null pointer argument");
     FORGE_REQUIRE(B > 0 && t > 0 && half_extent > 0.f, FORGE_EINVAL, "forge_rotate_xf_from_poses: bad B=%d t=%d e=%g", B, t, half_extent);
     const int n = B * t;
-    hipLaunchKernelGGL(pose_xf_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, xf, mode, B, t, half_extent);
+    hipLaunchKernelGGL(pose_xf_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, xf, mode, slot, dist, B, t, half_extent);
     FORGE_LAUNCH_CHECK("forge_rotate_xf_from_poses");
+    return 0;
+}
+
+extern "C" int forge_pack_cameras(const float* R, long long r0, long long r1, long long r2, const float* T, long long t0, long long t1,
+                                  const float* K, long long k0, long long k1, long long k2, float* cam16, float* origin, int V, forge_stream_t stream) {
+    FORGE_REQUIRE(R && T && K && cam16 && V > 0, FORGE_EINVAL, "forge_pack_cameras: null pointer argument or V <= 0");
+    hipLaunchKernelGGL(pack_cameras_kernel, dim3((V + 63) / 64), dim3(64), 0, (hipStream_t)stream, R, r0, r1, r2, T, t0, t1, K, k0, k1, k2, cam16, origin, V);
+    FORGE_LAUNCH_CHECK("forge_pack_cameras");
     return 0;
 }
 

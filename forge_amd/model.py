@@ -29,7 +29,7 @@ from .volume_render import VolRender
 def sequence_from_distance(trans):
     """models/model.py:152-158 — translations [b,t,3] -> view order by squared distance to view 0."""
     dist = ((trans - trans[:, 0:1, :]) ** 2).sum(dim=-1)
-    return torch.sort(dist, descending=False)[1]
+    return torch.sort(dist, descending=False, stable=True)[1]      # stable: equal distances keep their view order (deterministic)
 
 
 def chose_selected(tensor, idxs):
@@ -66,15 +66,22 @@ class FORGE(nn.Module):
         Returns (rgb [b*V,3,img,img], masks [b*V,1,img,img], origin_proj [b*V,2])."""
         b, t, C, D = features_raw.shape[:4]
         device = features_raw.device
-        if idxs is None:
-            idxs = sequence_from_distance(camPoses_cv2[:, :, :3, 3])
-        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D, order=idxs)   # warp + chose_selected
+        # warp + view ordering (models/model.py:127-128) in one launch; idxs = None: by distance to view 0, ranked on the device
+        features_transformed = self.rotate(voxels=features_raw, camPoses_cv2=camPoses_cv2, grid_size=D, order="distance" if idxs is None else idxs)
         features_mv, densities_mv = self.encoder_3d.heads(self.encoder_3d.fuse(features_transformed))
         if self.config.dataset.name == "omniobject3d":
             densities_mv = densities_mv.clamp(min=0.0, max=1.0)
         V = cameras["R"].shape[0] // b
-        view2vol = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
-        return self.render(cameras, features_mv, densities_mv, return_origin_proj=True, view2vol=view2vol)
+        return self.render(cameras, features_mv, densities_mv, return_origin_proj=True, view2vol=self._view2vol(b, V, device))
+
+    def _view2vol(self, b, V, device):
+        """scene index of every rendered view (b*V int32), built once per (b, V, device): the fused volume of a scene is rendered by its V
+        cameras through this index instead of being repeated V times (models/model.py:138-139)."""
+        cache = self.__dict__.setdefault("_v2v", {})
+        key = (b, V, str(device))
+        if key not in cache:
+            cache[key] = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
+        return cache[key]
 
     def forward(self, sample, dataset, device):
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
@@ -99,7 +106,6 @@ class FORGE(nn.Module):
             camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t]
             camPoses_cv2 = sample["cam_poses_cv2" + suffix][:, :t]
             camPose_return = None
-        idxs = sequence_from_distance(camPoses_cv2[:, :, :3, 3])
 
         if self.config.train.parameter in ("pose", "pose_head"):                       # :98-114
             origin_proj = self.render.proj_origin(geo_utils.camera_dict(camE_cv2, sample["K_cv2"][:, :t]), device)
@@ -111,7 +117,7 @@ class FORGE(nn.Module):
         assert V == t_all, "sample must carry intrinsics for every rendered camera"
         cameras = geo_utils.camera_dict(camE_all, sample["K_cv2"])
 
-        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras, idxs)
+        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras)       # views ordered by distance
         if self.config.train.use_gt_pose:
             return rendered_imgs, rendered_masks
         return rendered_imgs, rendered_masks, 2 * origin_proj / self.config.dataset.img_size, camPose_return

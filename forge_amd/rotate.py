@@ -45,8 +45,10 @@ class Rotate_world(nn.Module):
     @_lib.on_tensor_device
     def forward(self, voxels, camPoses_cv2, grid_size=32, order=None):
         """voxels [B,t,C,D,H,W], camPoses_cv2 [B,t,4,4] -> [B,t,C,D,H,W] (view 0 unchanged).
-        order (extension, inference only): the view permutation of models/model.py:127-128 ([B,t] indices, out[:, j] = warped[:, order[:, j]])
-        applied by the kernel's store instead of a gather copy afterwards; ignored (None) by the reference's callers."""
+        order (extension): the view permutation of models/model.py:127-128 applied to the output, out[:, j] = warped[:, order[:, j]] -
+        either [B,t] indices or the string "distance" (= sequence_from_distance of the poses' camera positions). In inference the
+        kernel's store applies it (forge_rotate_fwd_slots; for "distance" the ranks are computed by the pose kernel: no sort / gather
+        launches at all); under autograd it is a gather on the result. The reference's callers never pass it."""
         B, t, C, D, H, W = voxels.shape
         if grid_size not in _SUPPORTED:
             raise ValueError("Rotate_world: grid_size %r not in %s (models/rotate.py:109-123)" % (grid_size, _SUPPORTED))
@@ -60,19 +62,24 @@ class Rotate_world(nn.Module):
             # whose LU + info check costs more host time than the whole warp)
             xf = torch.empty(B * t, 12, dtype=torch.float32, device=device)
             mode = torch.empty(B * t, dtype=torch.int32, device=device)
-            _lib.check(_lib.lib().forge_rotate_xf_from_poses(_lib.ptr(poses.contiguous()), _lib.ptr(xf), _lib.ptr(mode), B, t, e,
-                                                             _lib.current_stream()), "forge_rotate_xf_from_poses")
-            if order is not None and not voxels.requires_grad:
-                inv = torch.argsort(order.to(device), dim=1)                                # slot of view i in the ordered stack
-                slot = (inv + torch.arange(B, device=device)[:, None] * t).to(torch.int32).reshape(B * t).contiguous()
+            fused_order = order is not None and not voxels.requires_grad
+            by_distance = fused_order and isinstance(order, str)
+            slot = torch.empty(B * t, dtype=torch.int32, device=device) if by_distance else None
+            trans = poses[:, :, :3, 3]                                                      # keys exactly as sequence_from_distance computes them
+            dist = ((trans - trans[:, 0:1]) ** 2).sum(dim=-1).contiguous() if by_distance else None
+            _lib.check(_lib.lib().forge_rotate_xf_from_poses(_lib.ptr(poses.contiguous()), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(slot), _lib.ptr(dist),
+                                                             B, t, e, _lib.current_stream()), "forge_rotate_xf_from_poses")
+            if fused_order:
+                if not by_distance:
+                    inv = torch.argsort(order.to(device), dim=1)                            # slot of view i in the ordered stack
+                    slot = (inv + torch.arange(B, device=device)[:, None] * t).to(torch.int32).reshape(B * t).contiguous()
                 vox_cl = ops.to_channels_last_3d(voxels.reshape(B * t, C, D, H, W))
                 out = ops._empty_like_cl(vox_cl)
                 _lib.check(_lib.lib().forge_rotate_fwd_slots(_lib.ptr(vox_cl), _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(slot), _lib.ptr(out),
                                                              B * t, C, D, H, W, _lib.current_stream()), "forge_rotate_fwd_slots")
                 return out.reshape(B, t, C, D, H, W)
             out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode)
-            out = out.reshape(B, t, C, D, H, W)
-            return out if order is None else out[torch.arange(B, device=device)[:, None], order.to(device)]
+            return self._gather_order(out.reshape(B, t, C, D, H, W), order, poses)
         if t > 1:
             T = self.get_transformation(poses)                                                  # [B(t-1),4,4]
             xf_w = torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(B, t - 1, 12)
@@ -83,4 +90,13 @@ class Rotate_world(nn.Module):
         mode = torch.ones(B, t, dtype=torch.int32, device=device)
         mode[:, 0] = 0
         out = ops.rotate_warp(voxels.reshape(B * t, C, D, H, W), xf, mode.reshape(B * t)).reshape(B, t, C, D, H, W)
-        return out if order is None else out[torch.arange(B, device=device)[:, None], order.to(device)]
+        return self._gather_order(out, order, poses)
+
+    @staticmethod
+    def _gather_order(out, order, poses):
+        if order is None:
+            return out
+        if isinstance(order, str):
+            trans = poses[:, :, :3, 3].detach()
+            order = torch.sort(((trans - trans[:, 0:1]) ** 2).sum(dim=-1), descending=False, stable=True)[1]
+        return out[torch.arange(out.shape[0], device=out.device)[:, None], order.to(out.device)]

@@ -86,6 +86,18 @@ class VolRender(co.PackedModule):
         K[:, -1, -1] = 1.0
         return K
 
+    def _pack_cameras_hip(self, camera_params, device, want_origin):
+        """Inference: camera packing + origin projection as ONE launch (forge_pack_cameras) on the possibly strided R / T / K views."""
+        R, T, K = (camera_params[k].to(device=device, dtype=torch.float32) for k in ("R", "T", "K"))
+        V = R.shape[0]
+        cam = torch.empty(V, 16, dtype=torch.float32, device=device)
+        origin = torch.empty(V, 2, dtype=torch.float32, device=device) if want_origin else None
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().forge_pack_cameras(_lib.ptr(R), R.stride(0), R.stride(1), R.stride(2), _lib.ptr(T), T.stride(0), T.stride(1),
+                                                     _lib.ptr(K), K.stride(0), K.stride(1), K.stride(2), _lib.ptr(cam), _lib.ptr(origin), V,
+                                                     _lib.current_stream()), "forge_pack_cameras")
+        return cam, origin
+
     def _pack_cameras(self, camera_params, device):
         R = camera_params["R"].to(device=device, dtype=torch.float32)
         T = camera_params["T"].to(device=device, dtype=torch.float32)
@@ -105,7 +117,11 @@ class VolRender(co.PackedModule):
                 view2vol=None):
         nvol, C, D, H, W = feature_3d.shape
         device = feature_3d.device
-        cam, T, K = self._pack_cameras(camera_params, device)
+        origin = None
+        if hip_inference(self, feature_3d) and not any(camera_params[k].requires_grad for k in ("R", "T", "K")):
+            cam, origin = self._pack_cameras_hip(camera_params, device, return_origin_proj)
+        else:
+            cam, T, K = self._pack_cameras(camera_params, device)
         V = cam.shape[0]
         if view2vol is None:
             if V != nvol:
@@ -129,7 +145,7 @@ class VolRender(co.PackedModule):
         if render_depth:
             result.append(F.interpolate(outs[2], size=[self.img_size] * 2, mode="bilinear", align_corners=False))
         if return_origin_proj:
-            result.append(self._origin_proj(T, K))
+            result.append(origin if origin is not None else self._origin_proj(T, K))
         return tuple(result)
 
     def _conv_rgb_packed_T(self):

@@ -65,8 +65,13 @@ int forge_rotate_fwd_slots(const float* vox, const float* xf, const int* mode, c
  * xf [B*t][12] = [R_T | t_T / half_extent] with T = P_0 P_i^-1 (general 4x4 inverse), mode [B*t] = (0,1,1,...).
  * Feeds forge_rotate_fwd without any host round trip. (Gradients w.r.t. poses go through the host-side torch
  * algebra instead, see forge_amd/rotate.py.)
+ * slot (nullable) [B*t]: the view order of models/model.py:152-158 (`sequence_from_distance`: views sorted by squared distance of their
+ * camera position to view 0's, ties by view index = a stable sort) as the dst_slot array of forge_rotate_fwd_slots:
+ * slot[b t + i] = b t + rank of view i. dist (nullable) [B*t]: the sort keys, when the caller wants its own distance values ranked
+ * (the torch host passes sequence_from_distance's: symmetric camera rigs produce near-ties whose order must not depend on who
+ * rounded the sum of squares); NULL: computed here as ((dx^2 + dy^2) + dz^2) without fused multiply-adds.
  */
-int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int B, int t, float half_extent,
+int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int* slot, const float* dist, int B, int t, float half_extent,
                                forge_stream_t stream);
 
 /* Backward of forge_rotate_fwd w.r.t. the volumes (and optionally the affine).
@@ -103,6 +108,14 @@ int forge_render_fwd(const float* feat, const float* dens, const float* cam, con
                      int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
                      float zmin, float zmax, float hx, float hy, float hz,
                      forge_stream_t stream);
+
+/* Camera dict of models/volume_render.py:40-51 ({'R' [V,3,3], 'T' [V,3], 'K' [V,3,3]}, element strides given: the tensors are usually
+ * slices of [V,4,4] extrinsics) -> cam [V][16] as forge_render_fwd takes it, with the reference's half-resolution intrinsics
+ * (K / 2, K[2][2] = 1, on a copy), and (origin nullable) the screen projection of the world origin of :77-79,
+ * (fx tx / tz + cx, fy ty / tz + cy). One launch instead of a dozen tensor ops per forward; inference only (the differentiable form
+ * for camera gradients is host-side torch algebra, forge_amd/volume_render.py). */
+int forge_pack_cameras(const float* R, long long r0, long long r1, long long r2, const float* T, long long t0, long long t1,
+                       const float* K, long long k0, long long k1, long long k2, float* cam16, float* origin, int V, forge_stream_t stream);
 
 /* Backward of forge_render_fwd w.r.t. volumes (and optionally cameras).
  *   g_feat [V][Hr][Wr][C], g_opac [V][Hr][Wr], g_depth [V][Hr][Wr] (nullable)

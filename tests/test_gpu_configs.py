@@ -523,3 +523,28 @@ def test_conv_wgrad_batch_chunking(dev, monkeypatch):
     want = torch.nn.grad.conv3d_weight(torch.cat([x1, h], dim=-1).permute(0, 4, 1, 2, 3).contiguous(), (2 * C, 2 * C, 3, 3, 3),
                                        dy.permute(0, 4, 1, 2, 3).contiguous(), padding=1)
     assert (got.permute(1, 2, 0).reshape(2 * C, 2 * C, 3, 3, 3) - want).abs().max().item() < 1e-3 * want.abs().max().item()
+
+
+def test_rotate_fused_view_order_equals_gather(dev):
+    """The view ordering of models/model.py:127-128 fused into the warp's store (forge_rotate_fwd_slots; ranks computed by the pose kernel
+    for order="distance") == warp followed by sequence_from_distance + chose_selected, bit for bit; explicit index orders and a tie
+    (two views at the same distance: lower view index first, as torch.sort's stable result on equal keys) included."""
+    from forge_amd.model import chose_selected, sequence_from_distance
+    from forge_amd.rotate import Rotate_world
+    rot = Rotate_world(syn.kubric_config()).to(dev)
+    g = torch.Generator().manual_seed(33)
+    jit = (torch.rand(10, 2, generator=g) - 0.5) * 0.4
+    p1, _, _ = syn.orbit_cameras(10, 1.5, 20.0, jit)
+    p2, _, _ = syn.orbit_cameras(10, 1.5, 5.0)
+    P = torch.stack([p1[[0, 4, 2, 7, 1]], p2[[0, 3, 3, 9, 6]]]).to(dev)          # scene 1: views 1 and 2 share a pose (tie)
+    vox = torch.randn(2, 5, 8, 16, 16, 16, generator=g).to(dev)
+    with torch.no_grad():
+        plain = rot(vox, P, grid_size=16)
+        idx = sequence_from_distance(P[:, :, :3, 3])
+        want = chose_selected(plain, idx)
+        assert torch.equal(rot(vox, P, grid_size=16, order="distance"), want)
+        assert torch.equal(rot(vox, P, grid_size=16, order=idx), want)
+        perm = torch.tensor([[4, 0, 3, 1, 2], [2, 1, 0, 4, 3]], device=dev)
+        assert torch.equal(rot(vox, P, grid_size=16, order=perm), chose_selected(plain, perm))
+    vg = vox.clone().requires_grad_(True)                                        # autograd path: gather on the result
+    assert torch.equal(rot(vg, P, grid_size=16, order="distance").detach(), want)

@@ -17,7 +17,7 @@ SHAPES = [(20480, 64, 64, 1, 1), (20480, 64, 64, 9, 3), (20480, 256, 64, 1, 4), 
           (5120, 128, 128, 9, 4), (5120, 512, 128, 1, 4), (5120, 512, 256, 1, 1), (5120, 128, 512, 1, 3), (5120, 256, 512, 1, 1),
           (5120, 256, 256, 9, 6), (5120, 1024, 256, 1, 6), (5120, 1024, 512, 1, 1), (5120, 256, 1024, 1, 5), (5120, 512, 1024, 1, 1),
           (5120, 512, 512, 9, 3), (5120, 2048, 512, 1, 3), (5120, 2048, 1024, 1, 1), (5120, 512, 2048, 1, 2)]
-spec = os.environ.get("AB_VARIANTS", "base:FORGE_CONV_PF2=0;pf2:FORGE_CONV_PF2=1")
+spec = os.environ.get("AB_VARIANTS", "plan:;nosplit:FORGE_CONV_KSPLIT=1;D:FORGE_CONV_TILE=D;B:FORGE_CONV_TILE=B")
 variants = []
 for item in spec.split(";"):
     name, _, envs = item.partition(":")

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Interleaved A/B of forge_conv_igemm launch variants selected by environment variables (read per launch by the library) on the
-ConvGRU shapes: AB_VARIANTS="name:ENV=VAL,ENV=VAL;name2:..." (default: static wave priority off / on). Prints ms and TFLOP/s per
+ConvGRU shapes: AB_VARIANTS="name:ENV=VAL,ENV=VAL;name2:..." (default: the plan's choice vs each forced tile; the round-2 experiments
+(priority, deeper prefetch, dual accumulators, chunk-outer 128x64 tile) were run through it with switches that no longer exist). Prints ms and TFLOP/s per
 (variant, shape), median of AB_ROUNDS interleaved rounds.   AB_SCENES=1|4|8 sets M = scenes * 32^3."""
 import os
 import statistics
@@ -19,7 +20,7 @@ x, hbuf, zbuf = torch.randn(M, Cc, device=dev), torch.randn(M, Cc, device=dev), 
 o1, o2 = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
 shapes = {"gates": (256, Cc, co.EPI_GRU_GATES), "state": (128, Cc, co.EPI_GRU_OUT), "fconv": (128, 0, co.EPI_AFFINE_ACT)}
 ws = {k: torch.randn(27, v[0], Cc + v[1], device=dev) * 0.01 for k, v in shapes.items()}
-spec = os.environ.get("AB_VARIANTS", "base:FORGE_CONV_PRIO=0;prio:FORGE_CONV_PRIO=1")
+spec = os.environ.get("AB_VARIANTS", "plan:;A:FORGE_CONV_TILE=A;B:FORGE_CONV_TILE=B;C:FORGE_CONV_TILE=C;D:FORGE_CONV_TILE=D")
 variants = []
 for item in spec.split(";"):
     name, _, envs = item.partition(":")

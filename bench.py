@@ -289,10 +289,10 @@ def cpu_worker(threads, n_forward, seed):
 
 def cpu_baseline(sample, weights, cfg):
     """The oracle (reference semantics, torch-CPU fp32: the port of the reference's CPU path) on this box's host cores.
-      1. single process: every candidate thread count gets 1 warm-up + 1 timed forward (a count whose warm-up exceeds 10 s is
+      1. single process: every candidate thread count gets 1 warm-up + 1 timed forward (a count whose warm-up exceeds 3 s is
          recorded as such and not timed again), then the fastest count gets 5 timed forwards;
       2. scene-parallel: P processes x T threads = all physical cores, each process running its own scene (how a CPU deployment would
-         fill the box; torch-CPU convolutions do not scale past ~16-32 threads), 1 warm-up + 2 timed forwards each, started together.
+         fill the box; torch-CPU convolutions do not scale past ~16-32 threads), 1 warm-up + 1 timed forward each, started together.
     `value` is the better of the two aggregates; both are reported."""
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -313,7 +313,7 @@ def cpu_baseline(sample, weights, cfg):
         r = run()
         warm = time.time() - t0
         ref = r if ref is None else ref
-        if warm > 10.0:
+        if warm > 3.0 and sweep:                     # hopeless thread count (3-4x slower than the best so far): its warm-up is its record
             sweep[nt] = {"warmup_s": round(warm, 2), "timed_s": None}
             continue
         t1 = time.time()
@@ -331,7 +331,7 @@ def cpu_baseline(sample, weights, cfg):
     # scene-parallel over all physical cores
     tpp = min(16, phys)
     nproc = max(1, phys // tpp)
-    nfw = 2
+    nfw = 1
     par = None
     try:
         sets = core_sets(nproc, tpp)                 # each process pinned to its own 16 physical cores (one socket, no SMT siblings)

@@ -15,8 +15,15 @@ Pinning status (see DESIGN.md "Oracle"):
     (i) `oracle/shims/pytorch3d`, an independently-structured restatement of the published
     0.7.0 algorithms (4x4 transforms + matrix inverse + cumprod), and (ii) the known answers
     in the reference text (grid half-extent 0.4844 models/rotate.py:23; origin projects to the
-    image centre scripts/kubric_compute_loss.py:60-62). => "parity unpinned" w.r.t. the real
-    PyTorch3D binary.
+    image centre scripts/kubric_compute_loss.py:60-62), and (iii) since round 2 the analytic
+    known answers of tests/kat_render.py, derived in float64 from the documented contracts of
+    those PyTorch3D pieces with neither this file nor the shims (uniform slabs on cubic and
+    anisotropic grids, single-voxel impulses under a rotated camera with fx != fy, cx != cy).
+    => still "parity unpinned" w.r.t. the real PyTorch3D BINARY (never run here), pinned w.r.t.
+    its documented semantics.
+  * predicted-pose orchestration (models/model.py:58-96 and the pose estimators it calls) is
+    not restated here: forge_amd's stock-torch pose estimators are compared directly with the
+    reference's outputs (tests/golden/forward_joint.npz).
 
 Weights are passed as a flat dict with the reference's state_dict key names
 (SURVEY.md Appendix B), e.g. "encoder_3d.fusion_feature.cells.0.conv_gate.weight".

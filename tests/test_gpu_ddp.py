@@ -173,3 +173,25 @@ def test_ray_sharded_render_two_ranks_on_the_gpu():
     for rank, equal, shapes in res:
         assert all(equal), (rank, equal)
         assert shapes == [(3, 16, 128, 128), (3, 1, 128, 128), (3, 1, 128, 128)]
+
+
+def test_bench_entry_two_ranks_on_the_shared_gpu():
+    """`python bench.py --gpus 2` (no torchrun environment) on the one-GPU test box: the entry starts its own two ranks, each captures its
+    hipGraph BEFORE the process group exists, the ranks rendezvous (gloo here: two ranks on one device; RCCL on a real node), time the step
+    between barriers, all-reduce time / SSE / view counts, and rank 0 prints one line with n_gpus = 2 and twice the per-rank views. Without
+    FORGE_BENCH_ALLOW_SHARED_GPUS the same command must refuse (a scaling number from shared devices would be meaningless)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-microbench"]
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert bad.returncode != 0 and "GPU(s) visible" in (bad.stderr + bad.stdout)
+    ok = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=root)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 5 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]          # whole-job views / max-over-ranks time

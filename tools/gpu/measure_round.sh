@@ -19,3 +19,5 @@ for f in ("r02_bench_b1","r02_bench_b8","r02_bench_grid64_b1","r02_bench_grid64_
     d=json.load(open("gpurun_out/%s.json"%f)); print(f, round(d["value"],1), round(d["ms_per_step"],2), round(d["roofline"]["frac"],3), d["stages_ms"])
 d=json.load(open("gpurun_out/r02_bench_b1.json")); print(json.dumps(d["cpu_baseline"])[:900]); print(d["kernels"]["rotate_fwd_kernel"], d["kernels"]["render_fwd_kernel"]); print(d.get("psnr_vs_oracle_db"), d.get("psnr_to_target_db"), d.get("speedup_vs_cpu_baseline"))
 PY
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+FORGE_BENCH_ALLOW_SHARED_GPUS=1 timeout 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-microbench 2> gpurun_out/r02_bench_2ranks_shared_gpu.err | tail -c 600

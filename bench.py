@@ -70,7 +70,7 @@ def stage_timers(model):
     wrap(model.render, "forward", "render_total")
     wrap(model.render, "_conv_rgb_hip", "conv_rgb")
     # every forge_conv_igemm launch: events + algorithmic FLOPs, keyed by kernel instantiation
-    from forge_amd import convops as co, encoder as enc_mod, fusion as fus_mod
+    from forge_amd import convops as co
     orig = co.conv_igemm
 
     def conv_timed(in1, C1, ld1, in2, C2, ld2, wp, *a, **kw):

@@ -91,6 +91,43 @@ def stage_timers(model):
         return out
     co.conv_igemm = conv_timed
     undo.append(lambda: setattr(co, "conv_igemm", orig))
+    # the Winograd path of the ConvGRU fusion: its 16 point GEMMs are ONE launch of the same conv_igemm_kernel (counted above with the
+    # MFMA FLOPs they execute, 2 x 16 R x Cout x 3 Cin - 2.25x fewer than the direct convolution they replace); the two transform
+    # kernels are HBM-bound and recorded with their algorithmic bytes
+    o_g, o_i, o_o = co.wino_gemm, co.wino_input, co.wino_output
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def gemm_timed(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw):
+        e0, e1 = ev()
+        e0.record()
+        out = o_g(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw)
+        e1.record()
+        R = n * D * Ht * Wt
+        tile, _ = co.conv_plan(16 * R, Cout, C1 + C2, 3, co.EPI_BIAS, Cout, ws_bytes=0)
+        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[tile], []).append((e0, e1, 2.0 * 16 * R * Cout * 3 * (C1 + C2), (16 * R, Cout, 3, C1 + C2)))
+        return out
+
+    def input_timed(x, C, ld, n, D, H, W, **kw):
+        e0, e1 = ev()
+        e0.record()
+        out = o_i(x, C, ld, n, D, H, W, **kw)
+        e1.record()
+        rec.setdefault("wino_input_kernel", []).append((e0, e1, 4.0 * n * D * H * W * C * (1 + 4)))       # reads the rows once, writes 16 points x R = 4x
+        return out
+
+    def output_timed(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue):
+        e0, e1 = ev()
+        e0.record()
+        r = o_o(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue)
+        e1.record()
+        rows = n * D * H * W
+        side = {co.EPI_GRU_GATES: 3 * Cout // 2, co.EPI_GRU_OUT: 3 * Cout + (Cout if out2 is not None else 0)}.get(epilogue, Cout)
+        rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * (4 * Cout + side)))       # reads 16 points x R x Cout = 4x, then the tail's operands
+        return r
+    co.wino_gemm, co.wino_input, co.wino_output = gemm_timed, input_timed, output_timed
+    undo.append(lambda: (setattr(co, "wino_gemm", o_g), setattr(co, "wino_input", o_i), setattr(co, "wino_output", o_o)))
     return rec, undo
 
 
@@ -201,7 +238,20 @@ def kernel_rooflines(dev, B, D=32):
                                                co.TAPS_3x3x3, epilogue=epi), iters=10, warm=2)
         flops = 2.0 * M * Cout * 27 * (Cc + C2)
         out["conv_igemm " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9,
-                                                  "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF}
+                                                  "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF,
+                                                  "used_by": "training / refinement (the inference fusion runs the Winograd launches below)"}
+    # the same kernel as the fusion's inference path launches it: 16 Winograd point GEMMs per launch, 3 depth taps, K = 3 Cin
+    R = B * D * (D // 2) * (D // 2)
+    V1, V2 = torch.randn(16, R, Cc, device=dev), torch.randn(16, R, Cc, device=dev)
+    Mm = torch.empty(16, R, 2 * Cc, device=dev)
+    for name, Cout, C2 in (("convgru_gates N=256 K=768", 256, Cc), ("convgru_state N=128 K=768", 128, Cc), ("fusion_conv N=128 K=384", 128, 0)):
+        U = torch.randn(16, 3, Cout, Cc + C2, device=dev) * 0.01
+        mm = Mm.view(-1)[:16 * R * Cout].view(16, R, Cout)
+        ms = time_kernel(lambda: co.wino_gemm(V1, Cc, V2 if C2 else None, C2, U, mm, B, D, D // 2, D // 2, Cout), iters=10, warm=2)
+        flops = 2.0 * 16 * R * Cout * 3 * (Cc + C2)
+        out["wino_gemm " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                                    "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF, "direct_equivalent_tflops": 2.25 * flops / ms / 1e9,
+                                    "kernel": "conv_igemm_kernel (16 batched 3-tap problems)"}
     return out
 
 
@@ -535,6 +585,7 @@ def main():
         eager_step()
     torch.cuda.synchronize()
     conv_rec = {k: rec.pop(k) for k in list(rec) if k.startswith("conv_igemm")}
+    wino_rec = {k: rec.pop(k) for k in list(rec) if k.startswith("wino_")}
     stages = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in rec.items()}
     conv_launch = {k: {"launches_per_step": len(v), "total_ms": sum(x[0].elapsed_time(x[1]) for x in v),
                        "gflop": sum(x[2] for x in v) / 1e9} for k, v in conv_rec.items()}
@@ -552,9 +603,17 @@ def main():
     result = None
     if rank == 0:
         kern = {} if args.no_microbench else kernel_rooflines(dev, B, args.grid)
+        for k, v in wino_rec.items():          # Winograd transform kernels of the fusion, as launched inside the step
+            ms, by = sum(x[0].elapsed_time(x[1]) for x in v), sum(x[2] for x in v)
+            kern[k] = {"bound": "hbm", "launches_per_step": len(v), "ms_total": ms, "bytes": by, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
+                       "note": "HIP events around the eager launches of one step (each includes the host launch gap); the transformed operands "
+                               "(67-134 MB per launch at one scene) are partly served by the 256 MB Infinity Cache"}
         # dominant kernel of the step: conv_igemm_kernel<BM, BN, waves> - ONE kernel (csrc/conv_igemm.hip) whose tile shape is picked per
         # launch by the plan model, so rocprofv3 lists it under several instantiation names; together they are ~95 % of the step.
-        # achieved = sum of the ALGORITHMIC FLOPs of all its launches in one step / sum of their HIP-event durations. The
+        # achieved = sum of the FLOPs of all its launches in one step / sum of their HIP-event durations - the FLOPs the launches execute:
+        # direct convolutions count 2 M N taps Cin, the Winograd point-GEMM launches of the fusion 2 x 16 R N x 3 Cin (2.25x fewer than the
+        # direct convolution they replace; the step's direct-convolution FLOPs are `gflop_per_step_algorithmic`). The
         # per-instantiation avg_launch_ms are directly comparable with rocprofv3's per-name AverageNs in profiles/.
         convs = {k: v for k, v in conv_launch.items() if k.startswith("conv_igemm_kernel<")}
         step_ms = dt / args.steps * 1e3
@@ -577,7 +636,7 @@ def main():
             metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
             workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
                         "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
-                        "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
+                        "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU (Winograd F(2x2,3x3) x 3 depth taps) / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
                         "eval BN, random-init seeded weights" % (1 if B == 1 else 2, B))
             gflop = B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB)
         else:
@@ -595,7 +654,7 @@ def main():
                        "render_grid": 2 * args.grid, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "parallelism": "dp%d (scene-sharded, no data-path collective; 3-scalar RCCL all-reduce of SSE/pixels/views for the PSNR report)" % world},
             "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
-            "gflop_per_step_algorithmic": gflop,
+            "gflop_per_step_algorithmic": gflop, "direct_equivalent_tflops": gflop / (dt / args.steps) / 1e3,
             "views_per_s_with_host_to_device_copy": pcie_views_per_s,
             "psnr_to_target_db_all_ranks": fdist.psnr_from_sse(sse, npix),
         }

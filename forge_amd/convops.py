@@ -165,12 +165,14 @@ def _splitk_workspace(device):
 TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
 
-def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
+def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1, ws_bytes=None):
     """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only). nphase = 4 / 8
-    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases)."""
+    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases). ws_bytes = 0: no split-K workspace
+    (forge_wino_gemm plans its 16 batched problems as M = 16 R rows, 3 taps, no split-K)."""
     import ctypes
     tile, ks = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
+    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo),
+                                                SPLITK_WS_BYTES if ws_bytes is None else int(ws_bytes),
                                                 ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
     return chr(tile.value), ks.value
 
@@ -214,6 +216,62 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
             off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
             arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st),
             "forge_conv_igemm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3) x 3 depth taps for the stride-1 3x3x3 convolutions of the inference path (csrc/winograd.hip)
+# ------------------------------------------------------------------------------------------------------------------
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def wino_pack_weight(w):
+    """nn.Conv3d weight [Cout,Cin,3,3,3] -> U [16][3][Cout][Cin]: U[4i+j][kd] = (G w[kd] G^T)[i][j], float64 product rounded once."""
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    U = torch.einsum("ia,jb,ockab->ijkoc", G, G, w.detach().double())
+    return U.reshape(16, 3, w.shape[0], w.shape[1]).float().contiguous()
+
+
+def wino_enabled():
+    """FORGE_WINOGRAD=0 keeps the direct implicit-GEMM kernel for the fused ConvGRU convolutions (A/B, tools/wino_ab.py)."""
+    import os
+    return os.environ.get("FORGE_WINOGRAD", "1") != "0"
+
+
+def wino_fits(n, D, H, W, C, views=1):
+    """H, W even, and every transformed operand ([n views D H/2 W/2][C] floats per Winograd point) within the kernel's 32-bit buffer offsets."""
+    return H % 2 == 0 and W % 2 == 0 and n * views * D * (H // 2) * (W // 2) * C * 4 <= MAX_OPERAND_BYTES
+
+
+@_lib.on_tensor_device
+def wino_input(x, C, ld, n, D, H, W, bs=0, out=None):
+    """V[16][n D H/2 W/2][C] = B^T d B of the channels-last rows x ([n][D][H][W] x ld floats, batch stride bs rows)."""
+    R = n * D * (H // 2) * (W // 2)
+    V = out if out is not None else torch.empty(16, R, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().forge_wino_input(_lib.ptr(x), ld, int(bs), _lib.ptr(V), C, 0, n, D, H, W, C, _lib.current_stream()), "forge_wino_input")
+    return V
+
+
+@_lib.on_tensor_device
+def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
+    """Mm[16][n D Ht Wt][Cout] = the 16 point GEMMs. V1 [16][n views D Ht Wt][C1] may hold `views` views per batch element (the
+    transformed inputs of every view of a scene, made by ONE wino_input launch): this call reads view `view`. V2 [16][R][C2] or None."""
+    vol = D * Ht * Wt
+    if U.shape != (16, 3, Cout, C1 + C2):
+        raise ValueError("transformed weight %s does not match Cout=%d Cin=%d" % (tuple(U.shape), Cout, C1 + C2))
+    p1 = ctypes.c_void_p(V1.data_ptr() + 4 * view * vol * C1)
+    _lib.check(_lib.lib().forge_wino_gemm(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
+                                          0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, _lib.current_stream()),
+               "forge_wino_gemm")
+    return Mm
+
+
+@_lib.on_tensor_device
+def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue):
+    """out = epilogue(A^T Mm A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles."""
+    _lib.check(_lib.lib().forge_wino_output(_lib.ptr(Mm), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
+                                            _lib.ptr(aux_h), _lib.ptr(aux_z), _lib.ptr(out), _lib.ptr(out2), _lib.ptr(out3), n, D, H, W, Cout, ldo,
+                                            epilogue, _lib.current_stream()), "forge_wino_output")
     return out
 
 

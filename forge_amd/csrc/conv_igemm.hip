@@ -61,6 +61,8 @@ struct ConvArgs {
     int nphase, tpp;                       // > 1: all output phases of a stride-2 transposed conv in ONE launch: phase p = (pz,py,px) bits uses taps [p tpp, (p+1) tpp)
     int epi;
     int lift;                              // > 0: 2D->3D lift of the output (models/encoder.py:49), see forge_hip.h
+    int nbat;                              // > 1: nbat independent GEMMs in one launch (the 16 Winograd points, forge_wino_gemm): problem p adds
+    long long pt1, pt2, ptw, pto;          //      p * pt1 / pt2 / ptw / pto floats to in1 / in2 / wp / out (EPI_BIAS, no split-K, no phases)
     float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
@@ -121,6 +123,13 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int pz = a.nphase > 1 ? (a.nphase == 8 ? (phase >> 2) & 1 : 0) : a.pz;
     const int py = a.nphase > 1 ? (phase >> 1) & 1 : a.py, px = a.nphase > 1 ? phase & 1 : a.px;
     const int t_lo = phase * a.tpp;
+    long long pb = 0;                                               // batched problems: workgroups [p tiles, (p+1) tiles) do problem p, so that (with
+    if (a.nbat > 1) {                                               // xcd_remap's contiguous chunks) an XCD's L2 holds the weights of its own problems only
+        const unsigned tiles = (unsigned)((M + BM - 1) / BM) * (unsigned)ntile_n;
+        pb = bid / tiles;
+        bid -= (unsigned)pb * tiles;
+    }
+    float* const outp = a.out + pb * a.pto;
     const long long m0 = (long long)(bid / ntile_n) * BM;
     const int n0 = (bid % ntile_n) * BN;
     const int Cin = a.C1 + a.C2;
@@ -129,9 +138,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
     const int nsteps = s_end - s_begin;
 
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 + pb * a.pt1), 0, (int)a.span1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 + pb * a.pt2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wp + pb * a.ptw), 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
 
     // ---- per-thread staging geometry: ACH A rows, BCH B rows, one 16-byte chunk each
     const int cp = tid & 7;                                      // physical chunk in the 128-byte LDS row
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                     float v = acc[i][j][r] + bias;
                     if (cok && orow >= 0) {
                         if constexpr (EPI == EPI_BIAS) {
-                            a.out[orow * a.ldo + col] = v;
+                            outp[orow * a.ldo + col] = v;
                         } else if constexpr (EPI == EPI_AFFINE_ACT) {
                             v = fmaf(v, sc, sh);
                             if (a.lift > 0) {
@@ -685,6 +694,29 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
     return best;
 }
 
+// Launch conv_igemm_kernel with the planned tile: ceil(M / BM) x ceil(Cout / BN) workgroups per (K slice, phase, batched problem).
+static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st) {
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+#define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
+    do {                                                                                                                   \
+        const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase * a.nbat;                                              \
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
+        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
+        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv>), lds);                                                    \
+        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
+    } while (0)
+    switch (tile) {
+        case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
+        case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
+        case 'C': FORGE_LAUNCH_CONV(128, 64, 8); break;
+        case 'E': FORGE_LAUNCH_CONV(128, 32, 4); break;
+        default: FORGE_LAUNCH_CONV(64, 64, 4); break;
+    }
+#undef FORGE_LAUNCH_CONV
+    return 0;
+}
+
 }  // namespace forge
 
 using namespace forge;
@@ -734,7 +766,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                   "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = (lift > 0 || epilogue == EPI_GRU_GATES || epilogue == EPI_GRU_OUT) ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.out3 = out3; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
-    a.nphase = 1; a.tpp = ntaps;
+    a.nphase = 1; a.tpp = ntaps; a.nbat = 1; a.pt1 = a.pt2 = a.ptw = a.pto = 0;
     if (pz < 0) {   // all output phases of a stride-2 transposed convolution in one launch
         FORGE_REQUIRE(os == 2 && py < 0 && px < 0 && Ho == 2 * H && Wo == 2 * W && (Do == 2 * D || Do == D), FORGE_EINVAL,
                       "forge_conv_igemm: merged phases (pz = py = px = -1) need os = 2 and a doubled output grid");
@@ -760,30 +792,42 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         const ConvPlan pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp,
                                       a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
                                       splitk_ws_bytes);
-        const char tile = pl.tile;
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
-        auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-#define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
-    do {                                                                                                                   \
-        const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase;                                                       \
-        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
-        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
-        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv>), lds);                                                    \
-        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
-    } while (0)
-        switch (tile) {
-            case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
-            case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
-            case 'C': FORGE_LAUNCH_CONV(128, 64, 8); break;
-            case 'E': FORGE_LAUNCH_CONV(128, 32, 4); break;
-            default: FORGE_LAUNCH_CONV(64, 64, 4); break;
-        }
-#undef FORGE_LAUNCH_CONV
+        if (int rc = launch_conv_tile(a, pl.tile, st)) return rc;
         if (a.ksplit > 1) {
             const long long total = M * (Cout / 4);
             hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
         }
     }
     FORGE_LAUNCH_CHECK("forge_conv_igemm");
+    return 0;
+}
+
+// The 16 point-GEMMs of a Winograd F(2x2, 3x3) x 3-depth-tap convolution (winograd.hip) in ONE launch: problem p = (i, j) multiplies
+// the transformed inputs V[p] (rows = (n, z, tile row, tile col), channels-last, the channel concatenation of V1 and V2) with the
+// transformed weights U[p] [3 depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a 3-tap implicit GEMM over the tile grid, K = 3 (C1 + C2).
+extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
+                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream) {
+    FORGE_REQUIRE(V1 && U && Mm, FORGE_EINVAL, "forge_wino_gemm: null pointer argument");
+    FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 16, FORGE_EINVAL, "forge_wino_gemm: bad dims n=%d D=%d Ht=%d Wt=%d Cout=%d (Cout > 16)", n,
+                  D, Ht, Wt, Cout);
+    FORGE_REQUIRE(C1 > 0 && C1 % BK == 0 && C2 >= 0 && C2 % BK == 0 && (C2 == 0) == (V2 == nullptr), FORGE_ESHAPE,
+                  "forge_wino_gemm: C1=%d / C2=%d must be multiples of %d, V2 given iff C2 > 0", C1, C2, BK);
+    FORGE_REQUIRE(ld1 >= C1 && ld1 % 4 == 0 && (C2 == 0 || (ld2 >= C2 && ld2 % 4 == 0)), FORGE_EINVAL, "forge_wino_gemm: bad row strides");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    const long long vol = (long long)D * Ht * Wt, R = (long long)n * vol;
+    a.in1 = V1; a.in2 = V2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.bs1r = bs1 > 0 ? bs1 : vol; a.bs2r = bs2 > 0 ? bs2 : vol;
+    a.span1 = ((long long)(n - 1) * a.bs1r + vol) * ld1 * 4;
+    a.span2 = V2 ? ((long long)(n - 1) * a.bs2r + vol) * ld2 * 4 : 0;
+    FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && R < (1ll << 31), FORGE_ESHAPE,
+                  "forge_wino_gemm: an operand spans >= 2 GiB per Winograd point (32-bit buffer offsets); split the batch");
+    a.wp = U; a.slope = 1.f; a.out = Mm; a.n = n; a.D = D; a.H = Ht; a.W = Wt; a.is = 1; a.Di = D; a.Hi = Ht; a.Wi = Wt;
+    a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = 3; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = 3; a.epi = EPI_BIAS;
+    a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = 3ll * Cout * (C1 + C2); a.pto = R * Cout;
+    a.tap[0][0] = -1; a.tap[2][0] = 1;                                  // depth taps (-1,0,0), (0,0,0), (1,0,0)
+    const ConvPlan pl = plan_conv(R * 16, Cout, C1 + C2, 3, false, 0);
+    if (int rc = launch_conv_tile(a, pl.tile, (hipStream_t)stream)) return rc;
+    FORGE_LAUNCH_CHECK("forge_wino_gemm");
     return 0;
 }

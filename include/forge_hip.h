@@ -189,6 +189,29 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
 int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase, int epilogue, int ldo, long long splitk_ws_bytes,
                           int* tile, int* ksplit);
 
+/* ---------------------------------------------------------------------------------------------
+ * a4 (inference)  the stride-1 3x3x3 convolutions of the ConvGRU fusion (models/fusion.py:29-35, 61-68, 88-95) as Winograd
+ * F(2x2, 3x3) over (H, W) with the three depth taps summed directly: 12 instead of 27 multiplies per output and channel pair.
+ *   y[z, 2th+i, 2tw+j] = sum_kd A^T [ U[kd] (.) (B^T d[z+kd-1] B) ] A,   U[kd] = G w[kd] G^T,   d = the 4x4 patch at (2th-1.., 2tw-1..)
+ * Three launches per convolution, all on channels-last rows, tile rows r = ((n D + z) H/2 + th) W/2 + tw, point p = 4 i + j:
+ *   forge_wino_input   V[p][r][c] = (B^T d B)[p] for the C channels of in (rows [n][D][H][W] x ld floats, batch stride bs rows,
+ *                      0 = dense); V[p] starts at V + p ptv floats (0 = dense R x ldv), rows of ldv floats. H, W even; C % 4 == 0.
+ *   forge_wino_gemm    Mm[p][r][co] = sum_kd sum_ci U[p][kd][co][ci] (V1 | V2)[p][r + kd plane][ci]  for the 16 points in ONE launch of the
+ *                      fp32-MFMA implicit-GEMM kernel (forge_conv_igemm's: 3 depth taps over the (n, D, Ht, Wt) tile grid, K = 3 (C1+C2));
+ *                      V1 / V2: channel-concatenated operands (V2 nullable with C2 = 0) with row strides ld, batch strides bs rows
+ *                      (0 = dense) and point strides pt floats; U [16][3][Cout][C1+C2]; Mm [16][R][Cout] dense. C1, C2 % 32 == 0.
+ *   forge_wino_output  y = A^T Mm A per tile, then forge_conv_igemm's epilogue 0..3 with the same operands (bias, scale/shift/slope,
+ *                      residual [rows][Cout] added to the pre-activation, aux_h / aux_z, out / out2 / out3; out rows of ldo floats).
+ * B^T and A^T hold 0 / +-1 only (exact additions); U is rounded once from a float64 product by the caller. Not bit-identical to
+ * forge_conv_igemm (different order of the fp32 additions); error vs a float64 convolution is ~1.4x the direct fp32 kernel's. */
+int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
+                     forge_stream_t stream);
+int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
+                    long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream);
+int forge_wino_output(const float* Mm, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
+                      int ldo, int epilogue, forge_stream_t stream);
+
 /* Weight gradient of forge_conv_igemm's convolution (training, scripts/kubric_trainer.py:56 -> torch conv backward):
  *   dw[t][co][ci] += sum_m dy[m][co] * x[voxel(m) + taps[t]][ci]      (x = channel concat of x1 | x2, zero outside the grid)
  * dy [M][ldy] is the upstream gradient of the conv output on the (n,D,H,W) row grid; x1/x2, is, Di.. as in forge_conv_igemm.

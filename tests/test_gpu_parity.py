@@ -336,13 +336,16 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
     from forge_amd import convops as co
     from forge_amd.fusion import ConvGRU_3D
     torch.manual_seed(5)
+    monkeypatch.setenv("FORGE_WINOGRAD", "0")           # the direct implicit-GEMM launcher is what chunks; the Winograd path falls back to it
     gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).eval()
     x = (torch.randn(6, 3, 128, 8, 8, 8) * 0.5).to(dev)
     with torch.no_grad():
         ref = gru.fuse_hip(x).clone()
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 3 * 8 * 8 * 8 * 128 * 4 * 2)          # two scenes' worth of the [b,t,...] input
         chunked = gru.fuse_hip(x)
-    assert torch.equal(ref, chunked)
+        assert torch.equal(ref, chunked)
+        monkeypatch.setenv("FORGE_WINOGRAD", "1")       # operands beyond the limit: the Winograd path declines (wino_fits) and the result is the same
+        assert torch.equal(gru.fuse_hip(x), ref)
 
 
 def test_training_loss_and_gradients_vs_oracle_autograd(dev):

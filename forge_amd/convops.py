@@ -267,9 +267,12 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
 
 
 @_lib.on_tensor_device
-def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue):
-    """out = epilogue(A^T Mm A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles."""
-    _lib.check(_lib.lib().forge_wino_output(_lib.ptr(Mm), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
+def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1):
+    """out = epilogue(A^T (Mm + Mm2) A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles. Mm2 (optional)
+    [16][n views D H/2 W/2][Cout]: point products of the input half for `views` views per batch element; this call adds view `view`."""
+    vol = D * (H // 2) * (W // 2)
+    p2 = None if Mm2 is None else ctypes.c_void_p(Mm2.data_ptr() + 4 * view * vol * Cout)
+    _lib.check(_lib.lib().forge_wino_output(_lib.ptr(Mm), p2, views * vol, 0 if Mm2 is None else Mm2.shape[1] * Cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
                                             _lib.ptr(aux_h), _lib.ptr(aux_z), _lib.ptr(out), _lib.ptr(out2), _lib.ptr(out3), n, D, H, W, Cout, ldo,
                                             epilogue, _lib.current_stream()), "forge_wino_output")
     return out

@@ -73,6 +73,8 @@ enum WinoEpilogue : int { W_BIAS = 0, W_AFFINE_ACT = 1, W_GRU_GATES = 2, W_GRU_O
 
 struct WinoOutArgs {
     const float* Mm; long long ptm;               // Mm[p] = Mm + p ptm, rows [n][D][H/2][W/2] x Cout floats
+    const float* Mm2; long long ptm2, bs2;        // nullable second addend (the input half of conv([x, h], W), shared across fusions):
+                                                  // Mm2[p] = Mm2 + p ptm2, batch element n starts at row n bs2 (rows [D][H/2][W/2] x Cout)
     const float* bias; const float* scale; const float* shift; float slope;
     const float* residual;                        // nullable, [rows][Cout]: added to the pre-activation
     const float* aux_h; const float* aux_z;
@@ -98,6 +100,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(mp + (4 * i + j) * a.ptm);
+    if (a.Mm2) {
+        const unsigned R1 = (unsigned)(a.D * Ht * Wt), nn = r / R1;
+        const float* mp2 = a.Mm2 + ((long long)nn * a.bs2 + (r - nn * R1)) * a.Cout + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] = f4_add(m[i][j], *reinterpret_cast<const float4*>(mp2 + (4 * i + j) * a.ptm2));
+    }
     float4 s[2][4];                                  // A^T m
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -189,7 +199,7 @@ extern "C" int forge_wino_input(const float* in, int ld, long long bs, float* V,
     return 0;
 }
 
-extern "C" int forge_wino_output(const float* Mm, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+extern "C" int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                                  const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
                                  int ldo, int epilogue, forge_stream_t stream) {
     FORGE_REQUIRE(Mm && out, FORGE_EINVAL, "forge_wino_output: null pointer argument");
@@ -203,7 +213,7 @@ extern "C" int forge_wino_output(const float* Mm, const float* bias, const float
     FORGE_REQUIRE(out3 == nullptr || epilogue == W_GRU_GATES || epilogue == W_GRU_OUT, FORGE_EINVAL, "forge_wino_output: out3 is a GRU-epilogue output");
     WinoOutArgs a;
     const long long R = (long long)n * D * (H / 2) * (W / 2);
-    a.Mm = Mm; a.ptm = R * Cout; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope; a.residual = residual; a.aux_h = aux_h; a.aux_z = aux_z;
+    a.Mm = Mm; a.ptm = R * Cout; a.Mm2 = Mm2; a.bs2 = bs2 > 0 ? bs2 : (long long)D * (H / 2) * (W / 2); a.ptm2 = pt2 > 0 ? pt2 : R * Cout; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope; a.residual = residual; a.aux_h = aux_h; a.aux_z = aux_z;
     a.out = out; a.out2 = out2; a.out3 = out3; a.ldo = ldo; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.epi = epilogue;
     FORGE_REQUIRE(R < (1ll << 31), FORGE_ESHAPE, "forge_wino_output: more than 2^31 tiles; split the batch");
     const long long total = R * (Cout / 4), grid = (total + 255) / 256;

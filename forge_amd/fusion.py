@@ -400,6 +400,16 @@ class ConvGRU_3D(co.PackedModule):
                       "fc0_U": co.wino_pack_weight(fc[0].weight), "fc3_U": co.wino_pack_weight(fc[3].weight)})
         return p
 
+    @staticmethod
+    def _wino_h0(p, mean, geo, Vh, Mc, t0, h):
+        """h = fusion_conv(mean): two Winograd convolutions with the folded BatchNorm + LeakyReLU tail (scratch Vh / Mc / t0)."""
+        b, D, H, W = geo
+        C = mean.shape[-1]
+        for src, dst, k, bn in ((mean, t0, "fc0", "bn1"), (t0, h, "fc3", "bn4")):
+            co.wino_input(src, C, C, b, D, H, W, out=Vh)
+            co.wino_gemm(Vh, C, None, 0, p[k + "_U"], Mc, b, D, H // 2, W // 2, C)
+            co.wino_output(Mc, p[k + "_b"], p[bn][0], p[bn][1], 0.01, None, None, None, dst, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
+
     def _fuse_wino(self, xr, h0=None):
         """fuse_hip with every 3x3x3 convolution as Winograd F(2x2, 3x3) x 3 depth taps (csrc/winograd.hip): 2.25x fewer MFMA FLOPs.
         The views are transformed once, by one launch; per GRU step: transform h, 16 point GEMMs over [V_x | V_h] (K = 3 x 256), inverse
@@ -416,13 +426,7 @@ class ConvGRU_3D(co.PackedModule):
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)                        # the C-column problems reuse the front of the buffer
         t0, h = new(), new()
         if h0 is None:
-            mean = xr.mean(dim=1).reshape(M, C)
-            co.wino_input(mean, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, Ht, Wt, C)
-            co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, *geo, C, C, co.EPI_AFFINE_ACT)
-            co.wino_input(t0, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, Ht, Wt, C)
-            co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, *geo, C, C, co.EPI_AFFINE_ACT)
+            self._wino_h0(p, xr.mean(dim=1).reshape(M, C), geo, Vh, Mc, t0, h)
         else:
             h.copy_(h0.permute(0, 2, 3, 4, 1).reshape(M, C))
         z, hr, h2, out = new(), new(), t0, new()
@@ -437,6 +441,51 @@ class ConvGRU_3D(co.PackedModule):
             h, h2 = h2, h
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
+    def _fuse_groups_wino(self, xr, groups):
+        """fuse_groups_hip in the Winograd domain: the views are transformed once and the point products of the INPUT halves of both GRU
+        convolutions are computed once, for all views in one launch each (Mm_x = V_x (x) U_x); every (group, view) step then runs the
+        hidden-state halves only (K = 3 x 128) and the inverse transform adds the view's Mm_x before the fused GRU tail."""
+        b, t, D, H, W, C = xr.shape
+        p = self._packed_wino()
+        if "gate_Ux" not in p:                                         # U = (U_x | U_h) along Cin
+            p.update({"gate_Ux": p["gate_U"][..., :C].contiguous(), "gate_Uh": p["gate_U"][..., C:].contiguous(),
+                      "out_Ux": p["out_U"][..., :C].contiguous(), "out_Uh": p["out_U"][..., C:].contiguous()})
+        dev, M, Ht, Wt = xr.device, b * D * H * W, H // 2, W // 2
+        R1 = D * Ht * Wt
+        R = b * R1
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        geo = (b, D, H, W)
+        Vx = co.wino_input(xr, C, C, b * t, D, H, W)
+        MXg = torch.empty(16, b * t * R1, 2 * C, dtype=torch.float32, device=dev)
+        MXc = torch.empty(16, b * t * R1, C, dtype=torch.float32, device=dev)
+        co.wino_gemm(Vx, C, None, 0, p["gate_Ux"], MXg, b * t, D, Ht, Wt, 2 * C)
+        co.wino_gemm(Vx, C, None, 0, p["out_Ux"], MXc, b * t, D, Ht, Wt, C)
+        Vh = torch.empty(16, R, C, dtype=torch.float32, device=dev)
+        Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
+        Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
+        outs = []
+        for grp in groups:
+            grp = list(grp)
+            if grp == list(range(grp[0], grp[0] + len(grp))):          # a run of views: a slice (no index tensor: capturable into a hipGraph)
+                mean = xr[:, grp[0]:grp[0] + len(grp)].mean(dim=1).reshape(M, C)
+            else:
+                mean = torch.stack([xr[:, ti] for ti in grp], dim=1).mean(dim=1).reshape(M, C)
+            t0, h = new(), new()
+            self._wino_h0(p, mean, geo, Vh, Mc, t0, h)
+            z, hr, h2, out = new(), new(), t0, new()
+            for k, ti in enumerate(grp):
+                co.wino_input(h, C, C, b, D, H, W, out=Vh)
+                co.wino_gemm(Vh, C, None, 0, p["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C)
+                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t)
+                co.wino_input(hr, C, C, b, D, H, W, out=Vh)
+                co.wino_gemm(Vh, C, None, 0, p["out_Uh"], Mc, b, D, Ht, Wt, C)
+                last = k == len(grp) - 1
+                co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C,
+                               co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t)
+                h, h2 = h2, h
+            outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
+        return outs
+
     def fuse_groups_hip(self, x, groups):
         """Several fusions over subsets of the SAME views in inference (FORGE_poseEstimator3D fuses views (0,1,2), (3,4) and (0..4) of
         the same rotated features, models/model_single_pose_estimator.py:108-120): conv([x, h], W) = conv(x, W_x) + conv(h, W_h), so the
@@ -448,6 +497,8 @@ class ConvGRU_3D(co.PackedModule):
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
+        if co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t):
+            return self._fuse_groups_wino(xr, groups)
         p = self._packed()
         if "gate_wx" not in p:                                         # W = (W_x | W_h) along Cin
             p.update({"gate_wx": p["gate_w"][:, :, :C].contiguous(), "gate_wh": p["gate_w"][:, :, C:].contiguous(),

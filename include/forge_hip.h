@@ -200,15 +200,17 @@ int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase,
  *                      fp32-MFMA implicit-GEMM kernel (forge_conv_igemm's: 3 depth taps over the (n, D, Ht, Wt) tile grid, K = 3 (C1+C2));
  *                      V1 / V2: channel-concatenated operands (V2 nullable with C2 = 0) with row strides ld, batch strides bs rows
  *                      (0 = dense) and point strides pt floats; U [16][3][Cout][C1+C2]; Mm [16][R][Cout] dense. C1, C2 % 32 == 0.
- *   forge_wino_output  y = A^T Mm A per tile, then forge_conv_igemm's epilogue 0..3 with the same operands (bias, scale/shift/slope,
+ *   forge_wino_output  y = A^T (Mm + Mm2) A per tile, then forge_conv_igemm's epilogue 0..3 with the same operands (bias, scale/shift/slope,
  *                      residual [rows][Cout] added to the pre-activation, aux_h / aux_z, out / out2 / out3; out rows of ldo floats).
+ *                      Mm2 (nullable): a second set of point products with batch stride bs2 rows and point stride pt2 floats (0 = as Mm) -
+ *                      the input half conv(x, W_x) of conv([x, h], W), computed once per view when several fusions share views.
  * B^T and A^T hold 0 / +-1 only (exact additions); U is rounded once from a float64 product by the caller. Not bit-identical to
  * forge_conv_igemm (different order of the fp32 additions); error vs a float64 convolution is ~1.4x the direct fp32 kernel's. */
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                     long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream);
-int forge_wino_output(const float* Mm, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
                       int ldo, int epilogue, forge_stream_t stream);
 

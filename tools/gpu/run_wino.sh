@@ -1,5 +1,4 @@
 cd /root/repo
-python -m pytest tests -q -m gpu -x 2>&1 | tail -15
-python bench.py 2>&1 | tail -1
-python bench.py --scenes 8 2>&1 | tail -1
-python bench.py --grid 64 2>&1 | tail -1
+python -m pytest tests/test_gpu_winograd.py tests/test_gpu_configs.py tests/test_gpu_parity.py -q -x 2>&1 | tail -8
+python tools/pose3d_probe.py 2>&1 | tail -4
+FORGE_WINOGRAD=0 python tools/pose3d_probe.py 2>&1 | tail -4

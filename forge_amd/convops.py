@@ -222,14 +222,77 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
 # ------------------------------------------------------------------------------------------------------------------
 # Winograd F(2x2, 3x3) x 3 depth taps for the stride-1 3x3x3 convolutions of the inference path (csrc/winograd.hip)
 # ------------------------------------------------------------------------------------------------------------------
-_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+@_lib.on_tensor_device
+def wino_pack_packed(wp, transpose=False):
+    """Packed weights [27][Cout][Cin] (pack_conv3d_weight) -> U [16][3][Cout][Cin] = G w[kd] G^T (forge_wino_weights: float64 inside,
+    rounded once). transpose: the weights of the DATA GRADIENT instead - the correlation of dy with the flipped kernel and swapped
+    channel roles, U [16][3][Cin][Cout]. One small kernel: the training path calls it per convolution and step."""
+    T, co_, ci_ = wp.shape
+    assert T == 27
+    wp = wp.detach()
+    wp = wp if wp.is_contiguous() else wp.contiguous()
+    U = torch.empty((16, 3, ci_, co_) if transpose else (16, 3, co_, ci_), dtype=torch.float32, device=wp.device)
+    _lib.check(_lib.lib().forge_wino_weights(_lib.ptr(wp), _lib.ptr(U), co_, ci_, 1 if transpose else 0, _lib.current_stream()), "forge_wino_weights")
+    return U
 
 
 def wino_pack_weight(w):
-    """nn.Conv3d weight [Cout,Cin,3,3,3] -> U [16][3][Cout][Cin]: U[4i+j][kd] = (G w[kd] G^T)[i][j], float64 product rounded once."""
-    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
-    U = torch.einsum("ia,jb,ockab->ijkoc", G, G, w.detach().double())
-    return U.reshape(16, 3, w.shape[0], w.shape[1]).float().contiguous()
+    """nn.Conv3d weight [Cout,Cin,3,3,3] -> U [16][3][Cout][Cin]: U[4i+j][kd] = (G w[kd] G^T)[i][j]."""
+    return wino_pack_packed(pack_conv3d_weight(w))
+
+
+def wino_conv_rows(x1, x2, U, bias, out, residual=None):
+    """out [n,D,H,W,Cout] = conv3x3x3(cat(x1, x2)) + bias (+ residual) on channels-last rows through the three Winograd launches.
+    x1 may have a batch stride (a view of a [b,t,...] stack)."""
+    n, D, H, W, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout = U.shape[2]
+    V1 = wino_input(x1, C1, C1, n, D, H, W, bs=_batch_stride_rows(x1))
+    V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W, bs=_batch_stride_rows(x2))
+    Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=x1.device)
+    wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
+    return wino_output(Mm, bias, None, None, 1.0, residual, None, None, out, None, None, n, D, H, W, Cout, Cout, EPI_BIAS)
+
+
+_ONE_ZERO = {}
+
+
+def _one_zero(device, C):
+    key = (str(device), C)
+    v = _ONE_ZERO.get(key)
+    if v is None:
+        v = _ONE_ZERO[key] = (torch.ones(C, device=device), torch.zeros(C, device=device))
+    return v
+
+
+def conv3_launch(x1, C1, x2, C2, wp, bias, out, grid, Cout, bs1=0, residual=None, dgrad=False, U=None, wT=None):
+    """out [rows][Cout] = conv3x3x3(cat(x1, x2)) + bias + residual on dense channels-last rows (x1 may have the batch stride bs1 rows),
+    from the layer's packed FORWARD weights wp [27][Co][Ci]. dgrad: the data gradient of that layer instead (x1 = dy with C1 = Co
+    channels, out = dx with Cout = Ci). Winograd launches when wino_applies, else the direct implicit-GEMM kernel. U / wT: the Winograd
+    weights / the transposed packed weights [27][Ci][Co] of the direct data gradient, if the caller caches them (frozen weights)."""
+    n, D, H, W = grid
+    if wino_applies(TAPS_3x3x3, 1, n, D, H, W, C1, C2, Cout):
+        U = U if U is not None else wino_pack_packed(wp, transpose=dgrad)
+        V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
+        V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
+        Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=out.device)
+        wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
+        return wino_output(Mm, bias, None, None, 1.0, residual, None, None, out, None, None, n, D, H, W, Cout, Cout, EPI_BIAS)
+    w = (wT if wT is not None else wp.transpose(1, 2).contiguous()) if dgrad else wp
+    taps = [(-a, -b, -c) for a, b, c in TAPS_3x3x3] if dgrad else TAPS_3x3x3
+    if residual is None:
+        return conv_igemm(x1, C1, C1, x2, C2, C2, w, bias, None, None, 1.0, None, None, None, out, None, grid, (D, H, W), Cout, Cout, taps,
+                          epilogue=EPI_BIAS, bs1=bs1)
+    one, zero = _one_zero(out.device, Cout)
+    return conv_igemm(x1, C1, C1, x2, C2, C2, w, bias, one, zero, 1.0, residual, None, None, out, None, grid, (D, H, W), Cout, Cout, taps,
+                      epilogue=EPI_AFFINE_ACT, bs1=bs1)
+
+
+def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
+    """The autograd convolution takes the Winograd launches for stride-1 3x3x3 problems with wide channels (K = 3 Cin per point must be
+    long enough to amortise the GEMM prologue; the 64-channel conv1 stays on the direct kernel)."""
+    return (wino_enabled() and istride == 1 and len(taps) == 27 and tuple(tuple(t) for t in taps) == tuple(TAPS_3x3x3) and C1 % 32 == 0 and C2 % 32 == 0
+            and C1 + C2 >= 128 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
 
 
 def wino_enabled():
@@ -333,8 +396,11 @@ class _ConvTapsRows(torch.autograd.Function):
         out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x1.device)
         bs1 = _batch_stride_rows(x1)
         bs2 = 0 if x2 is None else _batch_stride_rows(x2)
-        conv_igemm(x1, C1, C1, x2, C2, C2, wpc, bias, None, None, 1.0, None, None, None, out, None,
-                   (n, D, H, W), (Di, Hi, Wi), Cout, Cout, taps, istride=istride, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
+        if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
+            wino_conv_rows(x1, x2, wino_pack_packed(wpc), bias, out)
+        else:
+            conv_igemm(x1, C1, C1, x2, C2, C2, wpc, bias, None, None, 1.0, None, None, None, out, None,
+                       (n, D, H, W), (Di, Hi, Wi), Cout, Cout, taps, istride=istride, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
         ctx.save_for_backward(x1, x2, wpc)
         ctx.meta = (tuple(taps), istride, (D, H, W), bias is not None)
         return out
@@ -365,6 +431,9 @@ class _ConvTapsRows(torch.autograd.Function):
                     nb = min(16, Cin - j)
                     conv_igemm(dyk, 16, 16, None, 0, 0, wd[:, j:j + nb].contiguous(), None, None, None, 1.0, None, None, None, dx[..., j:], None,
                                (n, D, H, W), (D, H, W), nb, Cin, ntaps_, epilogue=EPI_BIAS)
+            elif istride == 1 and (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, Cout, 0, Cin):
+                dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
+                wino_conv_rows(dy, None, wino_pack_packed(wp, transpose=True), None, dx)
             elif istride == 1:
                 assert (D, H, W) == (Di, Hi, Wi)
                 dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)

@@ -69,6 +69,43 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     }
 }
 
+// U[4i+j][kd][o][c] = (G w[kd] G^T)[i][j] from packed weights wp[(kd 3 + a) 3 + b][co][ci]: one thread per (kd, o, c). Evaluated in float64
+// (exact: at most 9 fp32 terms with coefficients 1, 1/2, 1/4) and rounded once. transpose: the weights of the DATA GRADIENT - the
+// correlation of dy with the flipped kernel and swapped channel roles: w'[kd][a][b][o = ci][c = co] = wp[(2-kd, 2-a, 2-b)][co][ci].
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ wp, float* __restrict__ U, int Cout, int Cin, int transpose) {
+    const int No = transpose ? Cin : Cout, Nc = transpose ? Cout : Cin;      // U's [o][c] extents
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)No * Nc;
+    if (idx >= 3 * per) return;
+    const int kd = (int)(idx / per);
+    const long long oc = idx - kd * per;
+    const int o = (int)(oc / Nc), c = (int)(oc - (long long)o * Nc);
+    double w[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int tap = transpose ? ((2 - kd) * 3 + (2 - a)) * 3 + (2 - b) : (kd * 3 + a) * 3 + b;
+            w[a][b] = (double)wp[((long long)tap * Cout + (transpose ? c : o)) * Cin + (transpose ? o : c)];
+        }
+    double g[4][3];                                  // G w
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        g[0][b] = w[0][b];
+        g[1][b] = 0.5 * (w[0][b] + w[1][b] + w[2][b]);
+        g[2][b] = 0.5 * (w[0][b] - w[1][b] + w[2][b]);
+        g[3][b] = w[2][b];
+    }
+    float* up = U + ((long long)kd * No + o) * Nc + c;
+    const long long pt = 3 * per;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                    // (G w) G^T
+        up[(4 * i + 0) * pt] = (float)g[i][0];
+        up[(4 * i + 1) * pt] = (float)(0.5 * (g[i][0] + g[i][1] + g[i][2]));
+        up[(4 * i + 2) * pt] = (float)(0.5 * (g[i][0] - g[i][1] + g[i][2]));
+        up[(4 * i + 3) * pt] = (float)g[i][2];
+    }
+}
+
 enum WinoEpilogue : int { W_BIAS = 0, W_AFFINE_ACT = 1, W_GRU_GATES = 2, W_GRU_OUT = 3 };   // = ConvEpilogue of conv_igemm.hip
 
 struct WinoOutArgs {
@@ -181,6 +218,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
 }  // namespace forge
 
 using namespace forge;
+
+extern "C" int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int transpose, forge_stream_t stream) {
+    FORGE_REQUIRE(wp && U && Cout > 0 && Cin > 0, FORGE_EINVAL, "forge_wino_weights: bad argument");
+    const long long total = 3ll * Cout * Cin;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wp, U, Cout, Cin, transpose);
+    FORGE_LAUNCH_CHECK("forge_wino_weights");
+    return 0;
+}
 
 extern "C" int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                                 forge_stream_t stream) {

@@ -62,15 +62,15 @@ class _GRUCellRows(torch.autograd.Function):
         h = h.contiguous()
         wgc, woc = wg.detach().contiguous(), wo.detach().contiguous()
         bsx = co._batch_stride_rows(x)
-        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        grid = (b, D, H, W)
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
         g = new(2 * C)
-        co.conv_igemm(x, C, C, h, C, C, wgc, bg, None, None, 1.0, None, None, None, g, None, grid, ig, 2 * C, 2 * C, taps, epilogue=co.EPI_BIAS, bs1=bsx)
+        co.conv3_launch(x, C, h, C, wgc, bg, g, grid, 2 * C, bs1=bsx)
         z, r, hr = new(C), new(C), new(C)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         _lib.check(L.forge_gru_gates_fwd(p(g), p(h), p(z), p(r), p(hr), M, C, st()), "forge_gru_gates_fwd")
         cand = new(C)
-        co.conv_igemm(x, C, C, hr, C, C, woc, bo, None, None, 1.0, None, None, None, cand, None, grid, ig, C, C, taps, epilogue=co.EPI_BIAS, bs1=bsx)
+        co.conv3_launch(x, C, hr, C, woc, bo, cand, grid, C, bs1=bsx)
         hn = new(C)
         _lib.check(L.forge_gru_state_fwd(p(cand), p(h), p(z), p(hn), M, C, st()), "forge_gru_state_fwd")     # cand <- tanh(conv)
         ctx.save_for_backward(x, h, z, r, hr, cand, wgc, woc)
@@ -85,7 +85,6 @@ class _GRUCellRows(torch.autograd.Function):
         M = b * D * H * W
         dev = h.device
         grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
-        ntaps = [(-a, -b_, -c) for a, b_, c in taps]
         bsx = co._batch_stride_rows(x)
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
@@ -94,8 +93,7 @@ class _GRUCellRows(torch.autograd.Function):
         _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
         # candidate conv: c = conv([x | h r], wo)
         dxh = new(2 * C)                                                                   # (dx | d(h r))
-        co.conv_igemm(dc, C, C, None, 0, 0, wo.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh, None, grid, ig,
-                      2 * C, 2 * C, ntaps, epilogue=co.EPI_BIAS)
+        co.conv3_launch(dc, C, None, 0, wo, None, dxh, grid, 2 * C, dgrad=True)
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[4]:
             dwo = torch.zeros_like(wo)
@@ -106,8 +104,7 @@ class _GRUCellRows(torch.autograd.Function):
         dg = new(2 * C)
         _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
         dxh2 = new(2 * C)
-        co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, wg.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dxh2, None, grid, ig,
-                      2 * C, 2 * C, ntaps, epilogue=co.EPI_BIAS)
+        co.conv3_launch(dg, 2 * C, None, 0, wg, None, dxh2, grid, 2 * C, dgrad=True)
         if ctx.needs_input_grad[2]:
             dwg = torch.zeros_like(wg)
             co.conv_wgrad(dg, x, C, h, C, dwg, grid, ig, 2 * C, list(taps), bs1=bsx)
@@ -134,16 +131,15 @@ class _GRUCellPreRows(torch.autograd.Function):
         dev = h.device
         h, gx, cx = h.contiguous(), gx.contiguous(), cx.contiguous()
         wg, wo = wgh.detach().contiguous(), woh.detach().contiguous()
-        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        grid = (b, D, H, W)
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
-        one, zero = torch.ones(2 * C, device=dev), torch.zeros(2 * C, device=dev)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         g = new(2 * C)
-        co.conv_igemm(h, C, C, None, 0, 0, wg, bg, one, zero, 1.0, gx, None, None, g, None, grid, ig, 2 * C, 2 * C, taps, epilogue=co.EPI_AFFINE_ACT)
+        co.conv3_launch(h, C, None, 0, wg, bg, g, grid, 2 * C, residual=gx)
         z, r, hr = new(C), new(C), new(C)
         _lib.check(L.forge_gru_gates_fwd(p(g), p(h), p(z), p(r), p(hr), M, C, st()), "forge_gru_gates_fwd")
         cand = new(C)
-        co.conv_igemm(hr, C, C, None, 0, 0, wo, bo, one, zero, 1.0, cx, None, None, cand, None, grid, ig, C, C, taps, epilogue=co.EPI_AFFINE_ACT)
+        co.conv3_launch(hr, C, None, 0, wo, bo, cand, grid, C, residual=cx)
         hn = new(C)
         _lib.check(L.forge_gru_state_fwd(p(cand), p(h), p(z), p(hn), M, C, st()), "forge_gru_state_fwd")
         ctx.save_for_backward(h, z, r, hr, cand, wg, wo)
@@ -158,16 +154,13 @@ class _GRUCellPreRows(torch.autograd.Function):
         M = b * D * H * W
         dev = h.device
         grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
-        ntaps = [(-a, -b_, -c) for a, b_, c in taps]
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
-        one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
         dh, dz, dc = new(C), new(C), new(C)
         _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
         dhr = new(C)
-        co.conv_igemm(dc, C, C, None, 0, 0, wo.transpose(1, 2).contiguous(), None, None, None, 1.0, None, None, None, dhr, None, grid, ig, C, C, ntaps,
-                      epilogue=co.EPI_BIAS)
+        co.conv3_launch(dc, C, None, 0, wo, None, dhr, grid, C, dgrad=True)
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[5]:
             dwo = torch.zeros_like(wo)
@@ -177,8 +170,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         dg = new(2 * C)
         _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
         dh_total = new(C)                                          # dh (state + reset paths) + conv^T(dg, Wg_h), added in the GEMM epilogue
-        co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, wg.transpose(1, 2).contiguous(), None, one, zero, 1.0, dh, None, None, dh_total, None, grid, ig,
-                      C, C, ntaps, epilogue=co.EPI_AFFINE_ACT)
+        co.conv3_launch(dg, 2 * C, None, 0, wg, None, dh_total, grid, C, residual=dh, dgrad=True)
         if ctx.needs_input_grad[3]:
             dwg = torch.zeros_like(wg)
             co.conv_wgrad(dg, h, C, None, 0, dwg, grid, ig, 2 * C, list(taps))
@@ -201,26 +193,48 @@ class _FuseFrozen(torch.autograd.Function):
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
-        p = gru._packed()
         dev, M, vol = x.device, b * D * H * W, D * H * W
         grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         mean = xr.mean(dim=1).reshape(M, C)
         t0, h = new(), new()
-        co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, grid, ig, C, C, taps,
-                      epilogue=co.EPI_AFFINE_ACT)
-        co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, grid, ig, C, C, taps,
-                      epilogue=co.EPI_AFFINE_ACT)
+        wino = co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t)
         steps, out = [], new()
-        for ti in range(t):
-            xt = xr[:, ti]
-            z, hr, r, hn, cand = new(), new(), new(), new(), new()
-            co.conv_igemm(xt, C, C, h, C, C, p["gate_w"], p["gate_b"], None, None, 1.0, None, h, None, z, hr, grid, ig, 2 * C, C, taps,
-                          epilogue=co.EPI_GRU_GATES, bs1=t * vol, out3=r)
-            co.conv_igemm(xt, C, C, hr, C, C, p["out_w"], p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, hn, out if ti == t - 1 else None,
-                          grid, ig, C, C, taps, epilogue=co.EPI_GRU_OUT, bs1=t * vol, out3=cand)
-            steps.append((h, z, r, cand))
-            h = hn
+        if wino:                                                             # ConvGRU_3D._fuse_wino with the reset gate / candidate kept
+            p = gru._packed_wino()
+            Ht, Wt = H // 2, W // 2
+            R = b * D * Ht * Wt
+            Vx = co.wino_input(xr, C, C, b * t, D, H, W)
+            Vh = torch.empty(16, R, C, dtype=torch.float32, device=dev)
+            Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
+            Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
+            gru._wino_h0(p, mean, grid, Vh, Mc, t0, h)
+            for ti in range(t):
+                z, hr, r, hn, cand = new(), new(), new(), new(), new()
+                co.wino_input(h, C, C, b, D, H, W, out=Vh)
+                co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t)
+                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, r, *grid, 2 * C, C, co.EPI_GRU_GATES)
+                co.wino_input(hr, C, C, b, D, H, W, out=Vh)
+                co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t)
+                co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, hn, out if ti == t - 1 else None, cand, *grid, C, C,
+                               co.EPI_GRU_OUT)
+                steps.append((h, z, r, cand))
+                h = hn
+        else:
+            p = gru._packed()
+            co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, grid, ig, C, C, taps,
+                          epilogue=co.EPI_AFFINE_ACT)
+            co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, grid, ig, C, C, taps,
+                          epilogue=co.EPI_AFFINE_ACT)
+            for ti in range(t):
+                xt = xr[:, ti]
+                z, hr, r, hn, cand = new(), new(), new(), new(), new()
+                co.conv_igemm(xt, C, C, h, C, C, p["gate_w"], p["gate_b"], None, None, 1.0, None, h, None, z, hr, grid, ig, 2 * C, C, taps,
+                              epilogue=co.EPI_GRU_GATES, bs1=t * vol, out3=r)
+                co.conv_igemm(xt, C, C, hr, C, C, p["out_w"], p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, hn, out if ti == t - 1 else None,
+                              grid, ig, C, C, taps, epilogue=co.EPI_GRU_OUT, bs1=t * vol, out3=cand)
+                steps.append((h, z, r, cand))
+                h = hn
         ctx.gru, ctx.shape = gru, (b, t, C, D, H, W)
         ctx.steps, ctx.h0 = steps, (t0, steps[0][0])
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
@@ -232,11 +246,12 @@ class _FuseFrozen(torch.autograd.Function):
         b, t, C, D, H, W = ctx.shape
         p = gru._packed_T()
         dev, M = dout.device, b * D * H * W
-        grid, ig = (b, D, H, W), (D, H, W)
-        ntaps = [(-a, -b_, -c) for a, b_, c in co.TAPS_3x3x3]
+        grid = (b, D, H, W)
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         L, ptr, st = _lib.lib(), _lib.ptr, _lib.current_stream
-        one, zero = p["one"], p["zero"]
+        # data gradients of the four convolutions: Winograd launches with the cached transposed-domain weights, else the direct kernel
+        dgrad = lambda dy, Cdy, k, dst, Cdst, residual=None: co.conv3_launch(dy, Cdy, None, 0, p[k + "_w"], None, dst, grid, Cdst, residual=residual,
+                                                                           dgrad=True, U=p[k + "_UT"], wT=p[k + "_wT"])
         dr = dout.permute(0, 2, 3, 4, 1)
         dr = (dr if dr.is_contiguous() else dr.contiguous()).reshape(M, C)
         dhn = dr * p["norm_scale"]                                           # out = fusion_norm(h_T) = h_T * scale + shift
@@ -247,14 +262,12 @@ class _FuseFrozen(torch.autograd.Function):
             dh, dz, dc, dg = new(), new(), new(), new(2 * C)
             _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, st()), "forge_gru_state_bwd")
             dxh = new(2 * C)                                                 # (d x_t | d (h r)) of the candidate conv
-            co.conv_igemm(dc, C, C, None, 0, 0, p["out_wT"], None, None, None, 1.0, None, None, None, dxh, None, grid, ig, 2 * C, 2 * C, ntaps,
-                          epilogue=co.EPI_BIAS)
+            dgrad(dc, C, "out", dxh, 2 * C)
             # dg = gate pre-activation gradients; dh + d(hr) r lands in dxh's right half (over d(hr)): dxh = (dx_t part 1 | dh partial)
             _lib.check(L.forge_gru_gates_bwd(ptr(dz), ptr(dxh[:, C:]), 2 * C, ptr(h), ptr(z), ptr(r), ptr(dg), ptr(dh), ptr(dxh[:, C:]), 2 * C, M, C,
                                              st()), "forge_gru_gates_bwd")
             tot = new(2 * C)                                                 # conv^T(dg, Wg) + dxh = (d x_t | d h_{t-1})
-            co.conv_igemm(dg, 2 * C, 2 * C, None, 0, 0, p["gate_wT"], None, one, zero, 1.0, dxh, None, None, tot, None, grid, ig, 2 * C, 2 * C, ntaps,
-                          epilogue=co.EPI_AFFINE_ACT)
+            dgrad(dg, 2 * C, "gate", tot, 2 * C, residual=dxh)
             dx[:, ti] = tot.view(b, D, H, W, 2 * C)[..., :C]
             dhn, ld_dhn = tot[:, C:], 2 * C
         # h0 = lrelu(bn4(conv(lrelu(bn1(conv(mean_t x))))))
@@ -262,9 +275,9 @@ class _FuseFrozen(torch.autograd.Function):
         g = torch.empty(M, C, dtype=torch.float32, device=dev)
         affine_act_bwd(dhn, h0, p["bn4_scale"], 0.01, out=g)
         g2 = new()
-        co.conv_igemm(g, C, C, None, 0, 0, p["fc3_wT"], None, None, None, 1.0, None, None, None, g2, None, grid, ig, C, C, ntaps, epilogue=co.EPI_BIAS)
+        dgrad(g, C, "fc3", g2, C)
         affine_act_bwd(g2, t0, p["bn1_scale"], 0.01, out=g)
-        co.conv_igemm(g, C, C, None, 0, 0, p["fc0_wT"], None, None, None, 1.0, None, None, None, g2, None, grid, ig, C, C, ntaps, epilogue=co.EPI_BIAS)
+        dgrad(g, C, "fc0", g2, C)
         dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
         ctx.steps = ctx.h0 = None
         return dx.permute(0, 1, 5, 2, 3, 4), None
@@ -341,11 +354,9 @@ class ConvGRU_3D(co.PackedModule):
         p = self._packed()
         if "gate_wT" not in p:
             tr = lambda w: w.transpose(1, 2).contiguous()
-            dev = p["gate_w"].device
-            C2 = p["gate_w"].shape[1]
             p.update({"gate_wT": tr(p["gate_w"]), "out_wT": tr(p["out_w"]), "fc0_wT": tr(p["fc0_w"]), "fc3_wT": tr(p["fc3_w"]),
-                      "norm_scale": p["norm"][0], "bn1_scale": p["bn1"][0], "bn4_scale": p["bn4"][0],
-                      "one": torch.ones(C2, device=dev), "zero": torch.zeros(C2, device=dev)})
+                      "norm_scale": p["norm"][0], "bn1_scale": p["bn1"][0], "bn4_scale": p["bn4"][0]})
+            p.update({k + "_UT": co.wino_pack_packed(p[k + "_w"], transpose=True) for k in ("gate", "out", "fc0", "fc3")})   # Winograd-domain data-gradient weights
         return p
 
     def fuse_frozen_hip(self, x):

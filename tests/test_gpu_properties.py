@@ -111,7 +111,7 @@ def test_render_backward_vs_float64_oracle(dev, D, Hr, V):
     assert (dh.grad.cpu().double() - gd_ref).abs().max().item() < 1e-4 * gd_ref.abs().max().item()
 
 
-def test_conv_full_size_adjoints(dev):
+def test_conv_full_size_adjoints(dev, monkeypatch):
     """The ConvGRU gates convolution at full size (M = 32^3, 128+128 -> 256 channels): forward vs data gradient vs weight
     gradient are mutually adjoint — <conv(x;W), y> == <x, dgrad(y;W)> == <W, wgrad(x,y)>."""
     g = torch.Generator().manual_seed(1)
@@ -125,13 +125,22 @@ def test_conv_full_size_adjoints(dev):
     lhs = _dot(out.detach(), y)
     assert abs(lhs - (_dot(x1.detach(), x1.grad) + _dot(x2.detach(), x2.grad))) < 2e-5 * max(abs(lhs), 1.0)
     assert abs(lhs - _dot(w.detach(), w.grad)) < 2e-5 * max(abs(lhs), 1.0)
+    # the same three identities on the direct implicit-GEMM kernels (the autograd convolution above took the Winograd launches)
+    monkeypatch.setenv("FORGE_WINOGRAD", "0")
+    x1.grad = x2.grad = w.grad = None
+    direct = co.conv3x3x3_rows(x1, x2, w, None)
+    (direct * y).sum().backward()
+    lhs = _dot(direct.detach(), y)
+    assert abs(lhs - (_dot(x1.detach(), x1.grad) + _dot(x2.detach(), x2.grad))) < 2e-5 * max(abs(lhs), 1.0)
+    assert abs(lhs - _dot(w.detach(), w.grad)) < 2e-5 * max(abs(lhs), 1.0)
+    assert (direct.detach() - out.detach()).abs().max().item() < 1e-5 * out.detach().abs().max().item()
     # the fused inference epilogue (bias + identity affine, slope 1) equals the raw conv
     wp = co.pack_conv3d_weight(w.detach())
     fused = torch.empty_like(out)
     one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
     co.conv_igemm(x1.detach(), 128, 128, x2.detach(), 128, 128, wp, zero, one, zero, 1.0, None, None, None, fused, None, (1, D, D, D), (D, D, D),
                   256, 256, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
-    assert torch.equal(fused, out.detach())
+    assert torch.equal(fused, direct.detach())
 
 
 def test_graph_replay_is_deterministic(dev):

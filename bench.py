@@ -105,8 +105,7 @@ def stage_timers(model):
         out = o_g(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw)
         e1.record()
         R = n * D * Ht * Wt
-        tile, _ = co.conv_plan(16 * R, Cout, C1 + C2, 3, co.EPI_BIAS, Cout, ws_bytes=0)
-        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[tile], []).append((e0, e1, 2.0 * 16 * R * Cout * 3 * (C1 + C2), (16 * R, Cout, 3, C1 + C2)))
+        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout)], []).append((e0, e1, 2.0 * 16 * R * Cout * 3 * (C1 + C2), (16 * R, Cout, 3, C1 + C2)))
         return out
 
     def input_timed(x, C, ld, n, D, H, W, **kw):
@@ -133,7 +132,7 @@ def stage_timers(model):
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*pmc_summary.json: separate --pmc
+    """HBM bytes per launch of the kernel whose summary key contains `prefix`, from the committed rocprofv3 PMC passes (profiles/*pmc_summary.json: separate --pmc
     FETCH_SIZE / WRITE_SIZE runs of tools/probe_kernels.py, FETCH_SIZE doubled per MI355X_MICROARCH.md). PMC counters
     cannot be read from inside this process; null when no summary is committed."""
     import glob
@@ -143,7 +142,7 @@ def pmc_traffic(prefix):
         except Exception:
             continue
         for k, v in d.items():
-            if k.startswith(prefix) and isinstance(v, dict) and "hbm_bytes_corrected" in v:
+            if prefix in k and isinstance(v, dict) and "hbm_bytes_corrected" in v:
                 return {"hbm_bytes_per_launch": v["hbm_bytes_corrected"], "algorithmic_bytes": v.get("algorithmic_bytes"),
                         "launch": k, "source": os.path.basename(f)}
     return None
@@ -607,7 +606,7 @@ def main():
         for k, v in wino_rec.items():          # Winograd transform kernels of the fusion, as launched inside the step
             ms, by = sum(x[0].elapsed_time(x[1]) for x in v), sum(x[2] for x in v)
             kern[k] = {"bound": "hbm", "launches_per_step": len(v), "ms_total": ms, "bytes": by, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic(k),
                        "note": "HIP events around the eager launches of one step (each includes the host launch gap); the transformed operands "
                                "(67-134 MB per launch at one scene) are partly served by the 256 MB Infinity Cache"}
         # dominant kernel of the step: conv_igemm_kernel<BM, BN, waves> - ONE kernel (csrc/conv_igemm.hip) whose tile shape is picked per
@@ -628,11 +627,11 @@ def main():
         roofline = {"kernel": "conv_igemm_kernel<BM, BN, waves> (fp32 MFMA implicit-GEMM conv; all %d launches of one step, %d tile instantiations)"
                               % (n_launch, len(convs)),
                     "bound": "mfma", "achieved": tot_gf / tot_ms, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TF,
-                    "traffic": pmc_traffic("conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
+                    "traffic": pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
                     "gflop_per_step": tot_gf, "share_of_step": tot_ms / step_ms, "instantiations": inst,
                     "note": "durations are HIP events around each launch on the launch stream in an eager (non-graph) pass, so each includes "
                             "the host launch gap (and, for split-K launches, the reduction kernel); traffic is the PMC pass of the "
-                            "ConvGRU-gates launch of the 128x128 instantiation"}
+                            "ConvGRU-gates launch (the Winograd point-GEMM launch when the fusion runs it)"}
         if args.grid == 32:
             metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
             workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "

@@ -289,10 +289,11 @@ def conv3_launch(x1, C1, x2, C2, wp, bias, out, grid, Cout, bs1=0, residual=None
 
 
 def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
-    """The autograd convolution takes the Winograd launches for stride-1 3x3x3 problems with wide channels (K = 3 Cin per point must be
-    long enough to amortise the GEMM prologue; the 64-channel conv1 stays on the direct kernel)."""
+    """Stride-1 3x3x3 problems with GEMM-sized channel counts take the Winograd launches: K = 3 Cin per point must amortise the GEMM
+    prologue (measured, tools/wino_gemm_sweep.py: conv1's Cin = 64 -> 128 still runs at 95 TF of MFMA work = 214 TF direct-equivalent
+    against 120 TF on the direct kernel); narrower layers (the heads' 32 -> 16 / 8) stay on the direct kernels."""
     return (wino_enabled() and istride == 1 and len(taps) == 27 and tuple(tuple(t) for t in taps) == tuple(TAPS_3x3x3) and C1 % 32 == 0 and C2 % 32 == 0
-            and C1 + C2 >= 128 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
+            and C1 + C2 >= 64 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
 
 
 def wino_enabled():
@@ -327,6 +328,11 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
                                           0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, _lib.current_stream()),
                "forge_wino_gemm")
     return Mm
+
+
+def wino_gemm_tile(R, Cout):
+    """Tile letter forge_wino_gemm uses for R tile rows per point (names the kernel instantiation for profilers, bench.py)."""
+    return chr(_lib.lib().forge_wino_gemm_tile(int(R), int(Cout)))
 
 
 @_lib.on_tensor_device

@@ -803,6 +803,15 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     return 0;
 }
 
+// Workgroup tile of forge_wino_gemm for R tile rows per point. The makespan model (plan_conv) was fitted on single-problem launches; for
+// the 16 short-K problems of one launch the measured optimum (tools/wino_gemm_sweep.py, 1 and 4 scenes) is the 64x128 tile, except for
+// wide outputs on a small grid (the gates launch of one scene: 64x64 at 112 TF vs 104 TF), where more, smaller workgroups balance the
+// partial rounds better. FORGE_CONV_TILE overrides it (that tool).
+extern "C" int forge_wino_gemm_tile(long long R, int Cout) {
+    if (const char* ft = getenv("FORGE_CONV_TILE")) return *ft;
+    return (Cout >= 256 && 16 * R * (long long)Cout < (48ll << 20)) ? 'D' : 'B';
+}
+
 // The 16 point-GEMMs of a Winograd F(2x2, 3x3) x 3-depth-tap convolution (winograd.hip) in ONE launch: problem p = (i, j) multiplies
 // the transformed inputs V[p] (rows = (n, z, tile row, tile col), channels-last, the channel concatenation of V1 and V2) with the
 // transformed weights U[p] [3 depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a 3-tap implicit GEMM over the tile grid, K = 3 (C1 + C2).
@@ -826,8 +835,7 @@ extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, 
     a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = 3; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = 3; a.epi = EPI_BIAS;
     a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = 3ll * Cout * (C1 + C2); a.pto = R * Cout;
     a.tap[0][0] = -1; a.tap[2][0] = 1;                                  // depth taps (-1,0,0), (0,0,0), (1,0,0)
-    const ConvPlan pl = plan_conv(R * 16, Cout, C1 + C2, 3, false, 0);
-    if (int rc = launch_conv_tile(a, pl.tile, (hipStream_t)stream)) return rc;
+    if (int rc = launch_conv_tile(a, (char)forge_wino_gemm_tile(R, Cout), (hipStream_t)stream)) return rc;
     FORGE_LAUNCH_CHECK("forge_wino_gemm");
     return 0;
 }

@@ -420,13 +420,19 @@ class Encoder3D(co.PackedModule):
     def _conv1_hip(self, vol_rows):
         """conv1 = Conv3d(64,128,3,p1)+BN+LeakyReLU as one GEMM (models/encoder.py:36-40). vol_rows [N,D,H,W,64]."""
         conv, bn = self.conv1[0], self.conv1[1]
-        w, bias, sc, sh = self._c1_cache.get(
+        w, bias, sc, sh, U = self._c1_cache.get(
             [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var],
-            lambda: (co.pack_conv3d_weight(conv.weight), conv.bias.detach().contiguous()) + co.bn_affine(bn))
+            lambda: (co.pack_conv3d_weight(conv.weight), conv.bias.detach().contiguous()) + co.bn_affine(bn) + (co.wino_pack_weight(conv.weight),))
         n, D, H, W, C = vol_rows.shape
         out = torch.empty(n, D, H, W, 128, dtype=torch.float32, device=vol_rows.device)
-        co.conv_igemm(vol_rows, C, C, None, 0, 0, w, bias, sc, sh, 0.01, None, None, None, out, None,
-                      (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
+        if co.wino_applies(co.TAPS_3x3x3, 1, n, D, H, W, C, 0, 128):       # Winograd F(2x2,3x3) x 3 depth taps, BN + LeakyReLU in the inverse transform
+            V = co.wino_input(vol_rows, C, C, n, D, H, W)
+            Mm = torch.empty(16, n * D * (H // 2) * (W // 2), 128, dtype=torch.float32, device=vol_rows.device)
+            co.wino_gemm(V, C, None, 0, U, Mm, n, D, H // 2, W // 2, 128)
+            co.wino_output(Mm, bias, sc, sh, 0.01, None, None, None, out, None, None, n, D, H, W, 128, 128, co.EPI_AFFINE_ACT)
+        else:
+            co.conv_igemm(vol_rows, C, C, None, 0, 0, w, bias, sc, sh, 0.01, None, None, None, out, None,
+                          (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)
         return out.permute(0, 4, 1, 2, 3)
 
     def _heads_packed_T(self):

@@ -214,6 +214,7 @@ int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, l
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                     long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream);
+int forge_wino_gemm_tile(long long R, int Cout);   /* the workgroup tile letter ('A'..'E', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point */
 int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
                       int ldo, int epilogue, forge_stream_t stream);

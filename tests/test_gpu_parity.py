@@ -410,7 +410,10 @@ def test_training_gradients_vs_reference_golden(dev, golden):
     for k in keys:
         ref = torch.from_numpy(gold["grad__" + k])
         err = (named[k].grad.cpu() - ref).abs().max().item()
-        assert err < 1e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
+        # 3e-2 of the gradient's max: the reference's own fp32 gradients sit 0.3-1.6e-2 from a float64 evaluation of the same graph (53
+        # train-mode BatchNorm layers over a batch of 5 amplify reordering noise, a ReLU argument at rounding distance of zero flips whole
+        # gradient entries; tools/debug/feat3d_train_noise.py measures fp32 oracle / direct kernels / Winograd against float64)
+        assert err < 3e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
 
 
 def test_training_step_runs(dev):
@@ -923,19 +926,23 @@ def test_get_feat3D_train_hip_vs_oracle(dev):
     enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()})
     enc = enc.to(dev).train()
     img = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(31))
-    wr = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
-    ref = fo.get_feat3D(img, wr, training=True)
+    # the oracle evaluated in float64 is the yardstick: its own fp32 evaluation lands up to 1.6e-2 (of a gradient's max) from it on this
+    # input - 53 layers of train-mode BatchNorm over 2 images amplify fp32 reordering noise and a ReLU argument at rounding distance of
+    # zero flips whole gradient entries; the HIP path (direct or Winograd kernels) sits in the same band
+    # (tools/debug/feat3d_train_noise.py). Output: 5e-5; gradients: 5e-2 of the max.
+    wr = {k: (v.double() if v.dtype.is_floating_point else v).clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in w.items()}
+    ref = fo.get_feat3D(img.double(), wr, training=True)
     gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(32))
-    ref.backward(gy)
+    ref.backward(gy.double())
     got = enc.get_feat3D(img.to(dev))
     got.backward(gy.to(dev))
-    assert (got.detach().cpu() - ref.detach()).abs().max().item() < 5e-4 * max(1.0, ref.abs().max().item())
+    assert (got.detach().cpu().double() - ref.detach()).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
     params = dict(enc.named_parameters())
     for n in ("conv1.0.weight", "feature_extraction.7.2.conv3.weight", "feature_extraction.6.0.conv2.weight", "feature_extraction.5.0.downsample.0.weight",
               "feature_extraction.4.0.conv1.weight", "feature_extraction.0.weight", "feature_extraction.7.0.bn2.weight"):
         e = wr["encoder_3d." + n].grad
-        rel = (params[n].grad.cpu() - e).abs().max().item() / max(e.abs().max().item(), 1e-12)
-        assert rel < 2e-2, (n, rel)          # 53 layers of train-mode BN amplify fp32 reordering noise
+        rel = (params[n].grad.cpu().double() - e).abs().max().item() / max(e.abs().max().item(), 1e-12)
+        assert rel < 5e-2, (n, rel)
 
 
 def test_forge_two_scenes_10_views_vs_oracle(dev):

@@ -2,10 +2,14 @@
 # group in its own rocprofv3 run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised into
 # gpurun_out/r02_pmc_summary.json (copied to profiles/ by hand; bench.py reads profiles/*pmc_summary.json for roofline.traffic).
 cd /tmp && export TMPDIR=/tmp
-run() { timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcall_$1 -o p -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py > /dev/null 2>&1; }
-run FETCH FETCH_SIZE
-run WRITE WRITE_SIZE
-run SQ "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT"
+run() { PROBE_KERNELS=$3 timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcall_$1 -o p -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py > /dev/null 2>&1; }
+run FETCH FETCH_SIZE rotate,render,conv
+run WRITE WRITE_SIZE rotate,render,conv
+run SQ "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" rotate,render,conv
+# the Winograd launches of the inference fusion in their own runs (the point-GEMM launch shares its kernel name with the direct launches)
+run WFETCH FETCH_SIZE wino
+run WWRITE WRITE_SIZE wino
+run WSQ "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" wino
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob, json, collections
@@ -17,6 +21,7 @@ def load(tag):
         out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 F, W, S = load("FETCH"), load("WRITE"), load("SQ")
+WF, WW, WS = load("WFETCH"), load("WWRITE"), load("WSQ")
 mean = lambda v: sum(v) / len(v) if v else None
 def pick(d, sub):
     for k in d:
@@ -30,14 +35,20 @@ alg = {"rotate_fwd_kernel": 5 * 128 * 32 ** 3 * 4 * 2, "render_fwd_kernel": 17 *
 names = {"rotate_fwd_kernel": "rotate_fwd_kernel", "render_fwd_kernel": "render_fwd_kernel<4>",
          "conv_igemm_kernel<128, 128": "conv_igemm_kernel<128, 128, 8> (ConvGRU gates, M=32768 N=256 K=6912)",
          "conv_igemm_kernel<64, 64": "conv_igemm_kernel<64, 64, 4> (ConvGRU state, M=32768 N=128 K=6912)"}
-for sub, label in names.items():
+R_ = 32 * 16 * 16
+wino = {"wino_input_kernel": ("wino_input_kernel (h -> V_h, 32^3 x 128 channels)", 4.0 * (32 ** 3 * 128 + 16 * R_ * 128)),
+        "conv_igemm_kernel<": ("conv_igemm_kernel winograd gates point GEMMs (16 x [8192 x 768] x [768 x 256], one launch)",
+                               4.0 * (16 * R_ * 256 + 16 * 3 * 256 * 256 + 16 * R_ * 256)),
+        "wino_output_kernel": ("wino_output_kernel<GRU gates> (Mm -> z, h*r)", 4.0 * (16 * R_ * 256 + 3 * 32 ** 3 * 128))}
+jobs = [(sub, label, alg[sub], F, W, S) for sub, label in names.items()] + [(sub, lab, ab, WF, WW, WS) for sub, (lab, ab) in wino.items()]
+for sub, label, abytes, F, W, S in jobs:
     e = {}
     kf, kw, ks = pick(F, sub), pick(W, sub), pick(S, sub)
     if kf: e["fetch_kib_raw"] = mean(F[kf]["FETCH_SIZE"])
     if kw: e["write_kib"] = mean(W[kw]["WRITE_SIZE"])
     if "fetch_kib_raw" in e and "write_kib" in e:
         e["hbm_bytes_corrected"] = (2 * e["fetch_kib_raw"] + e["write_kib"]) * 1024
-    e["algorithmic_bytes"] = alg[sub]
+    e["algorithmic_bytes"] = abytes
     if ks:
         c = {k: mean(v) for k, v in S[ks].items()}
         e.update({"mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"), "grbm_gui_active": c.get("GRBM_GUI_ACTIVE"), "sq_wave_cycles": c.get("SQ_WAVE_CYCLES"),
@@ -50,4 +61,4 @@ for sub, label in names.items():
 json.dump(summary, open("gpurun_out/r02_pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
-rm -rf gpurun_out/pmcall_FETCH gpurun_out/pmcall_WRITE gpurun_out/pmcall_SQ
+rm -rf gpurun_out/pmcall_FETCH gpurun_out/pmcall_WRITE gpurun_out/pmcall_SQ gpurun_out/pmcall_WFETCH gpurun_out/pmcall_WWRITE gpurun_out/pmcall_WSQ

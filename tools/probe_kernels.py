@@ -58,5 +58,23 @@ if "conv" in which:
     for _ in range(iters):
         co.conv_igemm(x, Cc, Cc, o2, Cc, Cc, wps, bias[:128], None, None, 1.0, None, hbuf, zbuf, o1, None, (1, D, D, D), (D, D, D), 128, Cc,
                       co.TAPS_3x3x3, epilogue=co.EPI_GRU_OUT)
+if "wino" in which:
+    # the ConvGRU gates convolution as the inference path runs it (csrc/winograd.hip): transform of h, the 16 point GEMMs over
+    # [V_x | V_h] (one conv_igemm_kernel launch; its own PMC run: the kernel name is shared with the direct launches above), inverse
+    # transform fused with the gate epilogue
+    D, Cc = 32, 128
+    M, R = D ** 3, D * (D // 2) * (D // 2)
+    h = torch.randn(M, Cc, device=dev)
+    Vx, Vh = torch.randn(16, R, Cc, device=dev), torch.empty(16, R, Cc, device=dev)
+    U = torch.randn(16, 3, 256, 256, device=dev) * 0.02
+    Mm = torch.empty(16, R, 256, device=dev)
+    bias = torch.zeros(256, device=dev)
+    z, hr = torch.empty(M, Cc, device=dev), torch.empty(M, Cc, device=dev)
+    for _ in range(iters):
+        co.wino_input(h, Cc, Cc, 1, D, D, D, out=Vh)
+    for _ in range(iters):
+        co.wino_gemm(Vx, Cc, Vh, Cc, U, Mm, 1, D, D // 2, D // 2, 256)
+    for _ in range(iters):
+        co.wino_output(Mm, bias, None, None, 1.0, None, h, None, z, hr, None, 1, D, D, D, 256, Cc, co.EPI_GRU_GATES)
 torch.cuda.synchronize()
 print("probe done")

@@ -228,11 +228,12 @@ def wino_pack_packed(wp, transpose=False):
     rounded once). transpose: the weights of the DATA GRADIENT instead - the correlation of dy with the flipped kernel and swapped
     channel roles, U [16][3][Cin][Cout]. One small kernel: the training path calls it per convolution and step."""
     T, co_, ci_ = wp.shape
-    assert T == 27
+    assert T in (27, 9)                     # 3x3x3 kernels, or the 3x3 kernels of a 2-D convolution (pack_conv2d_weight): kd = 3 / 1 depth taps
+    kd = T // 9
     wp = wp.detach()
     wp = wp if wp.is_contiguous() else wp.contiguous()
-    U = torch.empty((16, 3, ci_, co_) if transpose else (16, 3, co_, ci_), dtype=torch.float32, device=wp.device)
-    _lib.check(_lib.lib().forge_wino_weights(_lib.ptr(wp), _lib.ptr(U), co_, ci_, 1 if transpose else 0, _lib.current_stream()), "forge_wino_weights")
+    U = torch.empty((16, kd, ci_, co_) if transpose else (16, kd, co_, ci_), dtype=torch.float32, device=wp.device)
+    _lib.check(_lib.lib().forge_wino_weights(_lib.ptr(wp), _lib.ptr(U), co_, ci_, kd, 1 if transpose else 0, _lib.current_stream()), "forge_wino_weights")
     return U
 
 
@@ -321,11 +322,12 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
     """Mm[16][n D Ht Wt][Cout] = the 16 point GEMMs. V1 [16][n views D Ht Wt][C1] may hold `views` views per batch element (the
     transformed inputs of every view of a scene, made by ONE wino_input launch): this call reads view `view`. V2 [16][R][C2] or None."""
     vol = D * Ht * Wt
-    if U.shape != (16, 3, Cout, C1 + C2):
+    kd = U.shape[1]
+    if U.shape != (16, kd, Cout, C1 + C2) or kd not in (1, 3):
         raise ValueError("transformed weight %s does not match Cout=%d Cin=%d" % (tuple(U.shape), Cout, C1 + C2))
     p1 = ctypes.c_void_p(V1.data_ptr() + 4 * view * vol * C1)
     _lib.check(_lib.lib().forge_wino_gemm(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
-                                          0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, _lib.current_stream()),
+                                          0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd, _lib.current_stream()),
                "forge_wino_gemm")
     return Mm
 

@@ -814,10 +814,11 @@ extern "C" int forge_wino_gemm_tile(long long R, int Cout) {
 
 // The 16 point-GEMMs of a Winograd F(2x2, 3x3) x 3-depth-tap convolution (winograd.hip) in ONE launch: problem p = (i, j) multiplies
 // the transformed inputs V[p] (rows = (n, z, tile row, tile col), channels-last, the channel concatenation of V1 and V2) with the
-// transformed weights U[p] [3 depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a 3-tap implicit GEMM over the tile grid, K = 3 (C1 + C2).
+// transformed weights U[p] [kd depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a kd-tap implicit GEMM over the tile grid, K = kd (C1 + C2);
+// kd = 3 for the 3x3x3 convolutions, kd = 1 for the 3x3 convolutions of a 2-D network (D = 1 or D = images: planes do not mix).
 extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
-                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream) {
-    FORGE_REQUIRE(V1 && U && Mm, FORGE_EINVAL, "forge_wino_gemm: null pointer argument");
+                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream) {
+    FORGE_REQUIRE(V1 && U && Mm && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_gemm: null pointer argument / kd not 1 or 3");
     FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 16, FORGE_EINVAL, "forge_wino_gemm: bad dims n=%d D=%d Ht=%d Wt=%d Cout=%d (Cout > 16)", n,
                   D, Ht, Wt, Cout);
     FORGE_REQUIRE(C1 > 0 && C1 % BK == 0 && C2 >= 0 && C2 % BK == 0 && (C2 == 0) == (V2 == nullptr), FORGE_ESHAPE,
@@ -832,9 +833,9 @@ extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, 
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && R < (1ll << 31), FORGE_ESHAPE,
                   "forge_wino_gemm: an operand spans >= 2 GiB per Winograd point (32-bit buffer offsets); split the batch");
     a.wp = U; a.slope = 1.f; a.out = Mm; a.n = n; a.D = D; a.H = Ht; a.W = Wt; a.is = 1; a.Di = D; a.Hi = Ht; a.Wi = Wt;
-    a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = 3; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = 3; a.epi = EPI_BIAS;
-    a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = 3ll * Cout * (C1 + C2); a.pto = R * Cout;
-    a.tap[0][0] = -1; a.tap[2][0] = 1;                                  // depth taps (-1,0,0), (0,0,0), (1,0,0)
+    a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = kd; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = kd; a.epi = EPI_BIAS;
+    a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = (long long)kd * Cout * (C1 + C2); a.pto = R * Cout;
+    if (kd == 3) { a.tap[0][0] = -1; a.tap[2][0] = 1; }                 // depth taps (-1,0,0), (0,0,0), (1,0,0); kd = 1: the 2-D convolution's single tap
     if (int rc = launch_conv_tile(a, (char)forge_wino_gemm_tile(R, Cout), (hipStream_t)stream)) return rc;
     FORGE_LAUNCH_CHECK("forge_wino_gemm");
     return 0;

@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
 // U[4i+j][kd][o][c] = (G w[kd] G^T)[i][j] from packed weights wp[(kd 3 + a) 3 + b][co][ci]: one thread per (kd, o, c). Evaluated in float64
 // (exact: at most 9 fp32 terms with coefficients 1, 1/2, 1/4) and rounded once. transpose: the weights of the DATA GRADIENT - the
 // correlation of dy with the flipped kernel and swapped channel roles: w'[kd][a][b][o = ci][c = co] = wp[(2-kd, 2-a, 2-b)][co][ci].
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ wp, float* __restrict__ U, int Cout, int Cin, int transpose) {
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ wp, float* __restrict__ U, int Cout, int Cin, int KD, int transpose) {
     const int No = transpose ? Cin : Cout, Nc = transpose ? Cout : Cin;      // U's [o][c] extents
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)No * Nc;
-    if (idx >= 3 * per) return;
+    if (idx >= KD * per) return;                      // KD = 3 depth taps (3x3x3 kernels) or 1 (3x3 kernels of a 2-D convolution)
     const int kd = (int)(idx / per);
     const long long oc = idx - kd * per;
     const int o = (int)(oc / Nc), c = (int)(oc - (long long)o * Nc);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-            const int tap = transpose ? ((2 - kd) * 3 + (2 - a)) * 3 + (2 - b) : (kd * 3 + a) * 3 + b;
+            const int tap = transpose ? ((KD - 1 - kd) * 3 + (2 - a)) * 3 + (2 - b) : (kd * 3 + a) * 3 + b;
             w[a][b] = (double)wp[((long long)tap * Cout + (transpose ? c : o)) * Cin + (transpose ? o : c)];
         }
     double g[4][3];                                  // G w
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
         g[3][b] = w[2][b];
     }
     float* up = U + ((long long)kd * No + o) * Nc + c;
-    const long long pt = 3 * per;
+    const long long pt = KD * per;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                    // (G w) G^T
         up[(4 * i + 0) * pt] = (float)g[i][0];
@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
 
 using namespace forge;
 
-extern "C" int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int transpose, forge_stream_t stream) {
-    FORGE_REQUIRE(wp && U && Cout > 0 && Cin > 0, FORGE_EINVAL, "forge_wino_weights: bad argument");
-    const long long total = 3ll * Cout * Cin;
-    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wp, U, Cout, Cin, transpose);
+extern "C" int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int kd, int transpose, forge_stream_t stream) {
+    FORGE_REQUIRE(wp && U && Cout > 0 && Cin > 0 && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_weights: bad argument (kd = 1 or 3)");
+    const long long total = (long long)kd * Cout * Cin;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wp, U, Cout, Cin, kd, transpose);
     FORGE_LAUNCH_CHECK("forge_wino_weights");
     return 0;
 }

@@ -6,6 +6,8 @@ methods (`get_feat3D`, `get_density3D`, `get_render_features`, `fuse`) and the s
 (SURVEY.md Appendix B). torchvision is not a dependency: the ResNet-50 trunk is built here with
 torchvision's module names so published checkpoints load with strict=True.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -296,6 +298,7 @@ class Encoder3D(co.PackedModule):
         return r if r.is_contiguous() else r.contiguous()
 
     LIFT_Z, LIFT_C = 32, 64          # z_2d.view(-1, 64, 32, H, W): trunk channel c = c3d*32 + z (models/encoder.py:49)
+    TRUNK_WINO_MIN_PLANES = int(os.environ.get("FORGE_TRUNK_WINO_MIN", "256"))
 
     def _trunk_packed(self):
         """Packed weights of ResNet layers 1-4 for the GEMM kernel. The 2048-wide residual stream of layer4 is kept in
@@ -322,7 +325,10 @@ class Encoder3D(co.PackedModule):
                     a3 = co.bn_affine(blk.bn3)
                     if pout is not None:
                         w3, a3 = w3[pout], (a3[0][pout].contiguous(), a3[1][pout].contiguous())
-                    d = {"w1": w1[None].contiguous(), "a1": co.bn_affine(blk.bn1), "w2": w2, "taps2": taps2, "a2": co.bn_affine(blk.bn2),
+                    # stride-1 3x3 convolutions with GEMM-sized channel counts (layer3 / layer4: K = planes >= 256 per Winograd point) run as
+                    # Winograd F(2x2, 3x3), csrc/winograd.hip with one "depth" tap; FORGE_TRUNK_WINO_MIN sets the channel threshold (A/B)
+                    u2 = co.wino_pack_packed(w2) if (blk.conv2.stride[0] == 1 and w1.shape[0] >= self.TRUNK_WINO_MIN_PLANES) else None
+                    d = {"w1": w1[None].contiguous(), "a1": co.bn_affine(blk.bn1), "w2": w2, "u2": u2, "taps2": taps2, "a2": co.bn_affine(blk.bn2),
                          "stride": blk.conv2.stride[0], "w3": w3[None].contiguous(), "a3": a3, "planes": w1.shape[0], "ds": None}
                     if blk.downsample is not None:
                         wd = blk.downsample[0].weight.detach()[:, :, 0, 0]
@@ -398,8 +404,14 @@ class Encoder3D(co.PackedModule):
             co.conv_igemm(xr, Cin, Cin, None, 0, 0, b["w1"], None, b["a1"][0], b["a1"][1], 0.0, None, None, None, y1, None,
                           (N, 1, H, W), (1, H, W), P, P, T1, epilogue=co.EPI_AFFINE_ACT)
             y2 = torch.empty(N, Ho, Wo, P, dtype=torch.float32, device=dev)
-            co.conv_igemm(y1, P, P, None, 0, 0, b["w2"], None, b["a2"][0], b["a2"][1], 0.0, None, None, None, y2, None,
-                          (N, 1, Ho, Wo), (1, H, W), P, P, b["taps2"], istride=s, epilogue=co.EPI_AFFINE_ACT)
+            if b["u2"] is not None and co.wino_enabled() and H % 2 == 0 and W % 2 == 0:
+                V = co.wino_input(y1, P, P, N, 1, H, W)
+                Mm = torch.empty(16, N * (H // 2) * (W // 2), P, dtype=torch.float32, device=dev)
+                co.wino_gemm(V, P, None, 0, b["u2"], Mm, N, 1, H // 2, W // 2, P)
+                co.wino_output(Mm, None, b["a2"][0], b["a2"][1], 0.0, None, None, None, y2, None, None, N, 1, H, W, P, P, co.EPI_AFFINE_ACT)
+            else:
+                co.conv_igemm(y1, P, P, None, 0, 0, b["w2"], None, b["a2"][0], b["a2"][1], 0.0, None, None, None, y2, None,
+                              (N, 1, Ho, Wo), (1, H, W), P, P, b["taps2"], istride=s, epilogue=co.EPI_AFFINE_ACT)
             if b["ds"] is not None:
                 wd, ad, sd = b["ds"]
                 idn = torch.empty(N, Ho, Wo, 4 * P, dtype=torch.float32, device=dev)

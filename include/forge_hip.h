@@ -204,16 +204,18 @@ int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase,
  *                      residual [rows][Cout] added to the pre-activation, aux_h / aux_z, out / out2 / out3; out rows of ldo floats).
  *                      Mm2 (nullable): a second set of point products with batch stride bs2 rows and point stride pt2 floats (0 = as Mm) -
  *                      the input half conv(x, W_x) of conv([x, h], W), computed once per view when several fusions share views.
- *   forge_wino_weights U [16][3][Cout][Cin] = G w[kd] G^T from forge_conv_igemm's packed weights wp [27][Cout][Cin] (float64 inside, rounded
- *                      once); transpose != 0: the weights of the DATA GRADIENT of that convolution instead, U [16][3][Cin][Cout]
+ *   forge_wino_weights U [16][kd][Cout][Cin] = G w[kd] G^T from forge_conv_igemm's packed weights wp [9 kd][Cout][Cin] (float64 inside, rounded
+ *                      once); transpose != 0: the weights of the DATA GRADIENT of that convolution instead, U [16][kd][Cin][Cout]
  *                      (dx = the Winograd convolution of dy with them) - a few microseconds, so training re-derives U every step.
+ * kd = 3: 3x3x3 kernels (three depth taps summed inside the point GEMMs); kd = 1: the 3x3 kernels of a 2-D convolution (ResNet
+ * bottlenecks: the planes of the (n, D) grid do not mix, so images can sit on either axis).
  * B^T and A^T hold 0 / +-1 only (exact additions); U is rounded once from a float64 product. Not bit-identical to
  * forge_conv_igemm (different order of the fp32 additions); error vs a float64 convolution is ~1.4x the direct fp32 kernel's. */
-int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int transpose, forge_stream_t stream);
+int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int kd, int transpose, forge_stream_t stream);
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
-                    long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, forge_stream_t stream);
+                    long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);
 int forge_wino_gemm_tile(long long R, int Cout);   /* the workgroup tile letter ('A'..'E', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point */
 int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,

@@ -1,4 +1,9 @@
 cd /root/repo
-python -m pytest tests -q -m gpu 2>&1 | tail -4
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['stages_ms']); print({k:(round(v.get('ms',v.get('ms_total',0)),4), round(v['achieved'],1)) for k,v in d['kernels'].items()}); print(d['roofline']['instantiations'].keys(), d['psnr_vs_oracle_db'], d['max_abs_err_vs_oracle'])"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_winograd.py -q -x -k "trunk or encoder or wino or feat3D or forward" 2>&1 | tail -4
+for t in 9999 256 128 64; do
+echo "FORGE_TRUNK_WINO_MIN=$t"
+FORGE_TRUNK_WINO_MIN=$t python bench.py --no-cpu-baseline --no-microbench 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' b1', round(d['value'],1), round(d['ms_per_step'],3), d['stages_ms']['encoder_resnet'])"
+FORGE_TRUNK_WINO_MIN=$t python bench.py --no-cpu-baseline --no-microbench --scenes 8 --steps 5 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' b8', round(d['value'],1), round(d['ms_per_step'],3), d['stages_ms']['encoder_resnet'])"
+done

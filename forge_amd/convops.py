@@ -165,14 +165,12 @@ def _splitk_workspace(device):
 TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
 
-def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1, ws_bytes=None):
+def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
     """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only). nphase = 4 / 8
-    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases). ws_bytes = 0: no split-K workspace
-    (forge_wino_gemm plans its 16 batched problems as M = 16 R rows, 3 taps, no split-K)."""
+    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases)."""
     import ctypes
     tile, ks = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo),
-                                                SPLITK_WS_BYTES if ws_bytes is None else int(ws_bytes),
+    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
                                                 ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
     return chr(tile.value), ks.value
 
@@ -301,6 +299,14 @@ def wino_enabled():
     """FORGE_WINOGRAD=0 keeps the direct implicit-GEMM kernel for the fused ConvGRU convolutions (A/B, tools/wino_ab.py)."""
     import os
     return os.environ.get("FORGE_WINOGRAD", "1") != "0"
+
+
+def wino_scene_chunk(b, D, H, W, C, views=1):
+    """Largest number of scenes (<= b) whose transformed operands stay within the kernel's buffer range (0: not even one, or odd H / W)."""
+    nb = b
+    while nb >= 1 and not wino_fits(nb, D, H, W, C, views=views):
+        nb = (nb + 1) // 2 if nb > 1 else 0
+    return nb
 
 
 def wino_fits(n, D, H, W, C, views=1):

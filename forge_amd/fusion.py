@@ -198,7 +198,7 @@ class _FuseFrozen(torch.autograd.Function):
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         mean = xr.mean(dim=1).reshape(M, C)
         t0, h = new(), new()
-        wino = co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t)
+        wino = co.wino_enabled() and co.wino_fits(b, D, H, W, C, views=t)
         steps, out = [], new()
         if wino:                                                             # ConvGRU_3D._fuse_wino with the reset gate / candidate kept
             p = gru._packed_wino()
@@ -377,8 +377,11 @@ class ConvGRU_3D(co.PackedModule):
             xr = xr.contiguous()
         p = self._packed()
         dev, M, vol = x.device, b * D * H * W, D * H * W
-        if co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t):
-            return self._fuse_wino(xr, h0)
+        nb = co.wino_scene_chunk(b, D, H, W, C, views=t) if co.wino_enabled() else 0
+        if nb:                                                        # scenes are independent: batches beyond the buffer range run in scene chunks
+            if nb >= b:
+                return self._fuse_wino(xr, h0)
+            return torch.cat([self._fuse_wino(xr[i:i + nb], None if h0 is None else h0[i:i + nb]) for i in range(0, b, nb)], dim=0)
         grid, ig = (b, D, H, W), (D, H, W)
         new = lambda: torch.empty(M, C, dtype=torch.float32, device=dev)
         taps = co.TAPS_3x3x3
@@ -508,8 +511,12 @@ class ConvGRU_3D(co.PackedModule):
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
-        if co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t):
-            return self._fuse_groups_wino(xr, groups)
+        nb = co.wino_scene_chunk(b, D, H, W, C, views=t) if co.wino_enabled() else 0
+        if nb:
+            if nb >= b:
+                return self._fuse_groups_wino(xr, groups)
+            parts = [self._fuse_groups_wino(xr[i:i + nb], groups) for i in range(0, b, nb)]
+            return [torch.cat([p_[g] for p_ in parts], dim=0) for g in range(len(groups))]
         p = self._packed()
         if "gate_wx" not in p:                                         # W = (W_x | W_h) along Cin
             p.update({"gate_wx": p["gate_w"][:, :, :C].contiguous(), "gate_wh": p["gate_w"][:, :, C:].contiguous(),

@@ -349,8 +349,14 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 3 * 8 * 8 * 8 * 128 * 4 * 2)          # two scenes' worth of the [b,t,...] input
         chunked = gru.fuse_hip(x)
         assert torch.equal(ref, chunked)
-        monkeypatch.setenv("FORGE_WINOGRAD", "1")       # operands beyond the limit: the Winograd path declines (wino_fits) and the result is the same
-        assert torch.equal(gru.fuse_hip(x), ref)
+        # the Winograd path splits the batch into scene chunks whose transformed operands fit (convops.wino_scene_chunk): bit-identical too
+        monkeypatch.setenv("FORGE_WINOGRAD", "1")
+        monkeypatch.setattr(co, "MAX_OPERAND_BYTES", (1 << 31) - 1)
+        wref = gru.fuse_hip(x).clone()
+        monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 2 * 3 * 8 * 4 * 4 * 128 * 4)          # two scenes' worth of V_x per Winograd point
+        assert co.wino_scene_chunk(6, 8, 8, 8, 128, views=3) == 2
+        assert torch.equal(gru.fuse_hip(x), wref)
+        assert (wref - ref).abs().max().item() < 2e-5
 
 
 def test_training_loss_and_gradients_vs_oracle_autograd(dev):

@@ -287,6 +287,36 @@ def conv3_launch(x1, C1, x2, C2, wp, bias, out, grid, Cout, bs1=0, residual=None
                       epilogue=EPI_AFFINE_ACT, bs1=bs1)
 
 
+def wino_wgrad_applies(n, D, H, W, C1, C2, Cout):
+    """The Winograd weight gradient runs on the 128-wide tiles of the wgrad kernel: wide layers only (with two inputs its Cin tiles must
+    not straddle them: C1 a multiple of 128)."""
+    return (wino_applies(TAPS_3x3x3, 1, n, D, H, W, C1, C2, Cout) and C1 + C2 >= 128 and Cout >= 64 and (C2 == 0 or C1 % 128 == 0)
+            and n * D * (H // 2) * (W // 2) * Cout * 4 <= MAX_OPERAND_BYTES)
+
+
+@_lib.on_tensor_device
+def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0):
+    """dwp [27][Cout][C1+C2] (zero-filled by the caller) += the weight gradient of conv3x3x3(cat(x1, x2)) for the upstream gradient dy
+    [rows][Cout]. Wide layers take the Winograd form - dMm = A dy A^T, dU[p] = dMm[p]^T (x) V[p] as 16 batched problems of the wgrad
+    GEMM kernel (2.25x fewer FLOPs), dw = G^T dU G - the others the direct kernel (conv_wgrad)."""
+    n, D, H, W = grid
+    if not wino_wgrad_applies(n, D, H, W, C1, C2, Cout):
+        return conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, (D, H, W), Cout, TAPS_3x3x3, bs1=bs1)
+    L, st = _lib.lib(), _lib.current_stream()
+    Ht, Wt = H // 2, W // 2
+    R = n * D * Ht * Wt
+    dev = dy.device
+    V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
+    V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
+    dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
+    _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
+    dU = torch.zeros(16, 3, Cout, C1 + C2, dtype=torch.float32, device=dev)
+    _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, 3, st), "forge_wino_wgrad")
+    dw = torch.empty_like(dwp)
+    _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dw), Cout, C1 + C2, 3, st), "forge_wino_dw")
+    return dwp.add_(dw)
+
+
 def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
     """Stride-1 3x3x3 problems with GEMM-sized channel counts take the Winograd launches: K = 3 Cin per point must amortise the GEMM
     prologue (measured, tools/wino_gemm_sweep.py: conv1's Cin = 64 -> 128 still runs at 95 TF of MFMA work = 214 TF direct-equivalent
@@ -469,8 +499,11 @@ class _ConvTapsRows(torch.autograd.Function):
             dx2 = dx[..., C1:] if (x2 is not None and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[2]:
             dwp = torch.zeros_like(wp)
-            conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
-                       bs2=0 if x2 is None else _batch_stride_rows(x2))
+            if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout) and (x2 is None or _batch_stride_rows(x2) == 0):
+                conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1))
+            else:
+                conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
+                           bs2=0 if x2 is None else _batch_stride_rows(x2))
         if has_bias and ctx.needs_input_grad[3]:
             db = dy.reshape(-1, Cout).sum(dim=0)
         return dx1, dx2, dwp, db, None, None, None

@@ -36,6 +36,8 @@ struct WgradArgs {
     int n, D, H, W;                           // GEMM-row grid of dY (M = n D H W)
     int is, Di, Hi, Wi;                       // input voxel = (z is + dz, ...)
     int Cout, ntaps, mchunk;                  // rows per M-chunk (multiple of 32)
+    int tpp; long long pty, pt1, pt2;         // tpp > 0: ntaps / tpp independent problems in one launch (forge_wino_wgrad: the 16 Winograd points);
+                                              // taps [p tpp, (p+1) tpp) read dy + p pty, x1 + p pt1, x2 + p pt2 (floats); dw[t] stays [ntaps][Cout][Cin]
     signed char tap[64][4];
 };
 
@@ -65,9 +67,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int nsteps = (int)((mend - mbeg + WK - 1) / WK);
     const int co0 = co_t * WT, ci0 = ci_t * CIW;
 
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
+    const long long pb = a.tpp > 0 ? t / a.tpp : 0;                  // batched problems: this tap's operands
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + pb * a.pty), 0, (int)a.spany, 0x00020000);
     const bool second = ci0 >= a.C1;                                 // this ci tile lives in x2
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a.x2 : a.x1), 0, (int)(second ? a.span2 : a.span1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a.x2 + pb * a.pt2 : a.x1 + pb * a.pt1), 0,
+                                                                        (int)(second ? a.span2 : a.span1), 0x00020000);
     const int ldx = second ? a.ld2 : a.ld1, cx0 = second ? ci0 - a.C1 : ci0, Cx = second ? a.C2 : a.C1;
     const long long bsx = second ? a.bs2r : a.bs1r;
     const int dz = a.tap[t][0], dy_ = a.tap[t][1], dx = a.tap[t][2];
@@ -355,6 +359,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_lines_kernel(const WgradArgs a
 
 using namespace forge;
 
+// conv_wgrad_kernel<ciw> over (taps x Cout tiles x Cin tiles x voxel chunks) workgroups.
+static int launch_wgrad_tiles(WgradArgs& a, int ciw, hipStream_t stream) {
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const int Cin = a.C1 + a.C2, Cout = a.Cout, ntaps = a.ntaps;
+    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + ciw - 1) / ciw);
+    // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
+    // workgroup ends with up to 16 K fp32 atomics for its tile, which must stay small next to its MFMA work. When that leaves the
+    // chip under-filled (ResNet at one scene: M = 5120, a handful of tiles) the floor drops to 8 K-steps: those launches are
+    // latency-bound and more, shorter workgroups are what shortens them.
+    long long target = 4096;      // many short workgroups: 512 are resident at a time, a coarse split leaves a mostly empty last round
+    long long nchunk = (target + tiles - 1) / tiles;
+    if (nchunk > M / 1024) nchunk = M / 1024;
+    if (nchunk < 1) nchunk = 1;
+    if (tiles * nchunk < 512) {
+        nchunk = (512 + tiles - 1) / tiles;
+        if (nchunk > M / 256) nchunk = M / 256;
+        if (nchunk < 1) nchunk = 1;
+    }
+    long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
+    a.mchunk = (int)mchunk;
+    nchunk = (M + mchunk - 1) / mchunk;
+    const long long grid = tiles * nchunk;
+    FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
+    const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 32 KiB
+#define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
+    do {                                                                                                                             \
+        FORGE_SET_MAX_LDS_ONCE(conv_wgrad_kernel<CIWv>, lds);                                                                        \
+        hipLaunchKernelGGL(conv_wgrad_kernel<CIWv>, dim3((unsigned)grid), dim3(256), lds, stream, a);                  \
+    } while (0)
+    if (ciw == 32) FORGE_LAUNCH_WGRAD(32);
+    else if (ciw == 64) FORGE_LAUNCH_WGRAD(64);
+    else FORGE_LAUNCH_WGRAD(128);
+#undef FORGE_LAUNCH_WGRAD
+    FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+    return 0;
+}
+
 extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C1, int ld1, long long bs1, const float* x2, int C2, int ld2,
                                 long long bs2, float* dw, int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout,
                                 const int* taps, int ntaps, forge_stream_t stream) {
@@ -368,6 +409,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
     WgradArgs a;
     a.dy = dy; a.ldy = ldy; a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.ld1 = ld1; a.ld2 = ld2; a.dw = dw;
     a.n = n; a.D = D; a.H = H; a.W = W; a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cout = Cout; a.ntaps = ntaps;
+    a.tpp = 0; a.pty = a.pt1 = a.pt2 = 0;
     a.bs1r = bs1 > 0 ? bs1 : (long long)Di * Hi * Wi; a.bs2r = bs2 > 0 ? bs2 : (long long)Di * Hi * Wi;
     const long long M = (long long)n * D * H * W;
     a.spany = M * ldy * 4;
@@ -424,36 +466,31 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         FORGE_LAUNCH_CHECK("forge_conv_wgrad");
         return 0;
     }
-    const int ciw = (x2 == nullptr && Cin <= 32) ? 32 : (x2 == nullptr && Cin <= 64) ? 64 : WT;
-    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + ciw - 1) / ciw);
-    // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
-    // workgroup ends with up to 16 K fp32 atomics for its tile, which must stay small next to its MFMA work. When that leaves the
-    // chip under-filled (ResNet at one scene: M = 5120, a handful of tiles) the floor drops to 8 K-steps: those launches are
-    // latency-bound and more, shorter workgroups are what shortens them.
-    long long target = 4096;      // many short workgroups: 512 are resident at a time, a coarse split leaves a mostly empty last round
-    long long nchunk = (target + tiles - 1) / tiles;
-    if (nchunk > M / 1024) nchunk = M / 1024;
-    if (nchunk < 1) nchunk = 1;
-    if (tiles * nchunk < 512) {
-        nchunk = (512 + tiles - 1) / tiles;
-        if (nchunk > M / 256) nchunk = M / 256;
-        if (nchunk < 1) nchunk = 1;
-    }
-    long long mchunk = ((M + nchunk - 1) / nchunk + WK - 1) / WK * WK;
-    a.mchunk = (int)mchunk;
-    nchunk = (M + mchunk - 1) / mchunk;
-    const long long grid = tiles * nchunk;
-    FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
-    const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 32 KiB
-#define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
-    do {                                                                                                                             \
-        FORGE_SET_MAX_LDS_ONCE(conv_wgrad_kernel<CIWv>, lds);                                                                        \
-        hipLaunchKernelGGL(conv_wgrad_kernel<CIWv>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);                  \
-    } while (0)
-    if (ciw == 32) FORGE_LAUNCH_WGRAD(32);
-    else if (ciw == 64) FORGE_LAUNCH_WGRAD(64);
-    else FORGE_LAUNCH_WGRAD(128);
-#undef FORGE_LAUNCH_WGRAD
-    FORGE_LAUNCH_CHECK("forge_conv_wgrad");
-    return 0;
+    return launch_wgrad_tiles(a, (x2 == nullptr && Cin <= 32) ? 32 : (x2 == nullptr && Cin <= 64) ? 64 : WT, (hipStream_t)stream);
+}
+
+// Weight gradient in the Winograd domain (csrc/winograd.hip): dU[p][kd][co][ci] = sum_r dMm[p][r][co] (V1 | V2)[p][r + kd plane][ci] for the 16
+// points in ONE launch of conv_wgrad_kernel - 16 kd "taps" whose operands advance by one point every kd taps. dU [16][kd][Cout][C1+C2] must
+// be zero-filled (fp32 atomics over voxel chunks). 2.25x fewer FLOPs than forge_conv_wgrad on the same convolution.
+extern "C" int forge_wino_wgrad(const float* dMm, const float* V1, int C1, long long bs1, long long pt1, const float* V2, int C2, long long bs2,
+                                long long pt2, float* dU, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream) {
+    FORGE_REQUIRE(dMm && V1 && dU && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_wgrad: null pointer argument / kd not 1 or 3");
+    FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 0 && Cout % 4 == 0 && C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 &&
+                  (C2 == 0) == (V2 == nullptr) && (C2 == 0 || C1 % WT == 0), FORGE_ESHAPE,
+                  "forge_wino_wgrad: bad dims (channel counts multiples of 4; with two inputs C1 a multiple of %d)", WT);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    const long long vol = (long long)D * Ht * Wt, R = (long long)n * vol;
+    a.dy = dMm; a.ldy = Cout; a.x1 = V1; a.x2 = V2; a.C1 = C1; a.C2 = C2; a.ld1 = C1; a.ld2 = C2; a.dw = dU;
+    a.n = n; a.D = D; a.H = Ht; a.W = Wt; a.is = 1; a.Di = D; a.Hi = Ht; a.Wi = Wt; a.Cout = Cout; a.ntaps = 16 * kd;
+    a.bs1r = bs1 > 0 ? bs1 : vol; a.bs2r = bs2 > 0 ? bs2 : vol;
+    a.spany = R * Cout * 4;
+    a.span1 = ((long long)(n - 1) * a.bs1r + vol) * C1 * 4;
+    a.span2 = V2 ? ((long long)(n - 1) * a.bs2r + vol) * C2 * 4 : 0;
+    FORGE_REQUIRE(a.spany < (1ll << 31) && a.span1 < (1ll << 31) && a.span2 < (1ll << 31), FORGE_ESHAPE,
+                  "forge_wino_wgrad: an operand spans >= 2 GiB per Winograd point (32-bit buffer offsets); split the batch");
+    a.tpp = kd; a.pty = R * Cout; a.pt1 = pt1 > 0 ? pt1 : R * C1; a.pt2 = V2 ? (pt2 > 0 ? pt2 : R * C2) : 0;
+    for (int t = 0; t < 16 * kd; ++t) a.tap[t][0] = (signed char)(kd == 3 ? t % 3 - 1 : 0);
+    const int Cin = C1 + C2;
+    return launch_wgrad_tiles(a, (V2 == nullptr && Cin <= 32) ? 32 : (V2 == nullptr && Cin <= 64) ? 64 : WT, (hipStream_t)stream);
 }

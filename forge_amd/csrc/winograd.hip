@@ -215,9 +215,104 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
         }
 }
 
+// ---- weight gradient in the Winograd domain: dL/dU[p][kd] = sum_r dMm[p][r] (x) V[p][r + kd plane] (forge_wino_wgrad: conv_wgrad_kernel
+// on 16 batched problems), with dMm = A dy A^T the adjoint of the inverse transform, then dL/dw[kd] = G^T dU[kd] G.
+struct WinoDyArgs {
+    const float* dy; int ldy;                     // upstream gradient rows [n][D][H][W] x ldy floats, Cout channels used
+    float* dM; long long ptm;                     // dM[p] = dM + p ptm, rows [n][D][H/2][W/2] x Cout floats
+    int n, D, H, W, Cout;
+};
+
+// one thread = one 2x2 output tile x 4 channels: 4 float4 loads, A = [1 0; 1 1; 1 -1; 0 -1] on both sides, 16 float4 stores
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
+    const int C4 = a.Cout >> 2, Ht = a.H >> 1, Wt = a.W >> 1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long R = (long long)a.n * a.D * Ht * Wt;
+    if (idx >= R * C4) return;
+    const unsigned r = (unsigned)(idx / C4);
+    const int c = (int)(idx - (long long)r * C4) << 2;
+    unsigned q = r, t = q / (unsigned)Wt;
+    const int tw = (int)(q - t * (unsigned)Wt); q = t; t = q / (unsigned)Ht;
+    const int th = (int)(q - t * (unsigned)Ht);                    // t = (n, z) plane index
+    const float* yp = a.dy + ((long long)t * a.H * a.W + (long long)(2 * th) * a.W + 2 * tw) * a.ldy + c;
+    float4 y[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) y[i][j] = *reinterpret_cast<const float4*>(yp + ((long long)i * a.W + j) * a.ldy);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s[4][2];                                  // A y
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        s[0][j] = y[0][j];
+        s[1][j] = f4_add(y[0][j], y[1][j]);
+        s[2][j] = f4_sub(y[0][j], y[1][j]);
+        s[3][j] = f4_sub(zero, y[1][j]);
+    }
+    float* mp = a.dM + (long long)r * a.Cout + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                    // (A y) A^T
+        *reinterpret_cast<float4*>(mp + (4 * i + 0) * a.ptm) = s[i][0];
+        *reinterpret_cast<float4*>(mp + (4 * i + 1) * a.ptm) = f4_add(s[i][0], s[i][1]);
+        *reinterpret_cast<float4*>(mp + (4 * i + 2) * a.ptm) = f4_sub(s[i][0], s[i][1]);
+        *reinterpret_cast<float4*>(mp + (4 * i + 3) * a.ptm) = f4_sub(zero, s[i][1]);
+    }
+}
+
+// dw[(kd 3 + a) 3 + b][co][ci] = sum_ij G[i][a] G[j][b] dU[4i+j][kd][co][ci]   (G^T dU G): one thread per (kd, co, ci)
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin, int KD) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)Cout * Cin;
+    if (idx >= KD * per) return;
+    const int kd = (int)(idx / per);
+    const long long oc = idx - kd * per;
+    const long long pt = KD * per;
+    float u[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[i][j] = dU[(4 * i + j) * pt + kd * per + oc];
+    float g[3][4];                                   // G^T u: rows a = 0..2
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        g[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        g[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        g[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+#pragma unroll
+    for (int a_ = 0; a_ < 3; ++a_) {                 // (G^T u) G
+        float* o = dw + ((long long)((kd * 3 + a_) * 3) * per) + oc;
+        o[0 * per] = g[a_][0] + 0.5f * (g[a_][1] + g[a_][2]);
+        o[1 * per] = 0.5f * (g[a_][1] - g[a_][2]);
+        o[2 * per] = 0.5f * (g[a_][1] + g[a_][2]) + g[a_][3];
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
+
+extern "C" int forge_wino_dy(const float* dy, int ldy, float* dM, int n, int D, int H, int W, int Cout, forge_stream_t stream) {
+    FORGE_REQUIRE(dy && dM, FORGE_EINVAL, "forge_wino_dy: null pointer argument");
+    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout > 0 && Cout % 4 == 0 && ldy >= Cout && ldy % 4 == 0, FORGE_ESHAPE,
+                  "forge_wino_dy: n=%d D=%d H=%d W=%d Cout=%d ldy=%d (H, W even; Cout, ldy multiples of 4)", n, D, H, W, Cout, ldy);
+    WinoDyArgs a;
+    const long long R = (long long)n * D * (H / 2) * (W / 2);
+    a.dy = dy; a.ldy = ldy; a.dM = dM; a.ptm = R * Cout; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout;
+    FORGE_REQUIRE(R < (1ll << 31), FORGE_ESHAPE, "forge_wino_dy: more than 2^31 tiles; split the batch");
+    const long long total = R * (Cout / 4), grid = (total + 255) / 256;
+    FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_wino_dy: grid too large");
+    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    FORGE_LAUNCH_CHECK("forge_wino_dy");
+    return 0;
+}
+
+extern "C" int forge_wino_dw(const float* dU, float* dw, int Cout, int Cin, int kd, forge_stream_t stream) {
+    FORGE_REQUIRE(dU && dw && Cout > 0 && Cin > 0 && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_dw: bad argument (kd = 1 or 3)");
+    const long long total = (long long)kd * Cout * Cin;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dU, dw, Cout, Cin, kd);
+    FORGE_LAUNCH_CHECK("forge_wino_dw");
+    return 0;
+}
 
 extern "C" int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int kd, int transpose, forge_stream_t stream) {
     FORGE_REQUIRE(wp && U && Cout > 0 && Cin > 0 && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_weights: bad argument (kd = 1 or 3)");

@@ -84,7 +84,7 @@ class _GRUCellRows(torch.autograd.Function):
         b, D, H, W, C = h.shape
         M = b * D * H * W
         dev = h.device
-        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        grid = (b, D, H, W)
         bsx = co._batch_stride_rows(x)
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
@@ -97,7 +97,7 @@ class _GRUCellRows(torch.autograd.Function):
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[4]:
             dwo = torch.zeros_like(wo)
-            co.conv_wgrad(dc, x, C, hr, C, dwo, grid, ig, C, list(taps), bs1=bsx)
+            co.conv3_wgrad(dc, x, C, hr, C, dwo, grid, C, bs1=bsx)
         if ctx.has_bias[1] and ctx.needs_input_grad[5]:
             dbo = dc.reshape(M, C).sum(dim=0)
         # gates: g = conv([x | h], wg); z = sigmoid(g[:C]), r = sigmoid(g[C:]), hr = h r
@@ -107,7 +107,7 @@ class _GRUCellRows(torch.autograd.Function):
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dxh2, grid, 2 * C, dgrad=True)
         if ctx.needs_input_grad[2]:
             dwg = torch.zeros_like(wg)
-            co.conv_wgrad(dg, x, C, h, C, dwg, grid, ig, 2 * C, list(taps), bs1=bsx)
+            co.conv3_wgrad(dg, x, C, h, C, dwg, grid, 2 * C, bs1=bsx)
         if ctx.has_bias[0] and ctx.needs_input_grad[3]:
             dbg = dg.reshape(M, 2 * C).sum(dim=0)
         dx = (dxh[..., :C] + dxh2[..., :C]) if ctx.needs_input_grad[0] else None
@@ -153,7 +153,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         b, D, H, W, C = h.shape
         M = b * D * H * W
         dev = h.device
-        grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
+        grid = (b, D, H, W)
         new = lambda c: torch.empty(b, D, H, W, c, dtype=torch.float32, device=dev)
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
@@ -164,7 +164,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[5]:
             dwo = torch.zeros_like(wo)
-            co.conv_wgrad(dc, hr, C, None, 0, dwo, grid, ig, C, list(taps))
+            co.conv3_wgrad(dc, hr, C, None, 0, dwo, grid, C)
         if ctx.has_bias[1] and ctx.needs_input_grad[6]:
             dbo = dc.reshape(M, C).sum(dim=0)
         dg = new(2 * C)
@@ -173,7 +173,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dh_total, grid, C, residual=dh, dgrad=True)
         if ctx.needs_input_grad[3]:
             dwg = torch.zeros_like(wg)
-            co.conv_wgrad(dg, h, C, None, 0, dwg, grid, ig, 2 * C, list(taps))
+            co.conv3_wgrad(dg, h, C, None, 0, dwg, grid, 2 * C)
         if ctx.has_bias[0] and ctx.needs_input_grad[4]:
             dbg = dg.reshape(M, 2 * C).sum(dim=0)
         return (dg if ctx.needs_input_grad[0] else None), (dc if ctx.needs_input_grad[1] else None), dh_total, dwg, dbg, dwo, dbo

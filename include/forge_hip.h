@@ -212,6 +212,14 @@ int forge_conv_igemm_plan(long long M, int Cout, int Cin, int ntaps, int nphase,
  * B^T and A^T hold 0 / +-1 only (exact additions); U is rounded once from a float64 product. Not bit-identical to
  * forge_conv_igemm (different order of the fp32 additions); error vs a float64 convolution is ~1.4x the direct fp32 kernel's. */
 int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int kd, int transpose, forge_stream_t stream);
+/* Weight gradient of the same convolution in the Winograd domain (training): dMm = A dy A^T (forge_wino_dy, the adjoint of the inverse
+ * transform; dM [16][R][Cout]), dU[p][kd][co][ci] = sum_r dMm[p][r][co] (V1 | V2)[p][r + kd plane][ci] (forge_wino_wgrad: the weight-gradient
+ * GEMM kernel of forge_conv_wgrad on 16 batched problems, dU [16][kd][Cout][C1+C2] ZERO-FILLED by the caller, fp32 atomics over voxel chunks),
+ * dw[9 kd][Cout][Cin] = G^T dU G (forge_wino_dw, written, not accumulated). V1 / V2 as in forge_wino_gemm (row strides = channel counts). */
+int forge_wino_dy(const float* dy, int ldy, float* dM, int n, int D, int H, int W, int Cout, forge_stream_t stream);
+int forge_wino_wgrad(const float* dMm, const float* V1, int C1, long long bs1, long long pt1, const float* V2, int C2, long long bs2,
+                     long long pt2, float* dU, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);
+int forge_wino_dw(const float* dU, float* dw, int Cout, int Cin, int kd, forge_stream_t stream);
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,

@@ -180,3 +180,41 @@ def test_frozen_fusion_winograd_matches_direct(monkeypatch):
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     assert rel(res["1"][0], res["0"][0]) < 1e-5
     assert rel(res["1"][1], res["0"][1]) < 1e-3        # sign flips of LeakyReLU arguments within 1e-6 of zero move single elements (test_gpu_configs)
+
+
+def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
+    """convops.conv3_wgrad (dMm = A dy A^T, 16 batched wgrad problems, G^T dU G) against float64 autograd and the direct wgrad kernel:
+    two-input form with a batch-strided first operand (the GRU cells' layout) and a single-input form."""
+    from forge_amd import convops as co
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    n, D, H, W, C1, C2, Co = 2, 4, 6, 8, 128, 128, 64
+    xs = torch.randn(n, 2, D, H, W, C1, generator=g)                       # views stacked: x1 = xs[:, 1] has a batch stride
+    x2 = torch.randn(n, D, H, W, C2, generator=g)
+    dy = torch.randn(n, D, H, W, Co, generator=g)
+    w = torch.zeros(Co, C1 + C2, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    xin = torch.cat([xs[:, 1], x2], dim=-1).double().permute(0, 4, 1, 2, 3)
+    torch.nn.functional.conv3d(xin, w, padding=1).backward(dy.double().permute(0, 4, 1, 2, 3))
+    ref = w.grad.reshape(Co, C1 + C2, 27).permute(2, 0, 1)                  # packed layout [27][Co][Ci]
+    xsd, x2d, dyd = xs.to(dev), x2.to(dev), dy.to(dev)
+    x1d = xsd[:, 1]
+    assert co.wino_wgrad_applies(n, D, H, W, C1, C2, Co)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FORGE_WINOGRAD", mode)
+        dwp = torch.zeros(27, Co, C1 + C2, device=dev)
+        co.conv3_wgrad(dyd, x1d, C1, x2d, C2, dwp, (n, D, H, W), Co, bs1=co._batch_stride_rows(x1d))
+        out[mode] = dwp.double().cpu()
+    scale = ref.abs().max().item()
+    e_w, e_d = (out["1"] - ref).abs().max().item() / scale, (out["0"] - ref).abs().max().item() / scale
+    assert e_d < 2e-5 and e_w < 2e-5, (e_w, e_d)
+    # single input, Cout = 256 (the data-gradient-shaped problem of the gates convolution)
+    x = torch.randn(1, 4, 8, 8, 256, generator=g)
+    dy2 = torch.randn(1, 4, 8, 8, 256, generator=g)
+    w2 = torch.zeros(256, 256, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3), w2, padding=1).backward(dy2.double().permute(0, 4, 1, 2, 3))
+    ref2 = w2.grad.reshape(256, 256, 27).permute(2, 0, 1)
+    monkeypatch.setenv("FORGE_WINOGRAD", "1")
+    dwp = torch.zeros(27, 256, 256, device=dev)
+    co.conv3_wgrad(dy2.to(dev), x.to(dev), 256, None, 0, dwp, (1, 4, 8, 8), 256)
+    assert (dwp.double().cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()

@@ -14,3 +14,4 @@ WINO_SCENES=4 python tools/wino_ab.py 2>&1 | grep -v amdgpu.ids
 python tools/wino_gemm_sweep.py 2>&1 | grep -v amdgpu.ids
 WINO_SCENES=4 python tools/wino_gemm_sweep.py 2>&1 | grep -v amdgpu.ids
 } > gpurun_out/r02_winograd_probes.txt 2>&1
+bash tools/gpu/run_trainprof.sh > gpurun_out/r02_train_step_kernel_stats.txt 2>&1

@@ -244,11 +244,17 @@ def wino_conv_rows(x1, x2, U, bias, out, residual=None):
     """out [n,D,H,W,Cout] = conv3x3x3(cat(x1, x2)) + bias (+ residual) on channels-last rows through the three Winograd launches.
     x1 may have a batch stride (a view of a [b,t,...] stack)."""
     n, D, H, W, C1 = x1.shape
-    C2 = 0 if x2 is None else x2.shape[-1]
+    return _wino_conv(x1, C1, _batch_stride_rows(x1), x2, 0 if x2 is None else x2.shape[-1], 0 if x2 is None else _batch_stride_rows(x2), U, bias, out,
+                      residual, (n, D, H, W))
+
+
+def _wino_conv(x1, C1, bs1, x2, C2, bs2, U, bias, out, residual, grid):
+    """The three launches of one Winograd convolution with the bias (+ residual) tail: transforms of x1 / x2, point GEMMs, inverse."""
+    n, D, H, W = grid
     Cout = U.shape[2]
-    V1 = wino_input(x1, C1, C1, n, D, H, W, bs=_batch_stride_rows(x1))
-    V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W, bs=_batch_stride_rows(x2))
-    Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=x1.device)
+    V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
+    V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W, bs=bs2)
+    Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=out.device)
     wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
     return wino_output(Mm, bias, None, None, 1.0, residual, None, None, out, None, None, n, D, H, W, Cout, Cout, EPI_BIAS)
 
@@ -271,12 +277,7 @@ def conv3_launch(x1, C1, x2, C2, wp, bias, out, grid, Cout, bs1=0, residual=None
     weights / the transposed packed weights [27][Ci][Co] of the direct data gradient, if the caller caches them (frozen weights)."""
     n, D, H, W = grid
     if wino_applies(TAPS_3x3x3, 1, n, D, H, W, C1, C2, Cout):
-        U = U if U is not None else wino_pack_packed(wp, transpose=dgrad)
-        V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
-        V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
-        Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=out.device)
-        wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
-        return wino_output(Mm, bias, None, None, 1.0, residual, None, None, out, None, None, n, D, H, W, Cout, Cout, EPI_BIAS)
+        return _wino_conv(x1, C1, bs1, x2, C2, 0, U if U is not None else wino_pack_packed(wp, transpose=dgrad), bias, out, residual, grid)
     w = (wT if wT is not None else wp.transpose(1, 2).contiguous()) if dgrad else wp
     taps = [(-a, -b, -c) for a, b, c in TAPS_3x3x3] if dgrad else TAPS_3x3x3
     if residual is None:

@@ -105,7 +105,7 @@ def stage_timers(model):
         out = o_g(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw)
         e1.record()
         R = n * D * Ht * Wt
-        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout)], []).append((e0, e1, 2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2)))
+        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout)], []).append((e0, e1, 2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2), 2.25))
         return out
 
     def input_timed(x, C, ld, n, D, H, W, **kw):
@@ -587,8 +587,10 @@ def main():
     conv_rec = {k: rec.pop(k) for k in list(rec) if k.startswith("conv_igemm")}
     wino_rec = {k: rec.pop(k) for k in list(rec) if k.startswith("wino_")}
     stages = {k: sum(a.elapsed_time(b) for a, b in v) for k, v in rec.items()}
+    # x[4] (Winograd point-GEMM launches only): direct-convolution FLOPs of the convolution / FLOPs the launch executes
     conv_launch = {k: {"launches_per_step": len(v), "total_ms": sum(x[0].elapsed_time(x[1]) for x in v),
-                       "gflop": sum(x[2] for x in v) / 1e9} for k, v in conv_rec.items()}
+                       "gflop": sum(x[2] for x in v) / 1e9, "gflop_direct_equivalent": sum(x[2] * (x[4] if len(x) > 4 else 1.0) for x in v) / 1e9}
+                   for k, v in conv_rec.items()}
     for u in undo:
         u()
     if args.dump_conv and rank == 0:
@@ -620,6 +622,8 @@ def main():
         tot_ms = sum(v["total_ms"] for v in convs.values())
         tot_gf = sum(v["gflop"] for v in convs.values())
         n_launch = sum(v["launches_per_step"] for v in convs.values())
+        alg_gf = sum(v["gflop_direct_equivalent"] for v in convs.values())
+        wino_ms = sum(x[0].elapsed_time(x[1]) for v in wino_rec.values() for x in v)
         inst = {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["total_ms"] / v["launches_per_step"],
                     "achieved": v["gflop"] / v["total_ms"], "frac": v["gflop"] / v["total_ms"] / FP32_MFMA_PEAK_TF,
                     "gflop_per_step": v["gflop"], "share_of_step": v["total_ms"] / step_ms}
@@ -629,7 +633,12 @@ def main():
                     "bound": "mfma", "achieved": tot_gf / tot_ms, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TF,
                     "traffic": pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
                     "gflop_per_step": tot_gf, "share_of_step": tot_ms / step_ms, "instantiations": inst,
-                    "note": "durations are HIP events around each launch on the launch stream in an eager (non-graph) pass, so each includes "
+                    # the same launches in SURVEY.md 8(d)'s ALGORITHMIC FLOPs (the direct convolutions the reference computes), the Winograd
+                    # transform kernels' time charged to them: above 1.0 where 2.25x of the 3x3x3 work is never executed
+                    "algorithmic": {"gflop_per_step": alg_gf, "ms_incl_winograd_transforms": tot_ms + wino_ms,
+                                    "achieved": alg_gf / (tot_ms + wino_ms), "frac": alg_gf / (tot_ms + wino_ms) / FP32_MFMA_PEAK_TF},
+                    "note": "achieved / frac count the FLOPs the launches EXECUTE (Winograd point-GEMM launches: 2.25x fewer than the direct "
+                            "convolution they replace; `algorithmic` restates them in the reference's direct-convolution FLOPs); durations are HIP events around each launch on the launch stream in an eager (non-graph) pass, so each includes "
                             "the host launch gap (and, for split-K launches, the reduction kernel); traffic is the PMC pass of the "
                             "ConvGRU-gates launch (the Winograd point-GEMM launch when the fusion runs it)"}
         if args.grid == 32:

@@ -133,6 +133,8 @@ def test_conv3_launch_forward_and_data_gradient_vs_torch():
     ref_y = y64.detach().permute(0, 2, 3, 4, 1) + res.double()
     ref_dx = x64.grad.permute(0, 2, 3, 4, 1)
     wp = co.pack_conv3d_weight(w.to(dev))
+    saved = os.environ.get("FORGE_WINOGRAD")
+    os.environ["FORGE_WINOGRAD"] = "1"
     assert co.wino_applies(co.TAPS_3x3x3, 1, n, D, H, W, Ci, 0, Co)
     for mode in ("1", "0"):
         os.environ["FORGE_WINOGRAD"] = mode
@@ -144,7 +146,7 @@ def test_conv3_launch_forward_and_data_gradient_vs_torch():
             # 128-channel dy as well so that the Winograd data gradient is exercised
             co.conv3_launch(dy.to(dev), Co, None, 0, wp, None, dx, (n, D, H, W), Ci, dgrad=True)
         finally:
-            os.environ.pop("FORGE_WINOGRAD", None)
+            os.environ["FORGE_WINOGRAD"] = "1"
         assert (y.double().cpu() - ref_y).abs().max().item() < 1e-5, mode
         assert (dx.double().cpu() - ref_dx).abs().max().item() < 1e-5, mode
     # wide data gradient (Co = 128 -> Winograd applies)
@@ -154,6 +156,10 @@ def test_conv3_launch_forward_and_data_gradient_vs_torch():
     torch.nn.functional.conv3d(x2, w2.double(), padding=1).backward(dy2.double().permute(0, 4, 1, 2, 3))
     dx2 = torch.empty(n, D, H, W, 128, device=dev)
     co.conv3_launch(dy2.to(dev), 128, None, 0, co.pack_conv3d_weight(w2.to(dev)), None, dx2, (n, D, H, W), 128, dgrad=True)
+    if saved is None:
+        os.environ.pop("FORGE_WINOGRAD", None)
+    else:
+        os.environ["FORGE_WINOGRAD"] = saved
     assert (dx2.double().cpu() - x2.grad.permute(0, 2, 3, 4, 1)).abs().max().item() < 1e-5
 
 
@@ -198,6 +204,7 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     ref = w.grad.reshape(Co, C1 + C2, 27).permute(2, 0, 1)                  # packed layout [27][Co][Ci]
     xsd, x2d, dyd = xs.to(dev), x2.to(dev), dy.to(dev)
     x1d = xsd[:, 1]
+    monkeypatch.setenv("FORGE_WINOGRAD", "1")
     assert co.wino_wgrad_applies(n, D, H, W, C1, C2, Co)
     out = {}
     for mode in ("1", "0"):

@@ -5,7 +5,7 @@ behind the reference's own nn.Module surface. See DESIGN.md / INTEGRATION.md.
     from forge_amd.model import FORGE                                   # models.model.FORGE
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
 """
-__version__ = "0.2.0"
+__version__ = "0.2.1"
 
 
 def invalidate_packed(module):

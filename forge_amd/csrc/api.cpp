@@ -15,5 +15,5 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace forge
 
-extern "C" int forge_version(void) { return 200; /* 0.2.0: round-2 ABI (conv out3 / GRU residual, rotate slots, strided GRU backward, new entry points) */ }
+extern "C" int forge_version(void) { return 210; /* 0.2.1: round-2 ABI (conv out3 / GRU residual, rotate slots, strided GRU backward, loss / camera / Winograd entry points) */ }
 extern "C" const char* forge_last_error(void) { return forge::g_err; }

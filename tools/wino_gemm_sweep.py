@@ -38,7 +38,7 @@ for name, n, D_, C1, C2, N in shapes:
     os.environ.pop("FORGE_CONV_TILE", None)
     plan = co.wino_gemm_tile(R, N)
     line = []
-    for tile in ("A", "B", "C", "D"):
+    for tile in os.environ.get("SWEEP_TILES", "A,B,C,D").split(","):
         os.environ["FORGE_CONV_TILE"] = tile
         ms = timed(lambda: co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D_, D_ // 2, D_ // 2, N))
         line.append("%s %.3f ms %5.1f TF" % (tile, ms, flops / ms / 1e9))

@@ -239,7 +239,8 @@ def kernel_rooflines(dev, B, D=32):
         flops = 2.0 * M * Cout * 27 * (Cc + C2)
         out["conv_igemm " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9,
                                                   "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF,
-                                                  "used_by": "training / refinement (the inference fusion runs the Winograd launches below)"}
+                                                  "used_by": "the direct form of the same convolution (FORGE_WINOGRAD=0, odd grids, operands beyond the buffer range); "
+                                                             "inference, refinement and training run the Winograd launches below"}
     # the same kernel as the fusion's inference path launches it: 16 Winograd point GEMMs per launch, 3 depth taps, K = 3 Cin
     R = B * D * (D // 2) * (D // 2)
     V1, V2 = torch.randn(16, R, Cc, device=dev), torch.randn(16, R, Cc, device=dev)

@@ -313,9 +313,8 @@ def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0):
     _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
     dU = torch.zeros(16, 3, Cout, C1 + C2, dtype=torch.float32, device=dev)
     _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, 3, st), "forge_wino_wgrad")
-    dw = torch.empty_like(dwp)
-    _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dw), Cout, C1 + C2, 3, st), "forge_wino_dw")
-    return dwp.add_(dw)
+    _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, 3, st), "forge_wino_dw")
+    return dwp
 
 
 def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):

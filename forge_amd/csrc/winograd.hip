@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
     }
 }
 
-// dw[(kd 3 + a) 3 + b][co][ci] = sum_ij G[i][a] G[j][b] dU[4i+j][kd][co][ci]   (G^T dU G): one thread per (kd, co, ci)
+// dw[(kd 3 + a) 3 + b][co][ci] += sum_ij G[i][a] G[j][b] dU[4i+j][kd][co][ci]   (G^T dU G): one thread per (kd, co, ci); accumulates into dw
+// like forge_conv_wgrad (each element is touched by exactly one thread: deterministic)
 __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin, int KD) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, per = (long long)Cout * Cin;
     if (idx >= KD * per) return;
@@ -281,9 +282,9 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 #pragma unroll
     for (int a_ = 0; a_ < 3; ++a_) {                 // (G^T u) G
         float* o = dw + ((long long)((kd * 3 + a_) * 3) * per) + oc;
-        o[0 * per] = g[a_][0] + 0.5f * (g[a_][1] + g[a_][2]);
-        o[1 * per] = 0.5f * (g[a_][1] - g[a_][2]);
-        o[2 * per] = 0.5f * (g[a_][1] + g[a_][2]) + g[a_][3];
+        o[0 * per] += g[a_][0] + 0.5f * (g[a_][1] + g[a_][2]);
+        o[1 * per] += 0.5f * (g[a_][1] - g[a_][2]);
+        o[2 * per] += 0.5f * (g[a_][1] + g[a_][2]) + g[a_][3];
     }
 }
 

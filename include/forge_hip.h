@@ -215,7 +215,7 @@ int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, int kd, int
 /* Weight gradient of the same convolution in the Winograd domain (training): dMm = A dy A^T (forge_wino_dy, the adjoint of the inverse
  * transform; dM [16][R][Cout]), dU[p][kd][co][ci] = sum_r dMm[p][r][co] (V1 | V2)[p][r + kd plane][ci] (forge_wino_wgrad: the weight-gradient
  * GEMM kernel of forge_conv_wgrad on 16 batched problems, dU [16][kd][Cout][C1+C2] ZERO-FILLED by the caller, fp32 atomics over voxel chunks),
- * dw[9 kd][Cout][Cin] = G^T dU G (forge_wino_dw, written, not accumulated). V1 / V2 as in forge_wino_gemm (row strides = channel counts). */
+ * dw[9 kd][Cout][Cin] += G^T dU G (forge_wino_dw: accumulates, like forge_conv_wgrad). V1 / V2 as in forge_wino_gemm (row strides = channel counts). */
 int forge_wino_dy(const float* dy, int ldy, float* dM, int n, int D, int H, int W, int Cout, forge_stream_t stream);
 int forge_wino_wgrad(const float* dMm, const float* V1, int C1, long long bs1, long long pt1, const float* V2, int C2, long long bs2,
                      long long pt2, float* dU, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);

@@ -1,0 +1,273 @@
+// bnorm.hip — train-mode BatchNorm (+ LeakyReLU / ReLU) on channels-last rows, forward and backward (training path, f1).
+//
+// The reference normalises with torch.nn.BatchNorm{2,3}d in train mode (models/fusion.py:49-58, models/encoder.py:16-40,
+// models/volume_render.py:29-37, torchvision Bottleneck) followed by a separate activation: through MIOpen that is three kernels forward,
+// three backward and an element-wise kernel each way - eight passes over the activation tensor. Here:
+//   forward   bn_stats_kernel        per-channel sum / sum of squares over the M rows, float64 accumulation (E[x^2] - mean^2 is then exact to
+//                                    ~1e-12); one partial per block -> ws[block][2][C] (no atomics: deterministic)
+//             bn_finalize_kernel     sums the partials; forward: mean / invstd, running_mean / running_var (unbiased) updated in place
+//             bn_apply_fwd_kernel    y = lrelu(x * scale + shift, slope), scale = gamma * invstd, shift = beta - mean * scale
+//   backward  bn_reduce_bwd_kernel   g = dy * (pre > 0 ? 1 : slope) with pre recomputed by the forward's own expression (same sign);
+//                                    per-channel sum g, sum g * xhat (float64 partials)
+//             bn_finalize_kernel     dbeta / dgamma (also the two means the apply kernel needs, kept in ws[0])
+//             bn_apply_bwd_kernel    dx = gamma * invstd * (g - mean(g) - xhat * mean(g xhat))
+// Five passes over the activation instead of eight, six launches instead of eight. slope = 1: no activation, slope = 0: ReLU.
+// Rows [M][ld] fp32 with C % 4 == 0 channels used; thread = (4 channels, one row group).
+#include "common.h"
+
+namespace forge {
+
+struct BnArgs {
+    const float* x; int ldx;
+    const float* dy; int lddy;            // backward only
+    float* out; int ldo;                   // forward: y; backward: dx
+    const float* gamma; const float* beta; // nullable (affine=False): 1 / 0
+    float* mean; float* invstd;            // [C]: written by the forward apply, read by the backward
+    float* running_mean; float* running_var; float momentum;   // nullable: no running statistics
+    float* dgamma; float* dbeta;           // backward outputs, nullable
+    double* ws;                            // [nblk][2][C] float64 partial sums of the reduction kernel; the finalize kernel leaves the totals in ws[0]
+    int nblk;                              // blocks (gridDim.x) of the reduction kernel = number of partials
+    float eps, slope;
+    long long M; int C;
+};
+
+constexpr int BN_THREADS = 256;
+
+// channel quad / row group of a thread: CQ = min(C/4, 256) quads per block (blockIdx.y selects the slab of quads), RG = 256 / CQ row groups
+__device__ __forceinline__ void bn_coords(int C, int& c, int& rg, int& RG) {
+    const int C4 = C >> 2, CQ = C4 < BN_THREADS ? C4 : BN_THREADS;
+    RG = BN_THREADS / CQ;
+    const int q = (int)threadIdx.x % CQ + (int)blockIdx.y * CQ;
+    rg = (int)threadIdx.x / CQ;
+    c = (q < C4 && rg < RG) ? q << 2 : -1;
+}
+
+__device__ __forceinline__ void bn_block_sum(double (&a)[8], int c, int rg, int RG, int C, double* ws) {
+    __shared__ double red[BN_THREADS][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = a[k];
+    __syncthreads();
+    if (c >= 0 && rg == 0) {
+        const int CQ = BN_THREADS / RG;
+        for (int g = 1; g < RG; ++g)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += red[threadIdx.x + g * CQ][k];
+        double* o = ws + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[c + k] = a[k];
+            o[C + c + k] = a[4 + k];
+        }
+    }
+}
+
+// totals of the nblk partials: block = 4 channels x 64 slices of the partial list. Forward (bwd == 0): mean / invstd (+ running statistics);
+// backward: dbeta / dgamma. Either way the two totals per channel are left in ws[0][2][C] for the apply kernel.
+__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const BnArgs a, int bwd) {
+    __shared__ double red[2][BN_THREADS];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < a.C)
+        for (int b = sl; b < a.nblk; b += 64) {
+            s0 += a.ws[(long long)b * 2 * a.C + c];
+            s1 += a.ws[(long long)b * 2 * a.C + a.C + c];
+        }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
+        if (sl < s) { red[0][threadIdx.x] += red[0][threadIdx.x + 4 * s]; red[1][threadIdx.x] += red[1][threadIdx.x + 4 * s]; }
+        __syncthreads();
+    }
+    if (sl != 0 || c >= a.C) return;
+    s0 = red[0][cl]; s1 = red[1][cl];
+    a.ws[c] = s0; a.ws[a.C + c] = s1;                // safe: every partial of this channel has been read (barriers above), other channels untouched
+    if (bwd) {
+        if (a.dbeta) a.dbeta[c] = (float)s0;
+        if (a.dgamma) a.dgamma[c] = (float)s1;
+        return;
+    }
+    const double m = s0 / (double)a.M, var = fmax(s1 / (double)a.M - m * m, 0.0);
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.running_mean) {
+        const double unbiased = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const BnArgs a) {
+    int c, rg, RG;
+    bn_coords(a.C, c, rg, RG);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c >= 0) {
+        const long long step = (long long)gridDim.x * RG;
+        for (long long r0 = (long long)blockIdx.x * RG + rg; r0 < a.M; r0 += 4 * step) {      // 4 independent loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long r = r0 + u * step;
+                v[u] = r < a.M ? *reinterpret_cast<const float4*>(a.x + r * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
+                acc[4] += (double)v[u].x * v[u].x; acc[5] += (double)v[u].y * v[u].y; acc[6] += (double)v[u].z * v[u].z; acc[7] += (double)v[u].w * v[u].w;
+            }
+        }
+    }
+    bn_block_sum(acc, c, rg, RG, a.C, a.ws);
+}
+
+// scale / shift of 4 channels from the float64 sums (forward) - also what the backward recomputes, bit for bit, from mean / invstd
+__device__ __forceinline__ void bn_affine4(const BnArgs& a, int c, const float* mean, const float* invstd, float (&sc)[4], float (&sh)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float g = a.gamma ? a.gamma[c + k] : 1.f, b = a.beta ? a.beta[c + k] : 0.f;
+        sc[k] = g * invstd[k];
+        sh[k] = b - mean[k] * sc[k];
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_fwd_kernel(const BnArgs a) {
+    int c, rg, RG;
+    bn_coords(a.C, c, rg, RG);
+    if (c < 0) return;
+    float mean[4], invstd[4], sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = a.mean[c + k]; invstd[k] = a.invstd[c + k]; }
+    bn_affine4(a, c, mean, invstd, sc, sh);
+    for (long long r = (long long)blockIdx.x * RG + rg; r < a.M; r += (long long)gridDim.x * RG) {
+        const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
+        float y[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) y[k] = y[k] > 0.f ? y[k] : y[k] * a.slope;
+        *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_reduce_bwd_kernel(const BnArgs a) {
+    int c, rg, RG;
+    bn_coords(a.C, c, rg, RG);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (c >= 0) {
+        float mean[4], invstd[4], sc[4], sh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { mean[k] = a.mean[c + k]; invstd[k] = a.invstd[c + k]; }
+        bn_affine4(a, c, mean, invstd, sc, sh);
+        const long long step = (long long)gridDim.x * RG;
+        for (long long r0 = (long long)blockIdx.x * RG + rg; r0 < a.M; r0 += 2 * step) {      // 2 x 2 independent loads in flight per thread
+            float4 v[2], d[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long long r = r0 + u * step;
+                const bool ok = r < a.M;
+                v[u] = ok ? *reinterpret_cast<const float4*>(a.x + r * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                d[u] = ok ? *reinterpret_cast<const float4*>(a.dy + r * a.lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = fmaf(xv[k], sc[k], sh[k]) > 0.f ? dv[k] : dv[k] * a.slope;     // dy = 0 beyond M: contributes nothing
+                    acc[k] += g;
+                    acc[4 + k] += (double)g * ((xv[k] - mean[k]) * invstd[k]);
+                }
+            }
+        }
+    }
+    bn_block_sum(acc, c, rg, RG, a.C, a.ws);
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_bwd_kernel(const BnArgs a) {
+    int c, rg, RG;
+    bn_coords(a.C, c, rg, RG);
+    if (c < 0) return;
+    float mean[4], invstd[4], sc[4], sh[4], k1[4], k2[4], k3[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mean[k] = a.mean[c + k]; invstd[k] = a.invstd[c + k]; }
+    bn_affine4(a, c, mean, invstd, sc, sh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double db = a.ws[c + k], dg = a.ws[a.C + c + k];
+        k1[k] = sc[k];                                  // gamma * invstd
+        k2[k] = (float)(db / (double)a.M);              // mean(g)
+        k3[k] = (float)(dg / (double)a.M);              // mean(g * xhat)
+    }
+    for (long long r = (long long)blockIdx.x * RG + rg; r < a.M; r += (long long)gridDim.x * RG) {
+        const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
+        const float4 d = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + c);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = fmaf(xv[k], sc[k], sh[k]) > 0.f ? dv[k] : dv[k] * a.slope;
+            o[k] = k1[k] * (g - k2[k] - (xv[k] - mean[k]) * invstd[k] * k3[k]);
+        }
+        *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int bn_check(const char* fn, const void* x, int ldx, long long M, int C, const void* ws) {
+    FORGE_REQUIRE(x && ws, FORGE_EINVAL, "%s: null pointer argument", fn);
+    FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0, FORGE_ESHAPE, "%s: M=%lld C=%d ld=%d (C, ld multiples of 4)", fn, M, C, ldx);
+    return 0;
+}
+
+// reduce = true (the two kernels that leave one partial per block): at most BN_MAX_PARTIALS blocks, each streaming >= 4 rows per row group;
+// the apply kernels take up to 2048 blocks.
+constexpr int BN_MAX_PARTIALS = 1024;
+static dim3 bn_grid(long long M, int C, bool reduce) {
+    const int C4 = C / 4, CQ = C4 < BN_THREADS ? C4 : BN_THREADS, RG = BN_THREADS / CQ;
+    const long long per = reduce ? 4 : 2, cap = reduce ? BN_MAX_PARTIALS : 2048;
+    long long bx = (M + RG * per - 1) / (RG * per);
+    if (bx > cap) bx = cap;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)((C4 + CQ - 1) / CQ));
+}
+
+}  // namespace forge
+
+using namespace forge;
+
+extern "C" int forge_bn_ws_doubles(int C) { return 2 * C * BN_MAX_PARTIALS; }   // size of the float64 scratch the two calls below need
+
+extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                                  float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
+                                  long long M, int C, forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_train_fwd", x, ldx, M, C, ws)) return rc;
+    FORGE_REQUIRE(y && mean && invstd && ldy >= C && ldy % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr), FORGE_EINVAL,
+                  "forge_bn_train_fwd: bad output / running-statistics arguments");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
+    a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.ws = ws; a.eps = eps; a.slope = slope; a.M = M; a.C = C;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gr = bn_grid(M, C, true);
+    a.nblk = (int)gr.x;
+    hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 0);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
+    FORGE_LAUNCH_CHECK("forge_bn_train_fwd");
+    return 0;
+}
+
+extern "C" int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                                  const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
+                                  forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_train_bwd", x, ldx, M, C, ws)) return rc;
+    FORGE_REQUIRE(dy && dx && mean && invstd && lddy >= C && lddy % 4 == 0 && lddx >= C && lddx % 4 == 0, FORGE_EINVAL, "forge_bn_train_bwd: bad arguments");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.gamma = gamma; a.beta = beta;
+    a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gr = bn_grid(M, C, true);
+    a.nblk = (int)gr.x;
+    hipLaunchKernelGGL(bn_reduce_bwd_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 1);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
+    FORGE_LAUNCH_CHECK("forge_bn_train_bwd");
+    return 0;
+}

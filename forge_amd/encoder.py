@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, convops as co
-from .fusion import ConvGRU_3D, affine_act_bwd, frozen_eval, hip_inference, require_hip_input
+from .fusion import ConvGRU_3D, affine_act_bwd, bn_act_rows, frozen_eval, hip_inference, require_hip_input
 
 
 class _Bottleneck(nn.Module):
@@ -182,7 +182,7 @@ class Encoder3D(co.PackedModule):
         N, H, W, _ = z.shape
         rows = z.reshape(N, H, W, 64, 32).permute(0, 4, 1, 2, 3).contiguous()     # view(-1,64,32,H,W) as rows [N,32,H,W,64]
         y = co.conv3x3x3_rows(rows, None, self.conv1[0].weight, self.conv1[0].bias)
-        return self.conv1[2](self.conv1[1](y.permute(0, 4, 1, 2, 3)))
+        return bn_act_rows(self.conv1[1], y, self.conv1[2].negative_slope).permute(0, 4, 1, 2, 3)
 
     def get_density3D(self, z_3d):
         """models/encoder.py:53-54. Callers that need both heads of the same volume should use heads() (one shared launch)."""
@@ -235,9 +235,7 @@ class Encoder3D(co.PackedModule):
 
     @staticmethod
     def _bn2d_rows(bn, rows, relu=True):
-        y = bn(rows.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-        y = y if y.is_contiguous() else y.contiguous()
-        return torch.relu(y) if relu else y
+        return bn_act_rows(bn, rows, 0.0 if relu else 1.0)
 
     @_lib.on_tensor_device
     def _trunk_autograd_hip(self, img):
@@ -274,20 +272,29 @@ class Encoder3D(co.PackedModule):
         autograd graph: every convolution forward, data gradient and weight gradient on the HIP GEMM / wgrad kernels, the
         normalisations and activations as torch ops on the same channels-last rows."""
         rows = self._rows(z)
-        for m in head:
+        mods = list(head)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             if isinstance(m, nn.ConvTranspose3d):
                 rows = co.convT3d_k4s2p1_rows(rows, m.weight, m.bias)
             elif isinstance(m, nn.Conv3d):
                 rows = co.conv3x3x3_rows_any(rows, m.weight, m.bias)
             elif isinstance(m, nn.modules.batchnorm._BatchNorm):
-                rows = m(rows.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
-                rows = rows if rows.is_contiguous() else rows.contiguous()
+                nxt = mods[i + 1] if i + 1 < len(mods) else None      # BatchNorm + the activation behind it: one fused pass each way (csrc/bnorm.hip)
+                if isinstance(nxt, nn.LeakyReLU):
+                    rows, i = bn_act_rows(m, rows, nxt.negative_slope), i + 1
+                elif isinstance(nxt, nn.ReLU):
+                    rows, i = bn_act_rows(m, rows, 0.0), i + 1
+                else:
+                    rows = bn_act_rows(m, rows)
             elif isinstance(m, nn.LeakyReLU):
                 rows = torch.nn.functional.leaky_relu(rows, m.negative_slope)
             elif isinstance(m, nn.ReLU):
                 rows = torch.relu(rows)
             else:
                 raise TypeError("unexpected layer in head: %r" % (m,))
+            i += 1
         return rows.permute(0, 4, 1, 2, 3)
 
     # ---------------------------------------------------------------- fused HIP inference path

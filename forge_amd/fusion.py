@@ -37,6 +37,66 @@ def affine_act_bwd(dy, y, scale, slope, out=None):
     return out
 
 
+class _BNTrainRows(torch.autograd.Function):
+    """Train-mode BatchNorm + LeakyReLU(slope) on channels-last rows [M, C] (csrc/bnorm.hip): batch statistics in float64, running statistics
+    updated in place, two kernels each way. slope 1 = no activation, 0 = ReLU."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+        M, C = x.shape
+        dev = x.device
+        y = torch.empty(M, C, dtype=torch.float32, device=dev)
+        mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
+                                                 p(running_mean), p(running_var), float(momentum), p(ws), M, C, _lib.current_stream()), "forge_bn_train_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        M, C = x.shape
+        dev = x.device
+        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= C) else dy.contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
+        ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
+        p = _lib.ptr
+        _lib.check(_lib.lib().forge_bn_train_bwd(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C,
+                                                 p(dg), p(db), p(ws), M, C, _lib.current_stream()), "forge_bn_train_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+def bn_act_rows(bn, rows, slope=1.0):
+    """BatchNorm module `bn` + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C]. Train mode with per-process batch
+    statistics runs the HIP kernels of csrc/bnorm.hip; SyncBatchNorm (cross-rank statistics), eval mode under autograd and a cumulative-average
+    momentum keep the torch module (on an NC... view of the same memory) followed by the activation."""
+    C = rows.shape[-1]
+    hip = (bn.training and not isinstance(bn, nn.SyncBatchNorm) and rows.is_cuda and rows.dtype == torch.float32 and C % 4 == 0
+           and (bn.momentum is not None or not bn.track_running_stats))
+    if hip:
+        x = rows.reshape(-1, C)
+        x = x if (x.stride(1) == 1 and x.stride(0) >= C and x.stride(0) % 4 == 0) else x.contiguous()
+        track = bn.track_running_stats and bn.running_mean is not None
+        y = _BNTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                               bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope)
+        if track and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return y.reshape(rows.shape)
+    nd = rows.dim()
+    y = bn(rows.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)
+    y = y if y.is_contiguous() else y.contiguous()
+    if slope == 1.0:
+        return y
+    return torch.relu(y) if slope == 0.0 else torch.nn.functional.leaky_relu(y, slope)
+
+
 def require_hip_input(what, x, channels=None):
     """The product has ONE implementation per op - the HIP kernels. Anything they cannot take is an error, never a silent stock-PyTorch
     detour (north_star: no dual code paths)."""
@@ -559,9 +619,7 @@ class ConvGRU_3D(co.PackedModule):
     @staticmethod
     def _bn_rows(bn, rows, act=None):
         """nn.BatchNorm3d / SyncBatchNorm module applied to channels-last rows [b,D,H,W,C] (batch statistics in train mode)."""
-        y = bn(rows.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1)
-        y = y if y.is_contiguous() else y.contiguous()
-        return y if act is None else act(y)
+        return bn_act_rows(bn, rows, 1.0 if act is None else act)
 
     def fuse_autograd_hip(self, x):
         """Encoder3D.fuse with an autograd graph (model.train(), or eval-mode pose refinement): the six convolutions per GRU step
@@ -574,12 +632,12 @@ class ConvGRU_3D(co.PackedModule):
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
         cell, fc = self.cells[0], self.fusion_conv
-        lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
+        lrelu = 0.01
         h = self._bn_rows(fc[1], co.conv3x3x3_rows(xr.mean(dim=1), None, fc[0].weight, fc[0].bias), lrelu)
         h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
         for xv in xr.unbind(1):                       # unbind: ONE stack in backward instead of a zero-filled [b,t,...] scatter per view
             h = gru_cell_rows(xv, h, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias)
-        return self.fusion_norm(h.permute(0, 4, 1, 2, 3))
+        return bn_act_rows(self.fusion_norm, h).permute(0, 4, 1, 2, 3)
 
     def fuse_groups_autograd_hip(self, x, groups):
         """Several fusions over subsets of the SAME views (groups = lists of view indices into x [b,t,C,D,H,W]) with an autograd graph:
@@ -597,7 +655,7 @@ class ConvGRU_3D(co.PackedModule):
         cx_all = co.conv3x3x3_rows(flat, None, Wo[:, :C], None).reshape(t, b, D, H, W, C).unbind(0)
         xviews = xt.unbind(0)
         wgh, woh = co._pack3d(Wg[:, C:]), co._pack3d(Wo[:, C:])
-        lrelu = lambda v: torch.nn.functional.leaky_relu(v, 0.01)
+        lrelu = 0.01
         outs = []
         for grp in groups:
             grp = list(grp)
@@ -606,7 +664,7 @@ class ConvGRU_3D(co.PackedModule):
             h = self._bn_rows(fc[4], co.conv3x3x3_rows(h, None, fc[3].weight, fc[3].bias), lrelu)
             for ti in grp:
                 h = _GRUCellPreRows.apply(gx_all[ti], cx_all[ti], h, wgh, cell.conv_gate.bias, woh, cell.out_gate.bias)
-            outs.append(self.fusion_norm(h.permute(0, 4, 1, 2, 3)))
+            outs.append(bn_act_rows(self.fusion_norm, h).permute(0, 4, 1, 2, 3))
         return outs
 
     def forward(self, x, hidden=None):

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, convops as co, ops
-from .fusion import affine_act_bwd, frozen_eval, hip_inference
+from .fusion import affine_act_bwd, bn_act_rows, frozen_eval, hip_inference
 
 
 class _ConvRgbFrozen(torch.autograd.Function):
@@ -202,9 +202,7 @@ class VolRender(co.PackedModule):
         rows = rows if rows.is_contiguous() else rows.contiguous()
         V, Hr, Wr, C = rows.shape
 
-        def bn_act(bn, r):                                           # r [V,H,W,C] -> BatchNorm2d on the NCHW view, LeakyReLU
-            y = bn(r.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
-            return F.leaky_relu(y if y.is_contiguous() else y.contiguous(), 0.01)
+        bn_act = lambda bn, r: bn_act_rows(bn, r, 0.01)             # r [V,H,W,C]: BatchNorm2d + LeakyReLU, one fused pass each way in train mode
 
         up = co.convT_s2_rows(rows.reshape(V, 1, Hr, Wr, C), cr[0].weight, cr[0].bias, self.pad_size, 2).reshape(V, 2 * Hr, 2 * Wr, -1)
         mid = bn_act(cr[4], co.conv2d_rows_any(bn_act(cr[1], up), cr[3].weight, cr[3].bias))

@@ -274,6 +274,21 @@ int forge_gru_state_bwd(const float* dhn, int ld_dhn, const float* h, const floa
 int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
                         float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, forge_stream_t stream);
 
+/* Train-mode BatchNorm (+ LeakyReLU / ReLU) on channels-last rows (training path; torch.nn.BatchNorm{2,3}d(train) + activation of
+ * models/fusion.py:49-58, models/encoder.py:16-40, models/volume_render.py:29-37 and the torchvision bottlenecks):
+ *   fwd   batch statistics over the M rows (float64 sums), y = lrelu((x - mean) invstd gamma + beta, slope); mean / invstd [C] are stored for the
+ *         backward; running_mean / running_var (nullable) are updated in place with `momentum` (unbiased variance), as nn.BatchNorm does
+ *   bwd   g = dy * (pre-activation > 0 ? 1 : slope); dx = gamma invstd (g - mean(g) - xhat mean(g xhat)); dgamma = sum g xhat, dbeta = sum g
+ * x / y / dy / dx rows [M][ld] fp32, C % 4 == 0; gamma / beta nullable (1 / 0); slope 1 = no activation, 0 = ReLU; ws = forge_bn_ws_doubles(C)
+ * doubles of scratch (one float64 partial per reduction block, summed by a second kernel in a fixed order: deterministic, no atomics). */
+int forge_bn_ws_doubles(int C);
+int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                       float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
+                       long long M, int C, forge_stream_t stream);
+int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                       const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
+                       forge_stream_t stream);
+
 /* Backward of forge_conv_igemm's epilogue 1 (folded eval-BatchNorm + LeakyReLU / ReLU) for frozen-weight optimisation loops (pose
  * refinement, kubric_eval.py:412-530): dx[m][c] = dy[m][c] * scale[c] * (y[m][c] > 0 ? 1 : slope), y = the forward OUTPUT (its sign
  * is the pre-activation's for slope >= 0). Rows may be strided (ld_* floats); scale nullable (= 1). The data gradient of the

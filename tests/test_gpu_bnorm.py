@@ -1,0 +1,53 @@
+"""Train-mode BatchNorm (+ activation) on the HIP kernels (csrc/bnorm.hip, fusion.bn_act_rows) against torch.nn.BatchNorm in float64."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape,slope", [((2, 4, 6, 8, 128), 0.01), ((3, 16, 20, 8), 0.0), ((1, 3, 5, 7, 2048), 1.0), ((5, 9, 11, 24), 0.01)])
+def test_bn_train_forward_backward_and_running_stats(shape, slope):
+    from forge_amd.fusion import bn_act_rows
+    dev = torch.device("cuda:0")
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(*shape, generator=g) * 1.7 + 0.4)
+    dy = torch.randn(*shape, generator=g)
+    bn = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    ref_bn = copy.deepcopy(bn).double().train()
+    nd = len(shape)
+    x64 = x.double().requires_grad_(True)
+    y64 = ref_bn(x64.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)
+    if slope != 1.0:
+        y64 = torch.nn.functional.leaky_relu(y64, slope)
+    y64.backward(dy.double())
+    hb = bn.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = bn_act_rows(hb, xd, slope)
+    y.backward(dy.to(dev))
+    scale = max(1.0, y64.abs().max().item())
+    assert (y.detach().double().cpu() - y64.detach()).abs().max().item() < 2e-6 * scale
+    # gradients: an activation argument within rounding of zero may take the other slope: bound the bulk and the outliers separately
+    dxe = (xd.grad.double().cpu() - x64.grad).abs()
+    assert (dxe > 1e-5 * x64.grad.abs().max()).double().mean().item() < 1e-4 and dxe.norm().item() < 1e-4 * x64.grad.norm().item()
+    assert (hb.weight.grad.double().cpu() - ref_bn.weight.grad).abs().max().item() < 2e-5 * max(1.0, ref_bn.weight.grad.abs().max().item())
+    assert (hb.bias.grad.double().cpu() - ref_bn.bias.grad).abs().max().item() < 2e-5 * max(1.0, ref_bn.bias.grad.abs().max().item())
+    assert (hb.running_mean.double().cpu() - ref_bn.running_mean).abs().max().item() < 1e-6
+    assert (hb.running_var.double().cpu() - ref_bn.running_var).abs().max().item() < 1e-5
+    assert int(hb.num_batches_tracked) == 1
+
+
+def test_bn_sync_and_eval_keep_the_torch_module():
+    """SyncBatchNorm (cross-rank statistics) and eval mode are not taken by the HIP kernels: same result as the module itself."""
+    from forge_amd.fusion import bn_act_rows
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 4, 4, 4, 32, device=dev)
+    bn = nn.BatchNorm3d(32).to(dev).eval()
+    ref = torch.nn.functional.leaky_relu(bn(x.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1), 0.01)
+    assert torch.equal(bn_act_rows(bn, x, 0.01), ref)

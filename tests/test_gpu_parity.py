@@ -390,7 +390,9 @@ def test_training_loss_and_gradients_vs_oracle_autograd(dev):
     for k in keys:
         ref, got = wo[k].grad, named[k].grad.cpu()
         err = (got - ref).abs().max().item()
-        assert err < 1e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
+        # 3e-2 of the gradient's max, as in test_training_gradients_vs_reference_golden: two fp32 evaluations of this graph (the oracle's and
+        # any kernel family's) sit 0.3-1.6e-2 apart on the trunk's parameter gradients (tools/debug/feat3d_train_noise.py, float64 yardstick)
+        assert err < 3e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
 
 
 def test_training_gradients_vs_reference_golden(dev, golden):

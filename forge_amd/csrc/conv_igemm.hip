@@ -24,6 +24,10 @@
 // flight under the current MFMAs. The K order inside a 32-chunk is permuted identically for A
 // and B: a lane's 16-byte read supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of
 // MFMA j.
+//
+// Round 2: the same kernel also runs the 16 point GEMMs of a Winograd F(2x2, 3x3) x depth-tap convolution in ONE launch (forge_wino_gemm,
+// `nbat` problems: workgroup ranges select the point and add a per-point offset to the operand / weight / output pointers; transforms in
+// winograd.hip) - the stride-1 3x3x3 convolutions of the fusion, conv1 and the ResNet layer3/4 3x3 convolutions take that route.
 #include "common.h"
 #include <cmath>
 #include <cstdlib>

@@ -12,7 +12,9 @@ dev = torch.device("cuda:0")
 L = _lib.lib()
 L.forge_debug_conv_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 shapes = [(5120, 512, 128, 1), (5120, 128, 512, 1), (5120, 128, 128, 9), (5120, 1024, 256, 1), (5120, 256, 256, 9), (5120, 512, 512, 9), (20480, 64, 64, 1),
-          (32768, 128, 256, 27)]
+          (32768, 128, 256, 27),
+          # the per-workgroup shape of the Winograd gates launch (16 points x 8192 rows as ONE 3-depth-tap problem, K = 768, 24 K-steps), forced 64x64 tile
+          (131072, 256, 256, 3)]
 for M, N, K, T in shapes:
     x = torch.randn(M, K, device=dev)
     w = torch.randn(T, N, K, device=dev) * 0.02
@@ -22,13 +24,19 @@ for M, N, K, T in shapes:
     side = int(round((M / 5) ** 0.5)) if T != 27 else 32
     grid = (5, 1, side, side) if T != 27 else (1, 32, 32, 32)
     os.environ["FORGE_CONV_KSPLIT"] = "1"
-    f = lambda: co.conv_igemm(x, K, K, None, 0, 0, w, None, sc, sh, 0.0, None, None, None, out, None, grid, grid[1:], N, N, taps, epilogue=co.EPI_AFFINE_ACT)
+    os.environ.pop("FORGE_CONV_TILE", None)
+    if T == 3:
+        taps, grid = [(-1, 0, 0), (0, 0, 0), (1, 0, 0)], (16, 32, 16, 16)
+        os.environ["FORGE_CONV_TILE"] = "D"
+    epi = co.EPI_BIAS if T == 3 else co.EPI_AFFINE_ACT          # the point GEMMs store raw products
+    f = lambda: co.conv_igemm(x, K, K, None, 0, 0, w, None, sc, sh, 0.0, None, None, None, out, None, grid, grid[1:], N, N, taps, epilogue=epi)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); f(); b.record(); torch.cuda.synchronize()
     tile, ks = co.conv_plan(M, N, K, T, co.EPI_AFFINE_ACT, N)
+    tile, ks = (os.environ.get("FORGE_CONV_TILE") or tile), 1
     bm, bn = {"A": (128, 128), "B": (64, 128), "C": (128, 64), "D": (64, 64), "E": (128, 32), "F": (128, 64)}[tile]
     nwg = -(-M // bm) * -(-N // bn)
     buf = np.zeros((min(nwg, 8192), 4), dtype=np.int64)

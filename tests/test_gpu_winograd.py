@@ -225,3 +225,23 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     dwp = torch.zeros(27, 256, 256, device=dev)
     co.conv3_wgrad(dy2.to(dev), x.to(dev), 256, None, 0, dwp, (1, 4, 8, 8), 256)
     assert (dwp.double().cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("hw", [(200, 200), (72, 104), (64, 96)])
+def test_encoder_odd_and_even_trunk_grids_vs_oracle(hw):
+    """Encoder3D.get_feat3D at image sizes whose /8 trunk grid is odd (25 x 25, 9 x 13: the 2-D Winograd launches of layer3/4 and of conv1
+    decline and the direct kernel runs) and even (8 x 12: Winograd) against the oracle - 5e-6 of the output's max either way."""
+    import forge_oracle as fo
+    from forge_amd import synthetic as syn
+    from forge_amd.encoder import Encoder3D
+    dev = _dev()
+    enc = Encoder3D(syn.kubric_config())
+    w = syn.seeded_state_dict({"encoder_3d." + k: v for k, v in enc.state_dict().items()}, 0)
+    enc.load_state_dict({k[len("encoder_3d."):]: v for k, v in w.items()})
+    enc = enc.to(dev).eval()
+    img = torch.rand(2, 3, *hw, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        got = enc.get_feat3D(img.to(dev)).cpu()
+        ref = fo.get_feat3D(img, w)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()

@@ -28,13 +28,13 @@ SIGNATURES = {
     "forge_pack_cameras": [_P, _LL, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _LL, _P, _P, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
-    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 10 + [_P, _LL, _P],
+    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 12 + [_P, _LL, _P],
     "forge_wino_weights": [_P, _P, _I, _I, _I, _I, _P],
     "forge_wino_dy": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "forge_wino_wgrad": [_P, _P, _I, _LL, _LL, _P, _I, _LL, _LL, _P, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_dw": [_P, _P, _I, _I, _I, _P],
     "forge_wino_input": [_P, _I, _LL, _P, _I, _LL, _I, _I, _I, _I, _I, _P],
-    "forge_wino_gemm": [_P, _I, _I, _LL, _LL, _P, _I, _I, _LL, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "forge_wino_gemm": [_P, _I, _I, _LL, _LL, _P, _I, _I, _LL, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_gemm_tile": [_LL, _I],
     "forge_wino_output": [_P, _P, _LL, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _P, _P],
@@ -94,14 +94,14 @@ def current_stream():
 
 
 def on_tensor_device(fn):
-    """Decorator for launch wrappers: run `fn` with the device of its first cuda tensor argument current, so that
+    """Decorator for launch wrappers: run `fn` with the device of its first cuda tensor argument (positional or keyword) current, so that
     `current_stream()` is that device's stream and per-device kernel attributes are applied to it (a process may hold models on
     several GPUs while torch's current device is another one)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*args, **kw):
-        for a in args:
+        for a in list(args) + list(kw.values()):       # keyword call sites too (the models call rotate / render with keywords)
             if torch.is_tensor(a) and a.is_cuda:
                 if a.device.index != torch.cuda.current_device():
                     with torch.cuda.device(a.device):

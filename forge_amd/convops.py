@@ -148,31 +148,52 @@ def invalidate_packed(module):
             m.invalidate_packed()
 
 
-_SPLITK_WS = {}
-SPLITK_WS_BYTES = 128 << 20
-
-
-def _splitk_workspace(device):
-    """Scratch for forge_conv_igemm's split-K mode, one per (device, stream): launches on different streams may run concurrently and
-    must not share partial-sum storage (allocated once per stream, outside any graph capture by the warm-up passes)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _SPLITK_WS.get(key)
-    if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=torch.float32, device=device)
-    return ws
-
+SPLITK_WS_BYTES = 128 << 20          # cap the plan model may assume for split-K partial tiles (ksplit x M x Cout floats)
 
 TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
+_PLAN_CACHE = {}
+_PLAN_OVERRIDE = [None]               # (tile letter or None, ksplit or None): set by force_plan() only (tools/conv_plan_sweep.py, tests)
+
+
+class force_plan:
+    """Context manager for tools / tests: pin the workgroup tile ('A'..'E') and / or the split-K factor of every forge_conv_igemm and
+    forge_wino_gemm launch made inside it, instead of the library's plan model. The library itself reads no environment variables; the
+    override travels as the explicit (tile, ksplit) arguments of the C-ABI calls."""
+
+    def __init__(self, tile=None, ksplit=None):
+        self.val = (tile, ksplit)
+
+    def __enter__(self):
+        self.prev = _PLAN_OVERRIDE[0]
+        _PLAN_OVERRIDE[0] = self.val
+        return self
+
+    def __exit__(self, *exc):
+        _PLAN_OVERRIDE[0] = self.prev
+        return False
+
 
 def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
-    """(tile letter, ksplit) forge_conv_igemm will use for this problem (forge_conv_igemm_plan; host arithmetic only). nphase = 4 / 8
-    for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases)."""
-    import ctypes
-    tile, ks = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
-                                                ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
-    return chr(tile.value), ks.value
+    """(tile letter, ksplit) of this problem: forge_conv_igemm_plan's makespan model (host arithmetic only, cached per shape), or the
+    force_plan() override. nphase = 4 / 8 for a merged-phase transposed-conv launch (M rows per phase, ntaps over all phases). The
+    launcher passes the answer to forge_conv_igemm explicitly and sizes the split-K scratch from it."""
+    key = (int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo) % 4 == 0)
+    pl = _PLAN_CACHE.get(key)
+    if pl is None:
+        tile, ks = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
+                                                    ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
+        pl = _PLAN_CACHE[key] = (chr(tile.value), ks.value)
+    ov = _PLAN_OVERRIDE[0]
+    if ov is not None and pl[0] != "N":
+        tile = ov[0] or pl[0]
+        ks = ov[1] if ov[1] is not None else (pl[1] if ov[0] is None else 1)
+        can_split = nphase == 1 and epilogue in (EPI_BIAS, EPI_AFFINE_ACT) and Cout % 4 == 0 and ldo % 4 == 0
+        if ks > 1 and not (can_split and ks * M * Cout * 4 <= SPLITK_WS_BYTES and ks <= (ntaps // nphase) * (Cin // 32)):
+            ks = 1
+        return tile, ks
+    return pl
 
 
 MAX_OPERAND_BYTES = (1 << 31) - 1       # 32-bit buffer offsets of the kernel's gathered operands (tests lower it to exercise the chunking)
@@ -197,8 +218,10 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
     nc = n
     while nc > 1 and (span(nc, b1, ld1) > limit or (in2 is not None and span(nc, b2, ld2) > limit)):
         nc = (nc + 1) // 2
-    ws = _splitk_workspace(out.device)
     L, st, arr = _lib.lib(), _lib.current_stream(), _taps_array(taps)
+    nphase = 1
+    if tuple(phase) == (-1, -1, -1):
+        nphase = 8 if Do == 2 * D else 4
 
     def off(t, floats):                       # device pointer of tensor t advanced by `floats` elements (None -> NULL)
         return None if t is None else ctypes.c_void_p(t.data_ptr() + 4 * floats)
@@ -206,13 +229,19 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
     for s0 in range(0, n, nc):
         k = min(nc, n - s0)
         orow = s0 * out_rows                  # first output row of the chunk (lift: rows of the un-lifted GEMM grid, same product)
+        # the plan is made here and handed over explicitly: a split-K launch gets scratch of exactly ksplit x M x Cout floats from
+        # torch's stream-ordered caching allocator (per-stream pools; inside a hipGraph capture it comes from the graph's private
+        # pool and is reused by the graph's later launches) - no process-global workspace
+        tile, ksplit = conv_plan(k * D * H * W, Cout, C1 + C2, len(taps), epilogue, ldo, nphase)
+        ws = torch.empty(ksplit * k * D * H * W * Cout, dtype=torch.float32, device=out.device) if ksplit > 1 else None
         o_ld = gate_w if epilogue == EPI_GRU_GATES else ldo
         _lib.check(L.forge_conv_igemm(
             off(in1, s0 * b1 * ld1), C1, ld1, int(bs1), off(in2, s0 * b2 * ld2), C2, ld2, int(bs2), _lib.ptr(wp), _lib.ptr(bias), _lib.ptr(scale),
             _lib.ptr(shift), float(slope), off(residual, orow * (Cout if (lift or epilogue in (EPI_GRU_GATES, EPI_GRU_OUT)) else ldo)),
             off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
             off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
-            arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), _lib.ptr(ws), SPLITK_WS_BYTES, st),
+            arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), 0 if tile == "N" else ord(tile), ksplit,
+            _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, st),
             "forge_conv_igemm")
     return out
 
@@ -325,10 +354,29 @@ def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
             and C1 + C2 >= 64 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
 
 
+_WINOGRAD = [True]
+
+
 def wino_enabled():
-    """FORGE_WINOGRAD=0 keeps the direct implicit-GEMM kernel for the fused ConvGRU convolutions (A/B, tools/wino_ab.py)."""
-    import os
-    return os.environ.get("FORGE_WINOGRAD", "1") != "0"
+    """The stride-1 3x3(x3) convolutions take the Winograd launches unless a tool / test asked for the direct implicit-GEMM kernel
+    (`with convops.winograd(False): ...`; A/B: tools/wino_ab.py, bit-equality tests of launcher mechanics)."""
+    return _WINOGRAD[0]
+
+
+class winograd:
+    """Context manager: run the enclosed launches with (True) / without (False) the Winograd path."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _WINOGRAD[0]
+        _WINOGRAD[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _WINOGRAD[0] = self.prev
+        return False
 
 
 def wino_scene_chunk(b, D, H, W, C, views=1):
@@ -363,13 +411,17 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
         raise ValueError("transformed weight %s does not match Cout=%d Cin=%d" % (tuple(U.shape), Cout, C1 + C2))
     p1 = ctypes.c_void_p(V1.data_ptr() + 4 * view * vol * C1)
     _lib.check(_lib.lib().forge_wino_gemm(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
-                                          0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd, _lib.current_stream()),
+                                          0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd,
+                                          ord(wino_gemm_tile(n * vol, Cout)), _lib.current_stream()),
                "forge_wino_gemm")
     return Mm
 
 
 def wino_gemm_tile(R, Cout):
     """Tile letter forge_wino_gemm uses for R tile rows per point (names the kernel instantiation for profilers, bench.py)."""
+    ov = _PLAN_OVERRIDE[0]
+    if ov is not None and ov[0]:
+        return ov[0]
     return chr(_lib.lib().forge_wino_gemm_tile(int(R), int(Cout)))
 
 

@@ -30,7 +30,6 @@
 // winograd.hip) - the stride-1 3x3x3 convolutions of the fusion, conv1 and the ResNet layer3/4 3x3 convolutions take that route.
 #include "common.h"
 #include <cmath>
-#include <cstdlib>
 #include <type_traits>
 
 namespace forge {
@@ -655,7 +654,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 //                prologue/epilogue term per round, larger for tile A whose 2 resident workgroups overlap it worst
 //   split-K    slices K across workgroups when the chip is under-filled (M = 5120: ResNet, one scene); costs the reduction kernel
 // Constants fitted on tools/conv_plan_sweep.py (52 shapes x 30 plans, 1 and 4 scenes): chosen plans are within 0.2 % of the
-// per-shape best in total. FORGE_CONV_TILE=A..E / FORGE_CONV_KSPLIT=n override the model (that tool).
+// per-shape best in total. Callers may pass an explicit (tile, ksplit) to forge_conv_igemm instead (tools/conv_plan_sweep.py, tests).
 struct ConvPlan { char tile; int ksplit; };
 
 static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes) {
@@ -668,15 +667,11 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
     const double K = (double)ntaps * Cin;
     ConvPlan best{'D', 1};
     double best_us = 1e300;
-    const char* ft = getenv("FORGE_CONV_TILE");
-    const char* fk = getenv("FORGE_CONV_KSPLIT");
     for (const Tile& t : tiles) {
-        if (ft && *ft != t.id) continue;
-        if (!ft && t.id == 'E' && Cout > 32) continue;
+        if (t.id == 'E' && Cout > 32) continue;
         const long long ntn = (Cout + t.bn - 1) / t.bn;
         const long long nb = ((M + t.bm - 1) / t.bm) * ntn;
         for (int k : splits) {
-            if (fk && atoi(fk) != k) continue;
             if (k > 1 && (!can_split || nsteps / k < 8 || (long long)k * M * Cout * 4 > ws_bytes)) continue;
             const long long wgs = nb * k, slots = 256LL * t.occ;
             const long long full = wgs / slots, rem = wgs - full * slots;
@@ -744,7 +739,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
+                                int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
@@ -793,9 +788,17 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
         hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
     } else {
-        const ConvPlan pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp,
-                                      a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0,
-                                      splitk_ws_bytes);
+        const bool can_split = a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0;
+        ConvPlan pl;
+        if (tile == 0) {
+            pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp, can_split, splitk_ws_bytes);
+        } else {                                                       // the caller's plan (forge_conv_igemm_plan's answer, or a sweep / test override)
+            pl = ConvPlan{(char)tile, ksplit > 1 ? ksplit : 1};
+            FORGE_REQUIRE(tile >= 'A' && tile <= 'E', FORGE_EINVAL, "forge_conv_igemm: tile '%c' is not one of A..E (0 = planned here)", (char)tile);
+            FORGE_REQUIRE(pl.ksplit == 1 || (can_split && pl.ksplit <= 8 && (long long)pl.ksplit * M * Cout * 4 <= splitk_ws_bytes &&
+                                             pl.ksplit <= a.tpp * ((C1 + C2) / BK)), FORGE_EINVAL,
+                          "forge_conv_igemm: ksplit=%d needs epilogue 0/1 without phases, Cout, ldo %% 4 == 0 and a workspace of ksplit M Cout floats", pl.ksplit);
+        }
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         if (int rc = launch_conv_tile(a, pl.tile, st)) return rc;
         if (a.ksplit > 1) {
@@ -810,9 +813,8 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
 // Workgroup tile of forge_wino_gemm for R tile rows per point. The makespan model (plan_conv) was fitted on single-problem launches; for
 // the 16 short-K problems of one launch the measured optimum (tools/wino_gemm_sweep.py, 1 and 4 scenes) is the 64x128 tile, except for
 // wide outputs on a small grid (the gates launch of one scene: 64x64 at 112 TF vs 104 TF), where more, smaller workgroups balance the
-// partial rounds better. FORGE_CONV_TILE overrides it (that tool).
+// partial rounds better. forge_wino_gemm's `tile` argument overrides it (that tool).
 extern "C" int forge_wino_gemm_tile(long long R, int Cout) {
-    if (const char* ft = getenv("FORGE_CONV_TILE")) return *ft;
     return (Cout >= 256 && 16 * R * (long long)Cout < (48ll << 20)) ? 'D' : 'B';
 }
 
@@ -821,7 +823,8 @@ extern "C" int forge_wino_gemm_tile(long long R, int Cout) {
 // transformed weights U[p] [kd depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a kd-tap implicit GEMM over the tile grid, K = kd (C1 + C2);
 // kd = 3 for the 3x3x3 convolutions, kd = 1 for the 3x3 convolutions of a 2-D network (D = 1 or D = images: planes do not mix).
 extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
-                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream) {
+                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile, forge_stream_t stream) {
+    FORGE_REQUIRE(tile == 0 || (tile >= 'A' && tile <= 'E'), FORGE_EINVAL, "forge_wino_gemm: tile must be 0 (default rule) or 'A'..'E'");
     FORGE_REQUIRE(V1 && U && Mm && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_gemm: null pointer argument / kd not 1 or 3");
     FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 16, FORGE_EINVAL, "forge_wino_gemm: bad dims n=%d D=%d Ht=%d Wt=%d Cout=%d (Cout > 16)", n,
                   D, Ht, Wt, Cout);
@@ -840,7 +843,7 @@ extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, 
     a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = kd; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = kd; a.epi = EPI_BIAS;
     a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = (long long)kd * Cout * (C1 + C2); a.pto = R * Cout;
     if (kd == 3) { a.tap[0][0] = -1; a.tap[2][0] = 1; }                 // depth taps (-1,0,0), (0,0,0), (1,0,0); kd = 1: the 2-D convolution's single tap
-    if (int rc = launch_conv_tile(a, (char)forge_wino_gemm_tile(R, Cout), (hipStream_t)stream)) return rc;
+    if (int rc = launch_conv_tile(a, (char)(tile ? tile : forge_wino_gemm_tile(R, Cout)), (hipStream_t)stream)) return rc;
     FORGE_LAUNCH_CHECK("forge_wino_gemm");
     return 0;
 }

@@ -21,7 +21,6 @@
 // Roofline: compulsory HBM traffic is tiny (one read of the 17-channel volume per scene + the
 // output planes); the kernel is bound by L1/TA gather rate — see DESIGN.md.
 #include "common.h"
-#include <cstdlib>
 
 namespace forge {
 
@@ -131,20 +130,11 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
                                                          const float* __restrict__ cams, const int* __restrict__ view2vol,
                                                          float* __restrict__ out_feat, float* __restrict__ out_opac,
                                                          float* __restrict__ out_depth, int D, int H, int W, int Hr, int Wr,
-                                                         int S, float zmin, float zmax, float hx, float hy, float hz, int xcd_order) {
+                                                         int S, float zmin, float zmax, float hx, float hy, float hz) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
-    // Workgroup -> (view, pixel tile). The dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with a private 4 MiB
-    // L2: in launch order every XCD marches every 8th tile of every view. xcd_order = 1 remaps the linear id so that an XCD owns a
-    // CONTIGUOUS run of tiles (a band of one or two views). Measured (tools/pmc_render.sh, round 2): L2 fills 430 -> 365 MB per 5-view
-    // launch but 0.096 -> 0.106 ms at 64^3 and 0.130 -> 0.140 ms at 128^3 (only 28 views of a 64^3 volume gain 4 %): the launch
-    // order stays the default, the remap is kept as an A/B switch (FORGE_RENDER_XCD_ORDER=1). Placement only; results are identical.
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (xcd_order) {
-        const unsigned lin = xcd_remap((bz * gridDim.y + by) * gridDim.x + bx, gridDim.x * gridDim.y * gridDim.z);
-        bx = lin % gridDim.x;
-        by = (lin / gridDim.x) % gridDim.y;
-        bz = lin / (gridDim.x * gridDim.y);
-    }
+    // Workgroup -> (view, pixel tile) in launch order (an XCD-contiguous remap of the tiles was measured slower at every size but
+    // 28 views x 64^3: profiles/r02_render_ab.txt).
+    const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     const int v = (int)bz;
     const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
     int lx, ly;
@@ -193,90 +183,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
     if (cg == 0) {
         out_opac[(long long)v * plane + pix] = 1.f - T;
         if (out_depth) out_depth[(long long)v * plane + pix] = depth;
-    }
-}
-
-// A/B variant named by the north star: "per-ray kernel with wavefront-prefix-summed transmittance and early-out". One WAVE marches one
-// ray; the 64 lanes are (16 consecutive samples) x (C4 = 4 channel groups), so a load instruction still requests 16 distinct 64-byte rows
-// (the gather-rate limit found in round 1) but they lie ALONG the ray instead of across a 4x4 pixel quad. Per 16-sample chunk the
-// transmittance is an inclusive prefix product across the sample lanes (shuffle-up by 4, 8, 16, 32 lanes), the chunk-to-chunk carry is
-// the last lane's product, and a chunk is skipped / the march ends when every lane's transmittance is exactly 0 (wave-uniform test).
-// Same early-out rules as render_fwd_kernel (ray/AABB sample interval, T == 0); the summation is a per-lane partial sum + a tree, so
-// results agree with the sequential march to fp32 rounding, not bit for bit. Selected with FORGE_RENDER_WAVE=1 (tools/render_probe.py,
-// tools/pmc_render.sh). Measured in round 2: 0.147 vs 0.097 ms for 5 views of a 64^3 volume, 0.176 vs 0.130 ms at 128^3, 1.01 vs 0.71 ms for
-// 28 views at 128^3, with 1.4-2.4x the L2 fills (samples along one ray share no voxel rows; the quads of neighbouring rays do) - the
-// sequential quad march stays the default.
-__global__ __launch_bounds__(256) void render_fwd_wave_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
-                                                              const float* __restrict__ cams, const int* __restrict__ view2vol,
-                                                              float* __restrict__ out_feat, float* __restrict__ out_opac,
-                                                              float* __restrict__ out_depth, int D, int H, int W, int Hr, int Wr,
-                                                              int S, float zmin, float zmax, float hx, float hy, float hz) {
-    constexpr int C4 = 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cg = lane & 3, sl = lane >> 2;                       // channel group, sample within the 16-sample chunk
-    // workgroup = 2x2 pixel quad (4 waves, one ray each); grid (Wr/2, Hr/2, V)
-    const int w = blockIdx.x * 2 + (wave & 1), h = blockIdx.y * 2 + (wave >> 1), v = blockIdx.z;
-    if (w >= Wr || h >= Hr) return;
-    const float* cam = cams + v * 16;
-    const long long nvox = (long long)D * H * W;
-    const float4* F = feat + (long long)view2vol[v] * nvox * C4 + cg;
-    const float* Dn = dens + (long long)view2vol[v] * nvox;
-    const RayCam ray = make_ray(cam, w, h);
-    const float step = (zmax - zmin) / (float)(S - 1);
-    int s0, s1;
-    ray_interval(ray, hx, hy, hz, W, H, D, S, zmin, step, s0, s1);
-    const float scx = (float)(W - 1), scy = (float)(H - 1), scz = (float)(D - 1);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float Tin = 1.f, depth = 0.f;
-    for (int sb = s0; sb <= s1; sb += 16) {
-        const int s = sb + sl;
-        float d = 0.f, z = 0.f;
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s <= s1) {
-            z = sample_depth(s, S, zmin, zmax, step);
-            const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
-            const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
-            const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
-            Taps t;
-            taps_ac_true(px, py, pz, W, H, D, t);
-            if (t.any) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const long long o = tap_off(t, k);
-                    d = fmaf(t.w[k], Dn[o], d);
-                    f = f4_fma(t.w[k], F[o * C4], f);
-                }
-            }
-        }
-        // inclusive prefix product of (1 - d) over the 16 sample lanes (lane stride 4 = same channel group)
-        float p = 1.f - d;
-#pragma unroll
-        for (int off = 4; off < 64; off <<= 1) {
-            const float q = __shfl_up(p, off, 64);
-            if (lane >= off) p *= q;
-        }
-        const float pprev = __shfl_up(p, 4, 64);                            // executed by ALL lanes (a divergent shuffle reads inactive lanes)
-        const float Texcl = Tin * (sl == 0 ? 1.f : pprev);                  // transmittance in front of this sample
-        const float wgt = d * Texcl;
-        acc = f4_fma(wgt, f, acc);
-        depth = fmaf(wgt, z, depth);
-        Tin *= __shfl(p, 60 + cg, 64);                                        // carry: product over the whole chunk
-        if (Tin == 0.f) break;                                                // wave-uniform: every later weight is exactly 0
-    }
-    // reduce the per-lane partial sums over the 16 sample lanes
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) {
-        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
-        depth += __shfl_xor(depth, off, 64);
-    }
-    const long long plane = (long long)Hr * Wr, pix = (long long)h * Wr + w;
-    if (sl == 0) {
-        reinterpret_cast<float4*>(out_feat)[((long long)v * plane + pix) * C4 + cg] = acc;
-        if (cg == 0) {
-            out_opac[(long long)v * plane + pix] = 1.f - Tin;
-            if (out_depth) out_depth[(long long)v * plane + pix] = depth;
-        }
     }
 }
 
@@ -617,22 +523,11 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
                                 float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
     if (int rc = check_render_args("forge_render_fwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
     FORGE_REQUIRE(out_feat && out_opac, FORGE_EINVAL, "forge_render_fwd: null output pointer");
-    const char* wv = getenv("FORGE_RENDER_WAVE");                       // A/B switch, read per call: one wave per ray, lanes = samples
-    const int wave_variant = wv ? atoi(wv) : 0;
-    if (wave_variant && C == 16) {
-        dim3 grid((Wr + 1) / 2, (Hr + 1) / 2, V);
-        hipLaunchKernelGGL(render_fwd_wave_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam, view2vol, out_feat,
-                           out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
-        FORGE_LAUNCH_CHECK("forge_render_fwd");
-        return 0;
-    }
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
         dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
-        const char* xo = getenv("FORGE_RENDER_XCD_ORDER");               // A/B switch, read per call: 1 = XCD-contiguous tiles
-        const int xcd_order = xo ? atoi(xo) : 0;
         hipLaunchKernelGGL(render_fwd_kernel<C4>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                           view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, xcd_order);
+                           view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
     });
     FORGE_LAUNCH_CHECK("forge_render_fwd");
     return 0;

@@ -6,8 +6,6 @@ methods (`get_feat3D`, `get_density3D`, `get_render_features`, `fuse`) and the s
 (SURVEY.md Appendix B). torchvision is not a dependency: the ResNet-50 trunk is built here with
 torchvision's module names so published checkpoints load with strict=True.
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -305,7 +303,7 @@ class Encoder3D(co.PackedModule):
         return r if r.is_contiguous() else r.contiguous()
 
     LIFT_Z, LIFT_C = 32, 64          # z_2d.view(-1, 64, 32, H, W): trunk channel c = c3d*32 + z (models/encoder.py:49)
-    TRUNK_WINO_MIN_PLANES = int(os.environ.get("FORGE_TRUNK_WINO_MIN", "256"))
+    TRUNK_WINO_MIN_PLANES = 256      # bottleneck width from which the stride-1 3x3 convolutions run as Winograd (sweep: profiles/TUNING_LOG.md)
 
     def _trunk_packed(self):
         """Packed weights of ResNet layers 1-4 for the GEMM kernel. The 2048-wide residual stream of layer4 is kept in
@@ -333,7 +331,7 @@ class Encoder3D(co.PackedModule):
                     if pout is not None:
                         w3, a3 = w3[pout], (a3[0][pout].contiguous(), a3[1][pout].contiguous())
                     # stride-1 3x3 convolutions with GEMM-sized channel counts (layer3 / layer4: K = planes >= 256 per Winograd point) run as
-                    # Winograd F(2x2, 3x3), csrc/winograd.hip with one "depth" tap; FORGE_TRUNK_WINO_MIN sets the channel threshold (A/B)
+                    # Winograd F(2x2, 3x3), csrc/winograd.hip with one "depth" tap (layer1/2 are too narrow: measured)
                     u2 = co.wino_pack_packed(w2) if (blk.conv2.stride[0] == 1 and w1.shape[0] >= self.TRUNK_WINO_MIN_PLANES) else None
                     d = {"w1": w1[None].contiguous(), "a1": co.bn_affine(blk.bn1), "w2": w2, "u2": u2, "taps2": taps2, "a2": co.bn_affine(blk.bn2),
                          "stride": blk.conv2.stride[0], "w3": w3[None].contiguous(), "a3": a3, "planes": w1.shape[0], "ds": None}

@@ -64,6 +64,16 @@ def grouped_mse(pred, target, gsize):
     """[F.mse_loss(pred[:, g*gsize:(g+1)*gsize], target[:, (g*gsize) % Vt ...]) for g] as ONE pass (f1: the four MSE terms of a training
     iteration are two calls - rgb and mask). pred [B,Vp,C,H,W], target [B,Vt,C,H,W] on the MI355X."""
     B, Vp, C, H, W = pred.shape
+    if not (pred.is_cuda and pred.dtype == torch.float32):
+        raise TypeError("grouped_mse: pred must be a float32 tensor on the MI355X (got %s on %s)" % (pred.dtype, pred.device))
+    if target.dim() != 5 or target.shape[0] != B or tuple(target.shape[2:]) != (C, H, W):
+        raise ValueError("grouped_mse: target %s does not match pred %s in batch / (C, H, W)" % (tuple(target.shape), tuple(pred.shape)))
+    if Vp % int(gsize) or target.shape[1] < 1:
+        raise ValueError("grouped_mse: %d predicted views are not a multiple of the group size %d" % (Vp, gsize))
+    # what F.mse_loss would do implicitly: bool / uint8 masks, float64 / half images are promoted to pred's dtype, and the kernel reads
+    # the target with raw fp32 pointers, so it must live on pred's device
+    if target.dtype != torch.float32 or target.device != pred.device:
+        target = target.to(device=pred.device, dtype=torch.float32)
     sse = _SseGroups.apply(pred, target, int(gsize))
     return sse / float(B * gsize * C * H * W)
 

@@ -148,8 +148,22 @@ class VolRender(co.PackedModule):
             result.append(origin if origin is not None else self._origin_proj(T, K))
         return tuple(result)
 
+    def _conv_rgb_pack(self):
+        """Packed / folded conv_rgb parameters of the fused inference launches (rebuilt when a source tensor changed)."""
+        cr = self.conv_rgb
+        src = [cr[0].weight, cr[0].bias, cr[3].weight, cr[3].bias, cr[6].weight, cr[6].bias] + \
+              [t for bn in (cr[1], cr[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
+
+        def build():
+            w3, taps3 = co.pack_conv2d_weight(cr[3].weight)
+            w6, taps6 = co.pack_conv2d_weight(cr[6].weight)
+            return {"ct": co.convT_phases_merged(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
+                    "w3": w3, "taps3": taps3, "b3": cr[3].bias.detach().contiguous(), "bn4": co.bn_affine(cr[4]),
+                    "w6": w6, "taps6": taps6, "b6": cr[6].bias.detach().contiguous()}
+        return self._rgb_cache.get(src, build)
+
     def _conv_rgb_packed_T(self):
-        p = self._rgb_cache.val
+        p = self._conv_rgb_pack()               # re-pack if the cache was dropped between forward and backward (train()/eval(), .to(), ...)
         if "ctT" not in p:
             cr = self.conv_rgb
             k, pad = cr[0].weight.shape[-1], self.pad_size
@@ -163,17 +177,7 @@ class VolRender(co.PackedModule):
         """conv_rgb + ReLU (models/volume_render.py:29-37,73) on the MFMA GEMM kernel: ConvTranspose2d(16,16,k+1,s2,p) as its 4
         output phases in one launch + folded BN + LeakyReLU, Conv2d(16,8,k)+BN+LeakyReLU, Conv2d(8,3,k)+ReLU. x [V,16,Hr,Wr] with
         channels-last memory (what the ray-marcher writes) -> [V,3,2Hr,2Wr] (channels-last memory)."""
-        cr = self.conv_rgb
-        src = [cr[0].weight, cr[0].bias, cr[3].weight, cr[3].bias, cr[6].weight, cr[6].bias] + \
-              [t for bn in (cr[1], cr[4]) for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)]
-
-        def build():
-            w3, taps3 = co.pack_conv2d_weight(cr[3].weight)
-            w6, taps6 = co.pack_conv2d_weight(cr[6].weight)
-            return {"ct": co.convT_phases_merged(cr[0].weight, self.pad_size, 2), "ct_b": cr[0].bias.detach().contiguous(), "bn1": co.bn_affine(cr[1]),
-                    "w3": w3, "taps3": taps3, "b3": cr[3].bias.detach().contiguous(), "bn4": co.bn_affine(cr[4]),
-                    "w6": w6, "taps6": taps6, "b6": cr[6].bias.detach().contiguous()}
-        p = self._rgb_cache.get(src, build)
+        p = self._conv_rgb_pack()
         V, C, Hr, Wr = x.shape
         xr = x.permute(0, 2, 3, 1)
         xr = xr if xr.is_contiguous() else xr.contiguous()

@@ -167,6 +167,9 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
  *   lift > 0 (epilogue 1, 2-D conv i.e. D = 1): fuses the 2D->3D feature lift of models/encoder.py:49 into the store —
  *            GEMM column j = z*(Cout/lift) + c of row (n, h, w) is written to out[n][z][h][w][c] (a channels-last
  *            (n, lift, H, W) volume with Cout/lift channels). The caller orders the weight rows accordingly.
+ *   tile / ksplit: the launch plan. tile = 0: planned inside the call (forge_conv_igemm_plan's model; split-K only if splitk_ws is given).
+ *            tile = 'A'..'E' with ksplit >= 1: the caller's plan, taken verbatim (normally forge_conv_igemm_plan's answer, so that the
+ *            caller can size splitk_ws to ksplit M Cout floats; also how tools / tests pin a tile). Ignored for Cout <= 16.
  *   splitk_ws (nullable, splitk_ws_bytes): scratch for split-K. When the M x Cout tile grid alone cannot fill the chip
  *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
  *            per tile; raw partial tiles go to splitk_ws[slice][M][Cout] and a second kernel sums them in a fixed order and
@@ -179,7 +182,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, int lift, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
+                     int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
 
 /* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
  * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
@@ -223,7 +226,8 @@ int forge_wino_dw(const float* dU, float* dw, int Cout, int Cin, int kd, forge_s
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
-                    long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);
+                    long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile /* 0 = forge_wino_gemm_tile's rule */,
+                    forge_stream_t stream);
 int forge_wino_gemm_tile(long long R, int Cout);   /* the workgroup tile letter ('A'..'E', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point */
 int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,

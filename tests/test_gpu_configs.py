@@ -104,7 +104,7 @@ def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
     """BASELINE configs[2]: full HIP path, batch = 8 scenes, 64^3 render grid, 1 GPU. Scenes 2 and 5 of the batch against the CPU
     oracle; every scene of the batch equals the same scene run alone (b = 1) up to fp32 summation order under the default launch
     plan (the plan model may pick another tile / split-K factor for another M), and BIT FOR BIT when both runs are pinned to one
-    plan (FORGE_CONV_TILE / FORGE_CONV_KSPLIT): the batch only changes M, never the per-row arithmetic."""
+    plan (convops.force_plan): the batch only changes M, never the per-row arithmetic."""
     from forge_amd.model import FORGE
     model, w, cfg = _model(FORGE, dev)
     ds = syn.SyntheticDataset(1.5)
@@ -128,8 +128,8 @@ def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
         worst = max(worst, (i1.cpu() - imgs[s]).abs().max().item(), (m1.cpu() - masks[s]).abs().max().item())
     # different M -> possibly different tile / split-K plans -> different fp32 summation orders: equality up to rounding, stated
     assert worst < 2e-4, worst
-    monkeypatch.setenv("FORGE_CONV_TILE", "D")
-    monkeypatch.setenv("FORGE_CONV_KSPLIT", "1")
+    from forge_amd import convops as co_
+    monkeypatch.setitem(co_._PLAN_OVERRIDE, 0, ("D", 1))
     with torch.no_grad():
         pi, pm = model(sample, ds, dev)
         pi, pm = pi.reshape(8, 5, 3, 256, 256).clone(), pm.reshape(8, 5, 1, 256, 256).clone()
@@ -447,40 +447,6 @@ def test_grouped_mse_equals_four_mse_losses(dev):
             (5.0 * m[0] + 0.3 * m[1]).backward()
             (5.0 * ref[0] + 0.3 * ref[1]).backward()
             assert (p1.grad - p2.grad).abs().max().item() < 1e-6 * p2.grad.abs().max().item() + 1e-9
-
-
-@pytest.mark.parametrize("env", [{"FORGE_RENDER_WAVE": "1"}, {"FORGE_RENDER_XCD_ORDER": "1"}])
-def test_render_ab_variants_match_default(dev, env, monkeypatch):
-    """The two ray-march A/B variants kept behind environment switches (wave-per-ray with a shuffle prefix product; XCD-contiguous
-    tile order) render the same images as the default kernel: XCD order bit for bit (placement only), wave-per-ray to fp32 rounding
-    (tree vs sequential products / sums) - plus the analytic KATs through the wave variant."""
-    feat, dens = syn.blob_volumes(2, 32, 16, seed=4)
-    _, extr, _ = syn.orbit_cameras(6, 1.5, 15.0)
-    E = extr[[0, 2, 3, 5]]
-    Kh = fo.halve_intrinsics(syn.intrinsics(128)[None].repeat(4, 1, 1))
-    cam = torch.cat([E[:, :3, :3].reshape(4, 9), E[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1).to(dev)
-    v2v = torch.tensor([0, 1, 1, 0], dtype=torch.int32, device=dev)
-    h = fo.grid_half_extent(32, 1.0)
-    args = (feat.to(dev), dens.to(dev), cam, v2v, 64, 64, 64, 0.5, 2.0, (h, h, h), True)
-    base = [o.clone() for o in ops.render_rays(*args)]
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    got = ops.render_rays(*args)
-    for a, b in zip(got, base):
-        if "FORGE_RENDER_XCD_ORDER" in env:
-            assert torch.equal(a, b)
-        else:
-            assert (a - b).abs().max().item() < 1e-5 * max(1.0, b.abs().max().item())
-    if "FORGE_RENDER_WAVE" in env:
-        case = [c for c in kat_render.cases() if c["name"] == "slab_cubic"][0]
-        cam_k = case["cam"]
-        f16 = torch.from_numpy(case["feat"]).float().repeat(4, 1, 1, 1)[None].to(dev)                      # 16 channels: the variant's shape
-        d = torch.from_numpy(case["dens"]).float()[None, None].to(dev)
-        c16 = torch.tensor(list(cam_k["R"].reshape(9)) + list(cam_k["T"]) + [cam_k["fx"], cam_k["fy"], cam_k["cx"], cam_k["cy"]], dtype=torch.float32)[None]
-        hk = 0.5 * 15 / 16
-        of, oo, od = ops.render_rays(f16, d, c16.to(dev), torch.zeros(1, dtype=torch.int32, device=dev), case["Hr"], case["Wr"], case["S"],
-                                     case["zmin"], case["zmax"], (hk, hk, hk), True)
-        kat_render.check(case, torch.cat([of[:, :4], oo, od], dim=1)[0].permute(1, 2, 0).cpu().numpy())
 
 
 def test_fuse_groups_inference_shares_input_halves(dev):

@@ -341,7 +341,7 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
     from forge_amd import convops as co
     from forge_amd.fusion import ConvGRU_3D
     torch.manual_seed(5)
-    monkeypatch.setenv("FORGE_WINOGRAD", "0")           # the direct implicit-GEMM launcher is what chunks; the Winograd path falls back to it
+    monkeypatch.setitem(co._WINOGRAD, 0, False)            # the direct implicit-GEMM launcher is what chunks; the Winograd path falls back to it
     gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).eval()
     x = (torch.randn(6, 3, 128, 8, 8, 8) * 0.5).to(dev)
     with torch.no_grad():
@@ -350,7 +350,7 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
         chunked = gru.fuse_hip(x)
         assert torch.equal(ref, chunked)
         # the Winograd path splits the batch into scene chunks whose transformed operands fit (convops.wino_scene_chunk): bit-identical too
-        monkeypatch.setenv("FORGE_WINOGRAD", "1")
+        monkeypatch.setitem(co._WINOGRAD, 0, True)
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", (1 << 31) - 1)
         wref = gru.fuse_hip(x).clone()
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 2 * 3 * 8 * 4 * 4 * 128 * 4)          # two scenes' worth of V_x per Winograd point
@@ -504,8 +504,7 @@ def test_conv_igemm_every_tile_and_splitk(dev, tile, monkeypatch):
     M = 2 * dims[0] * dims[1] * dims[2]
     seen = 0
     for k in (1, 2, 3, 4, 6):
-        monkeypatch.setenv("FORGE_CONV_TILE", tile)
-        monkeypatch.setenv("FORGE_CONV_KSPLIT", str(k))
+        monkeypatch.setitem(co._PLAN_OVERRIDE, 0, (tile, k))
         if co.conv_plan(M, Cout, Cin, 27, co.EPI_AFFINE_ACT, Cout) != (tile, k):
             continue
         seen += 1
@@ -604,13 +603,10 @@ def test_conv_igemm_strided2d_and_transpose_phases(dev):
     # the same 8 phases merged into ONE launch (phase = (-1,-1,-1)): identical results, for every tile the plan may pick
     taps_all, wp_all = co.convT_phases_merged(wt, 1, 3)
     for tile in "CDE":
-        os.environ["FORGE_CONV_TILE"] = tile
-        try:
+        with co.force_plan(tile=tile):
             out2 = torch.full((1, 8, 10, 6, 40), float("nan"), device=dev)
             co.conv_igemm(_rows(x).to(dev), 32, 32, None, 0, 0, wp_all.to(dev), b.to(dev), None, None, 1.0, None, None, None, out2, None,
                           (1, 4, 5, 3), (4, 5, 3), 40, 40, taps_all, out_grid=(8, 10, 6), ostride=2, phase=(-1, -1, -1), epilogue=co.EPI_BIAS)
-        finally:
-            os.environ.pop("FORGE_CONV_TILE", None)
         assert torch.equal(out2, out), tile
     # 2-D, narrow-N kernel: ConvTranspose2d(16, 16, 6, stride 2, padding 2) as 4 merged phases (conv_rgb's first layer)
     x2 = torch.randn(2, 16, 9, 11, generator=g)

@@ -6,6 +6,8 @@ import sys
 import pytest
 import torch
 
+from forge_amd import convops as _co
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
@@ -73,7 +75,7 @@ def test_wino_affine_epilogue_with_residual():
 
 
 def test_fuse_winograd_matches_direct_kernels_and_oracle(monkeypatch):
-    """Encoder3D.fuse on the Winograd path vs the direct implicit-GEMM path (FORGE_WINOGRAD=0) and the CPU oracle."""
+    """Encoder3D.fuse on the Winograd path vs the direct implicit-GEMM path (convops.winograd(False)) and the CPU oracle."""
     import forge_oracle as fo
     from forge_amd import synthetic as syn
     from forge_amd.fusion import ConvGRU_3D
@@ -86,9 +88,9 @@ def test_fuse_winograd_matches_direct_kernels_and_oracle(monkeypatch):
     x = torch.randn(2, 3, 32, 6, 8, 10, generator=torch.Generator().manual_seed(4))
     ref = fo.fuse(x, w)
     with torch.no_grad():
-        monkeypatch.setenv("FORGE_WINOGRAD", "1")
+        monkeypatch.setitem(_co._WINOGRAD, 0, True)
         a = gru.fuse_hip(x.to(dev)).cpu()
-        monkeypatch.setenv("FORGE_WINOGRAD", "0")
+        monkeypatch.setitem(_co._WINOGRAD, 0, False)
         d = gru.fuse_hip(x.to(dev)).cpu()
     assert a.shape == ref.shape
     assert (a - d).abs().max().item() < 2e-5, (a - d).abs().max().item()
@@ -96,7 +98,7 @@ def test_fuse_winograd_matches_direct_kernels_and_oracle(monkeypatch):
     # odd H: the Winograd path does not apply and fuse_hip keeps the direct kernel
     x2 = torch.randn(1, 2, 32, 4, 5, 6, generator=torch.Generator().manual_seed(5))
     with torch.no_grad():
-        monkeypatch.setenv("FORGE_WINOGRAD", "1")
+        monkeypatch.setitem(_co._WINOGRAD, 0, True)
         o = gru.fuse_hip(x2.to(dev)).cpu()
     assert (o - fo.fuse(x2, w)).abs().max().item() < 1e-4
 
@@ -133,20 +135,15 @@ def test_conv3_launch_forward_and_data_gradient_vs_torch():
     ref_y = y64.detach().permute(0, 2, 3, 4, 1) + res.double()
     ref_dx = x64.grad.permute(0, 2, 3, 4, 1)
     wp = co.pack_conv3d_weight(w.to(dev))
-    saved = os.environ.get("FORGE_WINOGRAD")
-    os.environ["FORGE_WINOGRAD"] = "1"
     assert co.wino_applies(co.TAPS_3x3x3, 1, n, D, H, W, Ci, 0, Co)
     for mode in ("1", "0"):
-        os.environ["FORGE_WINOGRAD"] = mode
-        try:
+        with co.winograd(mode == "1"):
             y = torch.empty(n, D, H, W, Co, device=dev)
             co.conv3_launch(x.to(dev), Ci, None, 0, wp, None, y, (n, D, H, W), Co, residual=res.to(dev))
             dx = torch.empty(n, D, H, W, Ci, device=dev)
             # Co = 64 < 128 input channels of the data-gradient problem: that one stays on the direct kernel in both modes; use a
             # 128-channel dy as well so that the Winograd data gradient is exercised
             co.conv3_launch(dy.to(dev), Co, None, 0, wp, None, dx, (n, D, H, W), Ci, dgrad=True)
-        finally:
-            os.environ["FORGE_WINOGRAD"] = "1"
         assert (y.double().cpu() - ref_y).abs().max().item() < 1e-5, mode
         assert (dx.double().cpu() - ref_dx).abs().max().item() < 1e-5, mode
     # wide data gradient (Co = 128 -> Winograd applies)
@@ -156,10 +153,6 @@ def test_conv3_launch_forward_and_data_gradient_vs_torch():
     torch.nn.functional.conv3d(x2, w2.double(), padding=1).backward(dy2.double().permute(0, 4, 1, 2, 3))
     dx2 = torch.empty(n, D, H, W, 128, device=dev)
     co.conv3_launch(dy2.to(dev), 128, None, 0, co.pack_conv3d_weight(w2.to(dev)), None, dx2, (n, D, H, W), 128, dgrad=True)
-    if saved is None:
-        os.environ.pop("FORGE_WINOGRAD", None)
-    else:
-        os.environ["FORGE_WINOGRAD"] = saved
     assert (dx2.double().cpu() - x2.grad.permute(0, 2, 3, 4, 1)).abs().max().item() < 1e-5
 
 
@@ -178,7 +171,7 @@ def test_frozen_fusion_winograd_matches_direct(monkeypatch):
     wgt = torch.randn(1, 128, 8, 8, 8, generator=torch.Generator().manual_seed(3)).to(dev)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("FORGE_WINOGRAD", mode)
+        monkeypatch.setitem(_co._WINOGRAD, 0, mode == "1")
         xi = x.clone().requires_grad_(True)
         out = gru.fuse_frozen_hip(xi)
         (out * wgt).sum().backward()
@@ -204,11 +197,11 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     ref = w.grad.reshape(Co, C1 + C2, 27).permute(2, 0, 1)                  # packed layout [27][Co][Ci]
     xsd, x2d, dyd = xs.to(dev), x2.to(dev), dy.to(dev)
     x1d = xsd[:, 1]
-    monkeypatch.setenv("FORGE_WINOGRAD", "1")
+    monkeypatch.setitem(_co._WINOGRAD, 0, True)
     assert co.wino_wgrad_applies(n, D, H, W, C1, C2, Co)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("FORGE_WINOGRAD", mode)
+        monkeypatch.setitem(_co._WINOGRAD, 0, mode == "1")
         dwp = torch.zeros(27, Co, C1 + C2, device=dev)
         co.conv3_wgrad(dyd, x1d, C1, x2d, C2, dwp, (n, D, H, W), Co, bs1=co._batch_stride_rows(x1d))
         out[mode] = dwp.double().cpu()
@@ -221,7 +214,7 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     w2 = torch.zeros(256, 256, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3), w2, padding=1).backward(dy2.double().permute(0, 4, 1, 2, 3))
     ref2 = w2.grad.reshape(256, 256, 27).permute(2, 0, 1)
-    monkeypatch.setenv("FORGE_WINOGRAD", "1")
+    monkeypatch.setitem(_co._WINOGRAD, 0, True)
     dwp = torch.zeros(27, 256, 256, device=dev)
     co.conv3_wgrad(dy2.to(dev), x.to(dev), 256, None, 0, dwp, (1, 4, 8, 8), 256)
     assert (dwp.double().cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()

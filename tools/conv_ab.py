@@ -56,11 +56,11 @@ variants = os.environ.get("AB_TILES", "A,B,D").split(",")
 res = {}
 for rnd in range(4):
     for v in variants:
-        os.environ["FORGE_CONV_TILE"] = v
-        for name in shapes:
-            if rnd == 0:
-                run(name)
-            res.setdefault((v, name), []).append(timeit(name))
+        with co.force_plan(tile=v):
+            for name in shapes:
+                if rnd == 0:
+                    run(name)
+                res.setdefault((v, name), []).append(timeit(name))
 for (v, name), ts in sorted(res.items()):
     Cout, C2, _ = shapes[name]
     fl = 2.0 * M * Cout * 27 * (Cc + C2)

@@ -76,27 +76,20 @@ ALL = []
 for (M, N, C, T) in SHAPES:
     run = setup(M, N, C, T)
     fl = 2.0 * M * N * C * T
-    os.environ.pop("FORGE_CONV_TILE", None)
-    os.environ.pop("FORGE_CONV_KSPLIT", None)
     model = co.conv_plan(M, N, C, T, co.EPI_AFFINE_ACT, N)
     res = {}
     for rnd in range(2):
-        os.environ.pop("FORGE_CONV_TILE", None)
-        os.environ.pop("FORGE_CONV_KSPLIT", None)
         t = timeit(run)
         res[("model",)] = min(res.get(("model",), 1e9), t)
         for tile in TILES:
             if tile != "E" and N <= 32 and tile in "AB":
                 continue
             for k in SPLITS:
-                os.environ["FORGE_CONV_TILE"] = tile
-                os.environ["FORGE_CONV_KSPLIT"] = str(k)
-                if co.conv_plan(M, N, C, T, co.EPI_AFFINE_ACT, N) != (tile, k):
-                    continue                                       # combination not admissible (K too short / workspace)
-                t = timeit(run)
+                with co.force_plan(tile, k):
+                    if co.conv_plan(M, N, C, T, co.EPI_AFFINE_ACT, N) != (tile, k):
+                        continue                                   # combination not admissible (K too short / workspace)
+                    t = timeit(run)
                 res[(tile, k)] = min(res.get((tile, k), 1e9), t)
-    os.environ.pop("FORGE_CONV_TILE", None)
-    os.environ.pop("FORGE_CONV_KSPLIT", None)
     tm = res.pop(("model",))
     ALL.append({"shape": [M, N, C, T], "model": list(model), "model_us": tm * 1e3, "us": {"%s%d" % k: v * 1e3 for k, v in res.items()}})
     (bt, bk), tb = min(res.items(), key=lambda kv: kv[1])

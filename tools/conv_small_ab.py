@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from forge_amd import convops as co  # noqa: E402
+from _variants import variant  # noqa: E402
 
 dev = torch.device("cuda:0")
 # (M, Cout, Cin, taps, occurrences in the trunk)
@@ -35,16 +36,14 @@ for (M, N, K, T, occ) in SHAPES:
                               epilogue=co.EPI_AFFINE_ACT)
     for rnd in range(int(os.environ.get("AB_ROUNDS", "5"))):
         for vname, env in variants:
-            for k in keys:
-                os.environ.pop(k, None)
-            os.environ.update(env)
-            f()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(20):
+            with variant(env):
                 f()
-            b.record()
-            torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20):
+                    f()
+                b.record()
+                torch.cuda.synchronize()
             res.setdefault((M, N, K, T, occ), {}).setdefault(vname, []).append(a.elapsed_time(b) / 20)
 tot = {v: 0.0 for v, _ in variants}
 for key, d in res.items():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Interleaved A/B of forge_conv_igemm launch variants selected by environment variables (read per launch by the library) on the
+"""Interleaved A/B of forge_conv_igemm launch variants selected by variant switches (tools/_variants.py: explicit plan arguments, no environment reads in the library) on the
 ConvGRU shapes: AB_VARIANTS="name:ENV=VAL,ENV=VAL;name2:..." (default: the plan's choice vs each forced tile; the round-2 experiments
 (priority, deeper prefetch, dual accumulators, chunk-outer 128x64 tile) were run through it with switches that no longer exist). Prints ms and TFLOP/s per
 (variant, shape), median of AB_ROUNDS interleaved rounds.   AB_SCENES=1|4|8 sets M = scenes * 32^3."""
@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from forge_amd import convops as co  # noqa: E402
+from _variants import variant  # noqa: E402
 
 dev = torch.device("cuda:0")
 D, Cc = 32, 128
@@ -50,11 +51,9 @@ def timeit(name, iters=8):
 res = {}
 for rnd in range(int(os.environ.get("AB_ROUNDS", "5"))):
     for vname, env in variants:
-        for k in keys:
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        for s in shapes:
-            res.setdefault((vname, s), []).append(timeit(s))
+        with variant(env):
+            for s in shapes:
+                res.setdefault((vname, s), []).append(timeit(s))
 for (vname, s), v in sorted(res.items(), key=lambda kv: (kv[0][1], kv[0][0])):
     Cout, C2, _ = shapes[s]
     ms = statistics.median(v)

@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from forge_amd import _lib, convops as co
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 dev = torch.device("cuda:0")
 L = _lib.lib()
 L.forge_debug_conv_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -24,10 +25,13 @@ for M, N, K, T in shapes:
     side = int(round((M / 5) ** 0.5)) if T != 27 else 32
     grid = (5, 1, side, side) if T != 27 else (1, 32, 32, 32)
     os.environ["FORGE_CONV_KSPLIT"] = "1"
+    apply_environ()
     os.environ.pop("FORGE_CONV_TILE", None)
+    apply_environ()
     if T == 3:
         taps, grid = [(-1, 0, 0), (0, 0, 0), (1, 0, 0)], (16, 32, 16, 16)
         os.environ["FORGE_CONV_TILE"] = "D"
+        apply_environ()
     epi = co.EPI_BIAS if T == 3 else co.EPI_AFFINE_ACT          # the point GEMMs store raw products
     f = lambda: co.conv_igemm(x, K, K, None, 0, 0, w, None, sc, sh, 0.0, None, None, None, out, None, grid, grid[1:], N, N, taps, epilogue=epi)
     for _ in range(3):

@@ -4,6 +4,7 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
 from forge_amd import convops as co
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 dev = torch.device("cuda:0")
 rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
 g = torch.Generator().manual_seed(3)
@@ -17,8 +18,11 @@ for D in (8, 16, 32):
     for tile in ("", "A", "B", "C", "D"):
         for ks in ("", "1", "2", "4"):
             os.environ.pop("FORGE_CONV_TILE", None); os.environ.pop("FORGE_CONV_KSPLIT", None)
+            apply_environ()
             if tile: os.environ["FORGE_CONV_TILE"] = tile
+            apply_environ()
             if ks: os.environ["FORGE_CONV_KSPLIT"] = ks
+            apply_environ()
             dz = torch.full((1, D, D, D, 128), float("nan"), device=dev)
             try:
                 co.conv_igemm(gu, 64, 64, None, 0, 0, wT, None, None, None, 1.0, None, None, None, dz, None, (1, D, D, D), (D2, D2, D2), 128, 128, taps, istride=2,

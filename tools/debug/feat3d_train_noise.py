@@ -11,6 +11,7 @@ import torch  # noqa: E402
 
 import forge_oracle as fo  # noqa: E402
 from forge_amd import synthetic as syn  # noqa: E402
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 from forge_amd.encoder import Encoder3D  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -35,6 +36,7 @@ for seed in (31, 41):
             res[mode] = (out.detach().double(), {n: wr["encoder_3d." + n].grad.double() for n in names})
         else:
             os.environ["FORGE_WINOGRAD"] = mode
+            apply_environ()
             enc.zero_grad(set_to_none=True)
             got = enc.get_feat3D(img.to(dev))
             got.backward(gy.to(dev))

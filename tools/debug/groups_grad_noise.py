@@ -3,10 +3,12 @@ Jumps to ~1e-4 are single LeakyReLU arguments within rounding of zero taking the
 import copy, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from forge_amd import synthetic as syn
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 from forge_amd.fusion import ConvGRU_3D
 dev = torch.device("cuda:0")
 for seed, mode in [(sd, m) for sd in (11, 12, 13, 14, 15) for m in ("0", "1")]:
     os.environ["FORGE_WINOGRAD"] = mode
+    apply_environ()
     torch.manual_seed(seed)
     a = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).train()
     bmod = copy.deepcopy(a)

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch  # noqa: E402
 
 from forge_amd import convops as co  # noqa: E402
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("WINO_SCENES", "1"))
@@ -29,6 +30,7 @@ def timed(fn, reps=10):
 for name, C1, C2, N in (("gates", 128, 128, 256), ("state", 128, 128, 128), ("fconv", 128, 0, 128)):
     for tile in ("B", "D"):
         os.environ["FORGE_CONV_TILE"] = tile
+        apply_environ()
         # committed form
         R = B * D * (D // 2) * (D // 2)
         V1, V2 = torch.randn(16, R, C1, device=dev), (torch.randn(16, R, C2, device=dev) if C2 else None)
@@ -49,3 +51,4 @@ for name, C1, C2, N in (("gates", 128, 128, 256), ("state", 128, 128, 128), ("fc
         print("scenes %d %-6s tile %s | 2-D x 3 taps: %.3f ms (%.0f TF) | 3-D, 64 points in 4 launches: %.3f ms (%.0f TF) | extra transform traffic ~%.0f MB"
               % (B, name, tile, t2, f2 / t2 / 1e9, t3, f3 / t3 / 1e9, (64 * R3 - 16 * R) * 4 * (C1 + (C2 if name != "fconv" else 0) * 0 + N) / 1e6))
 os.environ.pop("FORGE_CONV_TILE", None)
+apply_environ()

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch  # noqa: E402
 
 from forge_amd import convops as co  # noqa: E402
+import sys as _sys, os as _os; _sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), '..')); from _variants import apply_environ  # noqa: E402,E702
 
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(13)
@@ -18,6 +19,7 @@ for (n, D, H, W, Ci, Co) in ((1, 16, 16, 16, 256, 128), (1, 16, 16, 16, 128, 256
     wp = co.pack_conv3d_weight(w.to(dev))
     for mode in ("0", "1"):
         os.environ["FORGE_WINOGRAD"] = mode
+        apply_environ()
         dx = torch.empty(n, D, H, W, Ci, device=dev)
         co.conv3_launch(dy.to(dev), Co, None, 0, wp, None, dx, (n, D, H, W), Ci, dgrad=True)
         e = dx.double().cpu() - ref

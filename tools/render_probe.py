@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """forge_render_fwd at the big-volume shapes: D_r in {64, 128}, V in {5 (bench), 28 (360-degree NVS, kubric_eval.py:166-232)} views of ONE
 volume, 128^2 rays x 64 samples. Prints ms per launch and G taps/s; RENDER_PROBE_ITERS launches each (PMC target: tools/pmc_render.sh).
-FORGE_RENDER_XCD_ORDER=0|1 (read once per process by the library) selects launch-order vs XCD-contiguous tile placement."""
+(The XCD-contiguous tile order and the wave-per-ray variant measured with this tool in round 2 - profiles/r02_render_ab.txt - are no longer in the library.)"""
 import os
 import sys
 
@@ -44,4 +44,4 @@ for Dr, V in cases:
     ms = a.elapsed_time(b) / iters
     hit = (oo > 0).float().mean().item()
     print("render D_r=%d V=%d: %.4f ms/launch  %.1f us/view  %.2f G taps/s  (opacity>0 on %.0f%% of the rays; xcd_order=%s)"
-          % (Dr, V, ms, ms * 1e3 / V, V * 128 * 128 * 64 * 17 * 8 / ms / 1e6, 100 * hit, os.environ.get("FORGE_RENDER_XCD_ORDER", "1")))
+          % (Dr, V, ms, ms * 1e3 / V, V * 128 * 128 * 64 * 17 * 8 / ms / 1e6, 100 * hit, "launch"))

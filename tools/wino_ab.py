@@ -36,8 +36,7 @@ def timed(fn, reps=10):
 
 outs = {}
 for mode in ("0", "1"):
-    os.environ["FORGE_WINOGRAD"] = mode
-    with torch.no_grad():
+    with torch.no_grad(), co.winograd(mode == "1"):
         g = GraphedCall(lambda: gru.fuse_hip(x), dev, warmup=2)
         outs[mode] = g().clone()
         ms = timed(g)
@@ -45,7 +44,6 @@ for mode in ("0", "1"):
 print("max |winograd - direct| = %.3e (output max %.3f)" % ((outs["1"] - outs["0"]).abs().max().item(), outs["0"].abs().max().item()))
 
 # per-launch times of the Winograd pieces (eager, HIP events around each launch)
-os.environ["FORGE_WINOGRAD"] = "1"
 rec = []
 
 

@@ -35,12 +35,10 @@ for name, n, D_, C1, C2, N in shapes:
     U = torch.randn(16, 3, N, C1 + C2, device=dev) * 0.02
     Mm = torch.empty(16, R, N, device=dev)
     flops = 2.0 * 16 * R * N * 3 * (C1 + C2)
-    os.environ.pop("FORGE_CONV_TILE", None)
     plan = co.wino_gemm_tile(R, N)
     line = []
     for tile in os.environ.get("SWEEP_TILES", "A,B,C,D").split(","):
-        os.environ["FORGE_CONV_TILE"] = tile
-        ms = timed(lambda: co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D_, D_ // 2, D_ // 2, N))
+        with co.force_plan(tile=tile):
+            ms = timed(lambda: co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D_, D_ // 2, D_ // 2, N))
         line.append("%s %.3f ms %5.1f TF" % (tile, ms, flops / ms / 1e9))
-    os.environ.pop("FORGE_CONV_TILE", None)
     print("scenes %d  %-36s plan %s | %s" % (B, name, plan, " | ".join(line)))

@@ -1,9 +1,12 @@
 """Single-node data parallelism: one process per MI355X, torch.distributed over RCCL (backend
-"nccl" IS RCCL on PyTorch-ROCm) — the only parallelism the reference has (SURVEY.md §2.2:
+"nccl" IS RCCL on PyTorch-ROCm) - the only parallelism the reference has (SURVEY.md 2.2:
 DDP + DistributedSampler, kubric_train_pose_3D.py:74,124,130; eval sharding by batch index,
-kubric_eval.py:56). Scenes are independent, so the data path needs NO collective: scenes are
-sharded across ranks and only scalar metrics (losses / SSE / counts / time) are all-reduced.
-Gradient all-reduce in training is torch DDP's bucketed RCCL all-reduce, unchanged.
+kubric_eval.py:56). Scenes are independent, so the default data path needs NO collective: scenes are
+sharded across ranks and only scalar metrics (losses / SSE / counts / time) are all-reduced;
+gradient all-reduce in training is torch DDP's bucketed RCCL all-reduce, unchanged.
+Second half of the file: per-RAY sharding of one batch (BASELINE configs[4]) - differentiable row-band
+ray-march with an all_gather forward and an all-reduce / reduce-to-owner of d(volume) backward - and the
+cross-rank BatchNorm statistics exchange used by forge_amd.fusion's HIP SyncBatchNorm.
 """
 import os
 import sys
@@ -97,22 +100,143 @@ def band_cameras(cam, h0):
     return out
 
 
-def render_rays_sharded(feat, dens, cam, view2vol, Hr, Wr, S, zmin, zmax, half, want_depth=False, render_fn=None, group=None):
-    """Ray-sharded version of ops.render_rays (inference). Every rank passes the SAME arguments; returns the full-size outputs on
-    every rank. `render_fn` defaults to the HIP op (tests inject the CPU oracle)."""
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
+def _group_info(group=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def _gather_rows(band, world, group):
+    """[V, C, band, Wr] per rank -> [V, C, world * band, Wr] on every rank (ONE all_gather; rank r's rows land at [r band, (r+1) band))."""
+    band = band.contiguous()
+    parts = [torch.empty_like(band) for _ in range(world)]
+    dist.all_gather(parts, band, group=group)
+    return torch.cat(parts, dim=2)
+
+
+def _dense_view(g):
+    """A contiguous view of g's memory for the collective (channels-last volumes are dense but not `is_contiguous()`); a copy otherwise."""
+    if g.is_contiguous():
+        return g
+    if g.dim() == 5 and g.permute(0, 2, 3, 4, 1).is_contiguous():
+        return g.permute(0, 2, 3, 4, 1)
+    return g.contiguous()
+
+
+class _RenderRaysSharded(torch.autograd.Function):
+    """Differentiable ray-sharded render (BASELINE configs[4]).
+      forward   every rank marches its band of image rows of every view (band_cameras: principal point shifted by the band's first
+                row, so the unchanged ray-march kernel produces exactly those rows); ONE all_gather per output assembles the images.
+      backward  the rank takes the rows of the incoming image gradients that belong to ITS band, runs the ray-march backward
+                (forge_render_bwd) on them -> partial d(features), d(density) [the size of the volume: 17.8 MB at 64^3, 142.6 MB at
+                128^3] and d(cameras); `reduce="all"`: the partials are summed over ranks (all_reduce - every rank continues the
+                backward through its replica of fusion / encoder with the full gradient); `reduce="none"`: the partials are returned
+                as they are (the caller's differentiable broadcast_from_owner reduces them to the volume's owner instead).
+    The band render runs under a private autograd graph (enable_grad on detached leaves), so any `render_fn` with ops.render_rays'
+    signature works - the HIP op in the product, the CPU oracle in the gloo tests."""
+
+    @staticmethod
+    def forward(ctx, feat, dens, cam, view2vol, render_fn, cfg, group, reduce):
+        Hr, Wr, S, zmin, zmax, half, want_depth = cfg
+        rank, world = _group_info(group)
+        h0, h1 = ray_band(Hr, rank, world)
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]]
+        with torch.enable_grad():
+            f = feat.detach().requires_grad_(need[0])
+            d = dens.detach().requires_grad_(need[1])
+            c = band_cameras(cam.detach(), h0).requires_grad_(need[2])      # cy' = cy - h0: d/d cam = d/d band camera
+            outs = render_fn(f, d, c, view2vol, h1 - h0, Wr, S, zmin, zmax, half, want_depth)
+        ctx.local = (f, d, c, outs) if any(need) else None
+        ctx.meta = (h0, h1, world, group, reduce, need)
+        full = tuple(_gather_rows(o.detach(), world, group) if world > 1 else o.detach() for o in outs)
+        return full
+
+    @staticmethod
+    def backward(ctx, *grads):
+        h0, h1, world, group, reduce, need = ctx.meta
+        f, d, c, outs = ctx.local
+        gb = [torch.zeros_like(o) if g is None else g[:, :, h0:h1].contiguous() for g, o in zip(grads, outs)]
+        leaves = [t for t, n in zip((f, d, c), need) if n]
+        got = iter(torch.autograd.grad(outs, leaves, gb, allow_unused=True))
+        res = []
+        for t, n in zip((f, d, c), need):
+            g = next(got) if n else None
+            res.append(torch.zeros_like(t) if (n and g is None) else g)
+        ctx.local = None
+        if world > 1 and reduce == "all":
+            views = [(_dense_view(g), g) for g in res if g is not None]
+            work = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v, _ in views]
+            for w in work:
+                w.wait()
+            for v, g in views:
+                if v.data_ptr() != g.data_ptr():
+                    g.copy_(v)                                   # _dense_view had to copy (same shape): write the sum back
+        return res[0], res[1], res[2], None, None, None, None, None
+
+
+def render_rays_sharded(feat, dens, cam, view2vol, Hr, Wr, S, zmin, zmax, half, want_depth=False, render_fn=None, group=None, reduce="all"):
+    """Ray-sharded ops.render_rays, differentiable. Every rank passes the SAME arguments (replicated volume and cameras) and receives the
+    full-size outputs; gradients w.r.t. feat / dens / cam are the single-process ones on every rank (reduce="all") or this rank's band
+    partials (reduce="none", for broadcast_from_owner). `render_fn` defaults to the HIP op (tests inject the CPU oracle)."""
     if render_fn is None:
         from . import ops
         render_fn = ops.render_rays
-    h0, h1 = ray_band(Hr, rank, world)
-    outs = render_fn(feat, dens, band_cameras(cam, h0), view2vol, h1 - h0, Wr, S, zmin, zmax, half, want_depth)
+    if reduce not in ("all", "none"):
+        raise ValueError("reduce must be 'all' or 'none'")
+    cfg = (int(Hr), int(Wr), int(S), float(zmin), float(zmax), tuple(float(h) for h in half), bool(want_depth))
+    return _RenderRaysSharded.apply(feat, dens, cam, view2vol, render_fn, cfg, group, reduce)
+
+
+class _BroadcastFromOwner(torch.autograd.Function):
+    """Differentiable broadcast of the owner's tensors ("encoder + fusion for a scene run on its owner rank, fused volume
+    broadcast once ... backward: each rank's d(volume) partials reduce to the owner"). Forward: rank `src`'s tensors reach every rank;
+    backward: the ranks' gradients are summed onto `src` (dist.reduce), the other ranks get zeros (their inputs were placeholders)."""
+
+    @staticmethod
+    def forward(ctx, src, group, *tensors):
+        ctx.src, ctx.group = src, group
+        rank, world = _group_info(group)
+        outs = []
+        for t in tensors:
+            o = t.detach().clone().contiguous()
+            if world > 1:
+                dist.broadcast(o, src=src, group=group)
+            outs.append(o)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        rank, world = _group_info(ctx.group)
+        res = []
+        for g in grads:
+            if g is None:
+                res.append(None)
+                continue
+            g = g.contiguous().clone()
+            if world > 1:
+                dist.reduce(g, dst=ctx.src, op=dist.ReduceOp.SUM, group=ctx.group)
+                if rank != ctx.src:
+                    g.zero_()
+            res.append(g)
+        return (None, None) + tuple(res)
+
+
+def broadcast_from_owner(tensors, src, group=None):
+    """tensors (tuple) of the owner rank `src` -> the same values on every rank, differentiable (gradients are reduced to the owner).
+    Non-owners pass placeholders of the same shape / dtype / device."""
+    return _BroadcastFromOwner.apply(int(src), group, *tensors)
+
+
+def broadcast_sample(sample, src=0, group=None):
+    """Ray-sharded training renders ONE batch on all ranks: rank `src`'s sample dict (tensors of equal shapes on every rank) is broadcast."""
+    rank, world = _group_info(group)
     if world == 1:
-        return outs
-    full = []
-    for o in outs:                                             # [V, C, band, Wr] -> gather along the row axis
-        o = o.contiguous()
-        parts = [torch.empty_like(o) for _ in range(world)]
-        dist.all_gather(parts, o, group=group)
-        full.append(torch.cat(parts, dim=2))
-    return tuple(full)
+        return sample
+    out = {}
+    for k in sorted(sample):
+        v = sample[k]
+        if torch.is_tensor(v):
+            v = v.contiguous().clone()
+            dist.broadcast(v, src=src, group=group)
+        out[k] = v
+    return out

@@ -193,10 +193,25 @@ def adjust_lr(config, optimizer, iter_num, adjust_iter_num):
     return lr
 
 
+def enable_ray_sharding(model, on=True, group=None, reduce="all"):
+    """BASELINE configs[4] ("8 GPUs with per-ray sharding"): every rank processes the SAME batch, the ray-march of every rendered view
+    is split into row bands over the ranks of `group` (forge_amd/dist.py::render_rays_sharded: all_gather of the maps forward, all-reduce of
+    d(volume) / d(cameras) backward), encoder / pose networks / fusion / conv_rgb run replicated. Works on the bare model or a DDP wrapper
+    (DDP then averages identical gradients, which also keeps the replicas bit-identical despite atomics-ordered weight gradients)."""
+    m = model.module if hasattr(model, "module") else model
+    m.render.ray_shard, m.render.ray_shard_group, m.render.ray_shard_reduce = bool(on), group, reduce
+    return model
+
+
 def train_step(config, sample, dataset, model, optimizer, device, loss_func=compute_reconstruction_loss, epoch=0, batch_idx=0,
                perceptual_loss=None):
-    """One iteration of scripts/kubric_trainer.py:47-59 (without the logging): loss, backward, clip, optimizer step."""
+    """One iteration of scripts/kubric_trainer.py:47-59 (without the logging): loss, backward, clip, optimizer step. With ray sharding
+    enabled (enable_ray_sharding) rank 0's sample is broadcast first, so that all ranks render the same batch."""
     max_norm = 5.0 if config.dataset.name == "omniobject3d" else 10.0
+    bare = model.module if hasattr(model, "module") else model
+    if getattr(getattr(bare, "render", None), "ray_shard", False):
+        from . import dist as fdist
+        sample = fdist.broadcast_sample({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}, src=0, group=bare.render.ray_shard_group)
     accumulation = getattr(config.train, "accumulation_step", 1)
     loss, losses, imgs, masks = loss_func(config, epoch, sample, dataset, model, {}, device, perceptual_loss)
     (loss / accumulation).backward()

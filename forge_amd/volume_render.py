@@ -80,6 +80,22 @@ class VolRender(co.PackedModule):
             nn.Conv2d(8, 3, kernel_size=self.k_size, stride=1, padding=self.pad_size),
         )
 
+    # ray sharding (off by default): plain attributes, not parameters / buffers - the state_dict stays the reference's
+    ray_shard = False              # True: the ray-march of every forward is split into row bands over the ranks of ray_shard_group
+    ray_shard_group = None         # torch.distributed process group (None = the default group)
+    ray_shard_reduce = "all"       # "all": d(volume) all-reduced (replicated encoder / fusion); "none": partials (dist.broadcast_from_owner)
+
+    def _ray_shard_world(self, Hr):
+        if not self.ray_shard:
+            return 1
+        import torch.distributed as tdist
+        if not (tdist.is_available() and tdist.is_initialized()):
+            return 1
+        world = tdist.get_world_size(self.ray_shard_group)
+        if world > 1 and Hr % world:
+            raise ValueError("VolRender.ray_shard: %d image rows are not divisible by %d ranks" % (Hr, world))
+        return world
+
     @staticmethod
     def _half_res_intrinsics(K):
         K = K.to(torch.float32) / 2.0          # copy; volume_render.py:50-51 without the in-place write
@@ -132,8 +148,16 @@ class VolRender(co.PackedModule):
         Hr = Wr = self.img_size // 2
         vox = self.volume_physical_size / D                       # :58 single_voxel_size
         half = (0.5 * (W - 1) * vox, 0.5 * (H - 1) * vox, 0.5 * (D - 1) * vox)
-        outs = ops.render_rays(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray,
-                               self.min_depth, self.max_depth, half, want_depth=render_depth)
+        shard_world = self._ray_shard_world(Hr)
+        if shard_world > 1:
+            # BASELINE configs[4] "per-ray sharding": this rank marches its band of image rows of every view, one all_gather assembles the
+            # maps; backward = band backward + all-reduce (or reduce-to-owner) of d(volume) / d(cameras)  (forge_amd/dist.py)
+            from . import dist as fdist
+            outs = fdist.render_rays_sharded(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray, self.min_depth, self.max_depth, half,
+                                             want_depth=render_depth, group=self.ray_shard_group, reduce=self.ray_shard_reduce)
+        else:
+            outs = ops.render_rays(feature_3d, density_3d, cam, view2vol, Hr, Wr, self.n_pts_per_ray,
+                                   self.min_depth, self.max_depth, half, want_depth=render_depth)
         if hip_inference(self, outs[0]):
             rendered_imgs = self._conv_rgb_hip(outs[0])
         elif frozen_eval(self, outs[0]):

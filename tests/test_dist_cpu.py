@@ -157,3 +157,96 @@ def test_logged_losses_are_all_reduced_world2():
         assert p.exitcode == 0
     for r in (0, 1):
         assert res[r] == {"recon_img": pytest.approx(1.5), "recon_mask": pytest.approx(15.0)}
+
+
+def _oracle_render_fn():
+    import forge_oracle as fo
+
+    def oracle_fn(f, d, c, v2v_, Hr, Wr, S, zmin, zmax, half, want_depth):      # CPU stand-in with the ops.render_rays signature, differentiable
+        z, o = torch.zeros_like(c[:, 0]), torch.ones_like(c[:, 0])
+        K = torch.stack([c[:, 12], z, c[:, 14], z, c[:, 13], c[:, 15], z, z, o], dim=1).reshape(-1, 3, 3)
+        r = fo.render_rays(f[v2v_.long()], d[v2v_.long()], c[:, :9].reshape(-1, 3, 3), c[:, 9:12], K, Hr, Wr, S, zmin, zmax, 1.0, want_depth)
+        C = f.shape[1]
+        outs = [r[..., :C].permute(0, 3, 1, 2), r[..., C:C + 1].permute(0, 3, 1, 2)]
+        if want_depth:
+            outs.append(r[..., C + 1:].permute(0, 3, 1, 2))
+        return tuple(outs)
+    return oracle_fn
+
+
+def _ray_case():
+    import forge_oracle as fo
+    from forge_amd import synthetic as syn
+    feat, dens = syn.blob_volumes(1, 12, 4, seed=2)
+    _, extr, _ = syn.orbit_cameras(3, 1.5, 10.0)
+    Kh = fo.halve_intrinsics(syn.intrinsics(32)[None].repeat(3, 1, 1))
+    cam = torch.cat([extr[:, :3, :3].reshape(3, 9), extr[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1)
+    g = torch.Generator().manual_seed(3)
+    tg = [torch.randn(3, 4, 16, 16, generator=g), torch.randn(3, 1, 16, 16, generator=g), torch.randn(3, 1, 16, 16, generator=g)]
+    return feat, dens, cam, torch.zeros(3, dtype=torch.int32), fo.grid_half_extent(12, 1.0), tg
+
+
+def _ray_bwd_worker(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from forge_amd import dist as fd
+    fd.init(backend="gloo")
+    feat, dens, cam, v2v, h, tg = _ray_case()
+    fn = _oracle_render_fn()
+    cam = cam.clone().requires_grad_(True)
+    if mode == "all":                        # replicated volume: every rank ends up with the single-process gradients
+        feat, dens = feat.clone().requires_grad_(True), dens.clone().requires_grad_(True)
+        fin, din = feat, dens
+    else:                                    # owner mode: rank 0 owns the (differentiable) volume, the others hold placeholders
+        p = torch.full((1,), 0.7, requires_grad=True)
+        if rank == 0:
+            fin0, din0 = feat * p, dens * (2.0 * p)
+        else:
+            fin0, din0 = torch.zeros_like(feat) * p, torch.zeros_like(dens) * p
+        fin, din = fd.broadcast_from_owner((fin0, din0), src=0)
+    outs = fd.render_rays_sharded(fin, din, cam, v2v, 16, 16, 24, 0.5, 2.0, (h, h, h), True, render_fn=fn, reduce=mode)
+    loss = sum((o * t).sum() for o, t in zip(outs, tg))
+    loss.backward()
+    if mode == "all":
+        res = (float(loss), feat.grad.numpy(), dens.grad.numpy(), cam.grad.numpy())
+    else:
+        res = (float(loss), p.grad.numpy(), cam.grad.numpy())
+    q.put((rank, res))
+    fd.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["all", "none"])
+def test_ray_sharded_render_backward_world2(mode):
+    """BASELINE configs[4] is a FINE-TUNE: the ray-sharded render is differentiable. Two ranks (gloo, the CPU oracle injected as the band
+    renderer): loss and gradients of the volume, the density and the 16 camera parameters equal single-process autograd through the
+    full render - reduce="all": on EVERY rank (partials all-reduced); reduce="none" + broadcast_from_owner: the volume's owner (rank 0)
+    receives the full gradient of its upstream parameter, the other rank zero; camera partials sum to the full camera gradient."""
+    import forge_oracle  # noqa: F401  (conftest put oracle/ on the path)
+    feat, dens, cam, v2v, h, tg = _ray_case()
+    fn = _oracle_render_fn()
+    f1, d1, c1 = feat.clone().requires_grad_(True), dens.clone().requires_grad_(True), cam.clone().requires_grad_(True)
+    p1 = torch.full((1,), 0.7, requires_grad=True)
+    fin, din = (f1, d1) if mode == "all" else (feat * p1, dens * (2.0 * p1))
+    ref = sum((o * t).sum() for o, t in zip(fn(fin, din, c1, v2v, 16, 16, 24, 0.5, 2.0, (h, h, h), True), tg))
+    ref.backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ray_bwd_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    close = lambda a, b: float(abs(torch.from_numpy(a) - b).max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    for r in (0, 1):
+        assert abs(res[r][0] - float(ref.detach())) < 1e-4 * max(1.0, abs(float(ref.detach())))
+    if mode == "all":
+        for r in (0, 1):
+            assert close(res[r][1], f1.grad) and close(res[r][2], d1.grad) and close(res[r][3], c1.grad), r
+    else:
+        assert close(res[0][1], p1.grad) and float(abs(res[1][1]).max()) == 0.0
+        assert close(res[0][2] + res[1][2], c1.grad)

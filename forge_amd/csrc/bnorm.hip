@@ -29,6 +29,8 @@ struct BnArgs {
     int nblk;                              // blocks (gridDim.x) of the reduction kernel = number of partials
     float eps, slope;
     long long M; int C;
+    long long Mtot;                        // rows behind the totals the apply kernels normalise with (= M, or the all-rank count under SyncBatchNorm)
+    const double* cnt;                     // non-null: that count read from device memory (the all-reduced row count: no host round trip)
 };
 
 constexpr int BN_THREADS = 256;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const BnArgs a,
     if (sl != 0 || c >= a.C) return;
     s0 = red[0][cl]; s1 = red[1][cl];
     a.ws[c] = s0; a.ws[a.C + c] = s1;                // safe: every partial of this channel has been read (barriers above), other channels untouched
+    if (bwd == 2) return;                             // SyncBatchNorm forward: the local totals only (summed over ranks by the caller's all-reduce)
     if (bwd) {
         if (a.dbeta) a.dbeta[c] = (float)s0;
         if (a.dgamma) a.dgamma[c] = (float)s1;
@@ -91,6 +94,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const BnArgs a,
     a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
     if (a.running_mean) {
         const double unbiased = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+}
+
+// SyncBatchNorm forward, after the all-reduce: mean / invstd / running statistics from the all-rank totals (sum x, sum x^2 over Mtot rows).
+__global__ __launch_bounds__(BN_THREADS) void bn_from_totals_kernel(const BnArgs a, const double* __restrict__ totals) {
+    const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (c >= a.C) return;
+    const double n = a.cnt ? *a.cnt : (double)a.Mtot, m = totals[c] / n, var = fmax(totals[a.C + c] / n - m * m, 0.0);
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
         a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
         a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
     }
@@ -192,8 +209,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_bwd_kernel(const BnArgs a
     for (int k = 0; k < 4; ++k) {
         const double db = a.ws[c + k], dg = a.ws[a.C + c + k];
         k1[k] = sc[k];                                  // gamma * invstd
-        k2[k] = (float)(db / (double)a.M);              // mean(g)
-        k3[k] = (float)(dg / (double)a.M);              // mean(g * xhat)
+        const double n = a.cnt ? *a.cnt : (double)a.Mtot;
+        k2[k] = (float)(db / n);                        // mean(g)      over all rows the statistics were taken over (all ranks under SyncBN)
+        k3[k] = (float)(dg / n);                        // mean(g * xhat)
     }
     for (long long r = (long long)blockIdx.x * RG + rg; r < a.M; r += (long long)gridDim.x * RG) {
         const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
@@ -242,7 +260,7 @@ extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, c
     BnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
-    a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.ws = ws; a.eps = eps; a.slope = slope; a.M = M; a.C = C;
+    a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.ws = ws; a.eps = eps; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr = bn_grid(M, C, true);
     a.nblk = (int)gr.x;
@@ -261,7 +279,7 @@ extern "C" int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int
     BnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.gamma = gamma; a.beta = beta;
-    a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C;
+    a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr = bn_grid(M, C, true);
     a.nblk = (int)gr.x;
@@ -269,5 +287,79 @@ extern "C" int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 1);
     hipLaunchKernelGGL(bn_apply_bwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
     FORGE_LAUNCH_CHECK("forge_bn_train_bwd");
+    return 0;
+}
+
+// ---- SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, kubric_train_pose_3D.py:119): the same kernels with ONE all-reduce of
+// 2 C (+1) doubles between the reduction and the apply step, issued by the caller (forge_amd/fusion.py over torch.distributed = RCCL):
+//   forward   forge_bn_sync_stats       -> ws[0 .. 2C) = this rank's (sum x, sum x^2)           [all-reduce SUM together with the row count]
+//             forge_bn_sync_fwd_apply   mean / invstd / running statistics from the all-rank totals, y = lrelu(x scale + shift)
+//   backward  forge_bn_sync_bwd_reduce  -> ws[0 .. 2C) = this rank's (sum g, sum g xhat); dgamma / dbeta = the LOCAL sums (as torch's
+//                                          SyncBatchNorm: DDP averages parameter gradients afterwards)   [all-reduce SUM]
+//             forge_bn_sync_bwd_apply   dx = gamma invstd (g - mean_all(g) - xhat mean_all(g xhat))
+extern "C" int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_sync_stats", x, ldx, M, C, ws)) return rc;
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.ws = ws; a.M = M; a.C = C; a.Mtot = M;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gr = bn_grid(M, C, true);
+    a.nblk = (int)gr.x;
+    hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 2);
+    FORGE_LAUNCH_CHECK("forge_bn_sync_stats");
+    return 0;
+}
+
+extern "C" int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                                       float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
+                                       long long M_total, long long M, int C, forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_sync_fwd_apply", x, ldx, M, C, totals)) return rc;
+    FORGE_REQUIRE(y && mean && invstd && ldy >= C && ldy % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr) && (M_total == 0 || M_total >= M), FORGE_EINVAL,
+                  "forge_bn_sync_fwd_apply: bad output / running-statistics arguments or 0 < M_total < M");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
+    a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps; a.slope = slope; a.M = M; a.C = C; a.Mtot = M_total;
+    a.cnt = M_total == 0 ? totals + 2 * C : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_from_totals_kernel, dim3((unsigned)((C + BN_THREADS - 1) / BN_THREADS)), dim3(BN_THREADS), 0, st, a, totals);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
+    FORGE_LAUNCH_CHECK("forge_bn_sync_fwd_apply");
+    return 0;
+}
+
+extern "C" int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                                        const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C,
+                                        forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_sync_bwd_reduce", x, ldx, M, C, ws)) return rc;
+    FORGE_REQUIRE(dy && mean && invstd && lddy >= C && lddy % 4 == 0, FORGE_EINVAL, "forge_bn_sync_bwd_reduce: bad arguments");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean);
+    a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gr = bn_grid(M, C, true);
+    a.nblk = (int)gr.x;
+    hipLaunchKernelGGL(bn_reduce_bwd_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 1);
+    FORGE_LAUNCH_CHECK("forge_bn_sync_bwd_reduce");
+    return 0;
+}
+
+extern "C" int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                                       const float* invstd, float slope, float* dx, int lddx, const double* totals, long long M_total, long long M, int C,
+                                       forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_sync_bwd_apply", x, ldx, M, C, totals)) return rc;
+    FORGE_REQUIRE(dy && dx && mean && invstd && lddy >= C && lddy % 4 == 0 && lddx >= C && lddx % 4 == 0 && (M_total == 0 || M_total >= M), FORGE_EINVAL,
+                  "forge_bn_sync_bwd_apply: bad arguments");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.gamma = gamma; a.beta = beta;
+    a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.ws = const_cast<double*>(totals); a.slope = slope; a.M = M; a.C = C;
+    a.Mtot = M_total;
+    a.cnt = M_total == 0 ? totals + 2 * C : nullptr;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, (hipStream_t)stream, a);
+    FORGE_LAUNCH_CHECK("forge_bn_sync_bwd_apply");
     return 0;
 }

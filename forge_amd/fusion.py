@@ -73,19 +73,81 @@ class _BNTrainRows(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+class _SyncBNTrainRows(torch.autograd.Function):
+    """Train-mode SyncBatchNorm + LeakyReLU(slope) on channels-last rows [M, C]: the kernels of _BNTrainRows with ONE all-reduce of the
+    float64 (sum x, sum x^2, row count) forward and of (sum g, sum g xhat) backward over `group` (RCCL over xGMI; torch's SyncBatchNorm
+    all-gathers per-rank mean / invstd / count instead). dgamma / dbeta are this rank's sums, as torch's: DDP averages them."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, group):
+        import torch.distributed as tdist
+        M, C = x.shape
+        dev = x.device
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_sync_stats(p(x), x.stride(0), p(ws), M, C, st()), "forge_bn_sync_stats")
+        tot = ws[:2 * C + 1]
+        tot[2 * C:].fill_(float(M))                                 # the row count rides on the same all-reduce and stays on the device
+        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=group)
+        m_total = 0                                                 # = "read totals[2C]"
+        y = torch.empty(M, C, dtype=torch.float32, device=dev)
+        mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        _lib.check(L.forge_bn_sync_fwd_apply(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
+                                             p(running_mean), p(running_var), float(momentum), p(tot), m_total, M, C, st()), "forge_bn_sync_fwd_apply")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, tot[2 * C:].clone())
+        ctx.slope, ctx.group = float(slope), group
+        return y
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dy):
+        import torch.distributed as tdist
+        x, gamma, beta, mean, invstd, count = ctx.saved_tensors
+        M, C = x.shape
+        dev = x.device
+        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= C) else dy.contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_sync_bwd_reduce(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dg), p(db), p(ws),
+                                              M, C, st()), "forge_bn_sync_bwd_reduce")
+        tot = ws[:2 * C]
+        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=ctx.group)
+        ws[2 * C:2 * C + 1].copy_(count)                            # the forward's all-rank row count, read by the kernel at totals[2C]
+        _lib.check(L.forge_bn_sync_bwd_apply(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C, p(ws),
+                                             0, M, C, st()), "forge_bn_sync_bwd_apply")
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def _sync_world(bn):
+    """World size of the SyncBatchNorm module's process group (1: not initialised / single process -> plain batch statistics)."""
+    import torch.distributed as tdist
+    if not (isinstance(bn, nn.SyncBatchNorm) and tdist.is_available() and tdist.is_initialized()):
+        return 1
+    return tdist.get_world_size(bn.process_group)
+
+
 def bn_act_rows(bn, rows, slope=1.0):
-    """BatchNorm module `bn` + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C]. Train mode with per-process batch
-    statistics runs the HIP kernels of csrc/bnorm.hip; SyncBatchNorm (cross-rank statistics), eval mode under autograd and a cumulative-average
-    momentum keep the torch module (on an NC... view of the same memory) followed by the activation."""
+    """BatchNorm module `bn` + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C]. Train mode runs the HIP kernels of
+    csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process group for nn.SyncBatchNorm (one
+    all-reduce of 2C+1 float64 forward, 2C backward: _SyncBNTrainRows); eval mode under autograd and a cumulative-average momentum keep the
+    torch module (on an NC... view of the same memory) followed by the activation."""
     C = rows.shape[-1]
-    hip = (bn.training and not isinstance(bn, nn.SyncBatchNorm) and rows.is_cuda and rows.dtype == torch.float32 and C % 4 == 0
+    hip = (bn.training and rows.is_cuda and rows.dtype == torch.float32 and C % 4 == 0
            and (bn.momentum is not None or not bn.track_running_stats))
     if hip:
         x = rows.reshape(-1, C)
         x = x if (x.stride(1) == 1 and x.stride(0) >= C and x.stride(0) % 4 == 0) else x.contiguous()
         track = bn.track_running_stats and bn.running_mean is not None
-        y = _BNTrainRows.apply(x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                               bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope)
+        args = (x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
+                bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope)
+        if _sync_world(bn) > 1:                          # the reference's training configuration: statistics over all ranks, one all-reduce each way
+            y = _SyncBNTrainRows.apply(*args, bn.process_group)
+        else:
+            y = _BNTrainRows.apply(*args)
         if track and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         return y.reshape(rows.shape)

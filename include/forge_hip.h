@@ -292,6 +292,25 @@ int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float*
 int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                        const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
                        forge_stream_t stream);
+/* SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, kubric_train_pose_3D.py:119, kubric_train_joint.py:136): the same kernels
+ * with ONE all-reduce (SUM) of 2 C doubles (+ the row count) between the reduction and the apply step, issued by the caller (RCCL):
+ *   forge_bn_sync_stats       ws[0 .. 2C) = this rank's (sum x, sum x^2) over its M rows          -> all-reduce -> totals, M_total
+ *   forge_bn_sync_fwd_apply   mean / invstd (written) and running statistics (updated, unbiased over M_total) from the totals; y as above
+ *   forge_bn_sync_bwd_reduce  ws[0 .. 2C) = this rank's (sum g, sum g xhat); dgamma / dbeta = those LOCAL sums (torch's SyncBatchNorm
+ *                             does the same: DDP averages parameter gradients afterwards)           -> all-reduce -> totals
+ *   forge_bn_sync_bwd_apply   dx = gamma invstd (g - totals_g / M_total - xhat totals_gx / M_total)
+ * ws as for forge_bn_train_fwd (forge_bn_ws_doubles(C) doubles); totals may alias ws. M_total = 0: the all-rank row count is read from
+ * device memory at totals[2 C] (a double, all-reduced with the sums: no host round trip per layer). With M_total = M and no all-reduce the four calls
+ * reproduce forge_bn_train_fwd / _bwd bit for bit. */
+int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, forge_stream_t stream);
+int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
+                            float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
+                            long long M_total, long long M, int C, forge_stream_t stream);
+int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                             const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C, forge_stream_t stream);
+int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
+                            const float* invstd, float slope, float* dx, int lddx, const double* totals, long long M_total, long long M, int C,
+                            forge_stream_t stream);
 
 /* Backward of forge_conv_igemm's epilogue 1 (folded eval-BatchNorm + LeakyReLU / ReLU) for frozen-weight optimisation loops (pose
  * refinement, kubric_eval.py:412-530): dx[m][c] = dy[m][c] * scale[c] * (y[m][c] > 0 ? 1 : slope), y = the forward OUTPUT (its sign

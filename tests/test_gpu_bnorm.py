@@ -43,11 +43,15 @@ def test_bn_train_forward_backward_and_running_stats(shape, slope):
     assert int(hb.num_batches_tracked) == 1
 
 
-def test_bn_sync_and_eval_keep_the_torch_module():
-    """SyncBatchNorm (cross-rank statistics) and eval mode are not taken by the HIP kernels: same result as the module itself."""
+def test_bn_eval_keeps_the_torch_module_and_single_process_syncbn_runs_hip():
+    """Eval mode is not taken by the HIP kernels (same result as the module itself); a SyncBatchNorm module in a single process (no
+    process group) normalises with its own batch statistics on the HIP kernels, exactly like nn.BatchNorm3d."""
     from forge_amd.fusion import bn_act_rows
     dev = torch.device("cuda:0")
     x = torch.randn(2, 4, 4, 4, 32, device=dev)
     bn = nn.BatchNorm3d(32).to(dev).eval()
     ref = torch.nn.functional.leaky_relu(bn(x.permute(0, 4, 1, 2, 3)).permute(0, 2, 3, 4, 1), 0.01)
     assert torch.equal(bn_act_rows(bn, x, 0.01), ref)
+    plain, sync = nn.BatchNorm3d(32).to(dev).train(), nn.SyncBatchNorm(32).to(dev).train()
+    assert torch.equal(bn_act_rows(sync, x, 0.01), bn_act_rows(plain, x, 0.01))
+    assert torch.equal(sync.running_var, plain.running_var)

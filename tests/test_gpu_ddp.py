@@ -62,15 +62,22 @@ def _worker(rank, world, port, q, sync_bn=False):
     fd.init()                                       # 2 ranks on 1 GPU -> gloo, both on cuda:0
     dev = torch.device("cuda", torch.cuda.current_device())
     _, model = _build(dev, batch_stats=sync_bn)
+    calls = [0]
     if sync_bn:                                     # the reference's configuration (kubric_train_pose_3D.py:119-124): statistics over all ranks
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        orig_fwd = torch.nn.SyncBatchNorm.forward
+
+        def counted(self, inp):                     # torch's own SyncBatchNorm kernels must not run: the HIP path takes every layer
+            calls[0] += 1
+            return orig_fwd(self, inp)
+        torch.nn.SyncBatchNorm.forward = counted
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
     loss = _loss(ddp, _sample([100 + rank], dev), dev)
     loss.backward()
     torch.cuda.synchronize()
     named = dict(model.named_parameters())
     out = {k: named[k].grad.detach().cpu().numpy() for k in KEYS}      # numpy: pickled by value (tensors travel as fds of a process that may be gone)
-    q.put((rank, float(loss.detach()), out))
+    q.put((rank, float(loss.detach()), out, calls[0]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -102,6 +109,7 @@ def test_ddp_two_ranks_equal_one_process_batch_of_two(sync_bn):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert res[0][3] == 0 and res[1][3] == 0, "torch.nn.SyncBatchNorm.forward ran %s times: the HIP SyncBatchNorm path was bypassed" % (res[0][3],)
     # every rank holds the same (averaged) gradients
     for k in KEYS:
         assert (res[0][2][k] == res[1][2][k]).all(), k
@@ -339,3 +347,59 @@ def test_joint_finetune_step_ray_sharded_two_ranks_equal_one_process():
         for k, ref in ref_g.items():
             rel = float(np.linalg.norm((g[k] - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-20))
             assert rel <= 2e-4, (r, k, rel)
+
+
+def _syncbn_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from forge_amd import dist as fd
+    from forge_amd.fusion import bn_act_rows
+    fd.init()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x, dy, w, b = _syncbn_case()
+    rows = slice(0, 5) if rank == 0 else slice(5, 8)                       # UNEQUAL shards: 5 and 3 of the 8 batch elements
+    bn = torch.nn.SyncBatchNorm(48).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(w)
+        bn.bias.copy_(b)
+    xr = x[rows].to(dev).requires_grad_(True)
+    y = bn_act_rows(bn, xr, 0.01)
+    y.backward(dy[rows].to(dev))
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in dict(y=y, dx=xr.grad, dw=bn.weight.grad, db=bn.bias.grad, rm=bn.running_mean,
+                                                              rv=bn.running_var).items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _syncbn_case():
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(8, 6, 6, 6, 48, generator=g) * 1.7 + 0.4
+    return x, torch.randn(8, 6, 6, 6, 48, generator=g), torch.rand(48, generator=g) + 0.5, torch.randn(48, generator=g)
+
+
+def test_hip_sync_batchnorm_two_ranks_equal_one_process_batch():
+    """HIP SyncBatchNorm - bn_stats partials (float64) -> ONE all-reduce -> apply; backward likewise. Two ranks with UNEQUAL
+    shards (5 + 3 batch elements) == one process running train-mode BatchNorm over all 8: outputs, input gradients and running statistics
+    to 1e-6, per-rank weight / bias gradients summing to the single-process ones (DDP averages them afterwards, as with torch's module)."""
+    import numpy as np
+    from forge_amd.fusion import bn_act_rows
+    res = _spawn2(_syncbn_worker, timeout=240)
+    dev = torch.device("cuda:0")
+    x, dy, w, b = _syncbn_case()
+    bn = torch.nn.BatchNorm3d(48).to(dev).train()
+    with torch.no_grad():
+        bn.weight.copy_(w)
+        bn.bias.copy_(b)
+    xr = x.to(dev).requires_grad_(True)
+    y = bn_act_rows(bn, xr, 0.01)
+    y.backward(dy.to(dev))
+    cat = lambda k: np.concatenate([res[0][k], res[1][k]], axis=0)
+    assert np.abs(cat("y") - y.detach().cpu().numpy()).max() < 1e-6 * max(1.0, float(y.abs().max()))
+    assert np.abs(cat("dx") - xr.grad.cpu().numpy()).max() < 1e-6 * max(1.0, float(xr.grad.abs().max()))
+    for k, ref in (("dw", bn.weight.grad), ("db", bn.bias.grad)):
+        assert np.abs(res[0][k] + res[1][k] - ref.cpu().numpy()).max() < 2e-6 * max(1.0, float(ref.abs().max())), k
+    for r in (0, 1):
+        assert np.abs(res[r]["rm"] - bn.running_mean.cpu().numpy()).max() < 1e-6
+        assert np.abs(res[r]["rv"] - bn.running_var.cpu().numpy()).max() < 1e-6

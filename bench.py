@@ -1,24 +1,32 @@
 #!/usr/bin/env python
-"""bench.py — rendered views/sec of the FORGE reconstruction hot path on N MI355X.
+"""bench.py - rendered views/sec of the FORGE reconstruction hot path on N MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scenes B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path a1..a7 (SURVEY.md §8a) over one batch of B synthetic scenes
+One "step" = one pass of the hot path a1..a7 (SURVEY.md 8a) over one batch of B synthetic scenes
 per GPU: 5 input views 256^2 -> ResNet lift -> 32^3x128 feature volumes -> HIP pose warp -> ConvGRU
 fusion -> heads -> 64^3 (16+1)-channel volume -> HIP ray-march of 5 views x 128^2 rays x 64 samples ->
 conv_rgb -> 5 RGB 256^2 views + masks, through forge_amd.model.FORGE.forward (GT poses, eval-mode BN,
 fp32). Inputs are resident in HBM before the timed region. Weak scaling: every rank processes its own
-B scenes, no data-path collective (scenes are independent, SURVEY.md §8e); rank 0 prints ONE JSON line.
+B scenes, no data-path collective (scenes are independent, SURVEY.md 8e); rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      the dominant stage/kernel of the step against its bound (HIP-event timings taken inside
-                this process on the launch stream)
-  kernels       per hand-written HIP kernel: algorithmic bytes / avg launch duration vs HBM peak
-  stages_ms     HIP-event split of one step
-  cpu_baseline  the CPU oracle (reference semantics, torch-CPU) timed on this box's host cores on a
-                bounded sample of the same workload (N=1, rank 0 only)
+  roofline        the dominant kernel of the step (conv_igemm_kernel, fp32 MFMA): FLOPs its launches EXECUTE / their HIP-event time
+                  vs the 157.3 TF pipe, plus the whole step against its own executed-FLOP time floor (floor_ms, step_over_floor)
+  extra_configs   (N = 1) the other BASELINE configurations, bounded: configs[2] (8 scenes), the 128^3-voxel grid, FORGE_poseEstimator3D
+                  inference, one GT-pose training step, one pose-refinement iteration - each with ms_per_step, views_per_s and its
+                  executed-FLOP floor
+  strong_scaling  8 scenes in total split over the N ranks (the default line is weak scaling)
+  kernels         per hand-written HIP kernel: algorithmic bytes / avg launch duration vs HBM peak
+  stages_ms       HIP-event split of one step
+  cpu_baseline    the CPU oracle (reference semantics, torch-CPU) timed on this box's host cores on a
+                  bounded sample of the same workload (N=1, rank 0 only)
+  ranks_ok        ranks that completed the timed region (a failing rank reports its error instead of hanging the others)
+
+`--train`: the data-parallel TRAINING step instead (BASELINE configs[3]: FORGE_poseEstimator3D under SyncBatchNorm + DDP, forward +
+backward + clip + Adam, RCCL gradient all-reduce) - an extra mode with its own metric string, never the driver's line.
 """
 import argparse
 import json
@@ -321,13 +329,10 @@ def core_sets(nsets, per_set):
 
 
 def cpu_worker(threads, n_forward, seed):
-    """`bench.py --cpu-worker THREADS N SEED`: one process of the scene-parallel CPU baseline (pinned to FORGE_CPU_SET, a comma list of
-    logical CPUs, when given). Prints 'CPUWORKER t_start t_end n'."""
-    if os.environ.get("FORGE_CPU_SET"):
-        try:
-            os.sched_setaffinity(0, {int(c) for c in os.environ["FORGE_CPU_SET"].split(",")})
-        except Exception:
-            pass
+    """`bench.py --cpu-worker THREADS N SEED`: one process of the scene-parallel CPU baseline. Its CPU set was applied by the parent
+    BEFORE exec (preexec_fn -> sched_setaffinity), so the OpenMP runtime sizes and places its threads inside that set; no OMP_PROC_BIND
+    (round 2 set OMP_PROC_BIND=close with the affinity applied after `import torch`: the OpenMP places had already been computed from the
+    full mask, every process bound its 16 threads to the SAME first cores - 35 s per 1.1 s forward). Prints 'CPUWORKER t0 t1 n'."""
     run = _cpu_forward_fn(seed, threads)
     run()                                            # warm-up (allocator, oneDNN primitive caches)
     print("CPUWORKER_READY", flush=True)
@@ -339,7 +344,8 @@ def cpu_worker(threads, n_forward, seed):
 
 
 def cpu_baseline(sample, weights, cfg):
-    """The oracle (reference semantics, torch-CPU fp32: the port of the reference's CPU path) on this box's host cores.
+    """The oracle (reference semantics, torch-CPU fp32: the port of the reference's CPU path) on this box's host cores, on a BOUNDED
+    sample (one scene per forward; ~20-40 s of CPU work in total).
       1. single process: every candidate thread count gets 1 warm-up + 1 timed forward (a count whose warm-up exceeds 3 s is
          recorded as such and not timed again), then the fastest count gets 5 timed forwards;
       2. scene-parallel: P processes x T threads = all physical cores, each process running its own scene (how a CPU deployment would
@@ -386,10 +392,14 @@ def cpu_baseline(sample, weights, cfg):
     par = None
     try:
         sets = core_sets(nproc, tpp)                 # each process pinned to its own 16 physical cores (one socket, no SMT siblings)
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_PROC_BIND", "OMP_PLACES", "GOMP_CPU_AFFINITY", "KMP_AFFINITY")}
+        env.update(OMP_NUM_THREADS=str(tpp), MKL_NUM_THREADS=str(tpp))
+
+        def pin(cpus):                               # runs in the child between fork and exec: the interpreter starts inside its CPU set
+            return (lambda: os.sched_setaffinity(0, set(cpus))) if cpus else None
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(tpp), str(nfw), str(2000 + i)],
-                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
-                                  env=dict(os.environ, OMP_NUM_THREADS=str(tpp), MKL_NUM_THREADS=str(tpp), OMP_PROC_BIND="close",
-                                           FORGE_CPU_SET=",".join(map(str, sets[i])) if sets else "")) for i in range(nproc)]
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env,
+                                  preexec_fn=pin(sets[i] if sets else None)) for i in range(nproc)]
         for p in procs:
             while True:
                 line = p.stdout.readline()
@@ -439,28 +449,297 @@ def self_launch(args):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    sys.exit(subprocess.call(cmd, env=rank_env(os.environ)))
+
+
+def rank_env(base):
+    """Environment of the ranks: dmabuf IPC for RCCL across processes on this driver, a bounded OpenMP pool per rank, RCCL warnings on."""
+    env = dict(base)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    sys.exit(subprocess.call(cmd, env=env))
+    env.setdefault("NCCL_DEBUG", "WARN")
+    return env
+
+
+def pin_rank_to_gpu_numa(dev):
+    """Bind this rank's host threads to the CPUs of its GPU's NUMA node (PCI bus id -> /sys/bus/pci/devices/<bdf>/numa_node ->
+    /sys/devices/system/node/nodeN/cpulist): launch latency and pinned-memory copies stay on the GPU's socket. Best effort: returns a
+    description for the JSON line, never raises."""
+    try:
+        prop = torch.cuda.get_device_properties(dev)
+        bdf = "%04x:%02x:%02x.0" % (getattr(prop, "pci_domain_id", 0), prop.pci_bus_id, prop.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return {"pci": bdf, "numa_node": node, "pinned": False, "reason": "no NUMA information"}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"pci": bdf, "numa_node": node, "pinned": False, "reason": "node CPUs outside the allowed set"}
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception as e:                                        # containers without sysfs, exotic topologies: run unpinned
+        return {"pinned": False, "reason": repr(e)[:120]}
 
 
 def dry_run(args, rank, world):
     """`--dry-run`: the launch / rendezvous / timing-reduction skeleton of this entry point on CPU over gloo, with a token CPU workload
-    instead of the HIP step (tests/test_dist_cpu.py runs `python bench.py --gpus 8 --dry-run` here, where there is no GPU)."""
+    instead of the HIP step (tests/test_dist_cpu.py runs `python bench.py --gpus 8 --dry-run` here, where there is no GPU). With --train the
+    token workload is a DistributedDataParallel step (bucketed gradient all-reduce over gloo), as the real --train mode wraps the model."""
     fdist.init(backend="gloo")
     fdist.barrier()
+    ddp = opt = None
+    if args.train:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+        ddp = torch.nn.parallel.DistributedDataParallel(net) if world > 1 else net
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    ok, err = 1.0, None
     t0 = time.perf_counter()
     acc = 0.0
-    for _ in range(args.steps):
-        acc += float(torch.ones(64, 64).sum())
+    try:
+        for _ in range(args.steps):
+            if ddp is not None:
+                opt.zero_grad()
+                loss = ddp(torch.full((4, 64), 1.0 + rank)).square().mean()
+                loss.backward()
+                opt.step()
+                acc += float(loss)
+            else:
+                acc += float(torch.ones(64, 64).sum())
+    except Exception as e:                                        # a failing rank still joins the reductions below
+        ok, err = 0.0, repr(e)
     fdist.barrier()
     dt = fdist.all_reduce_scalars([time.perf_counter() - t0], "cpu", "max")[0]
-    units = fdist.all_reduce_scalars([float(args.scenes * V_OUT * args.steps)], "cpu", "sum")[0]
+    units, ranks_ok = fdist.all_reduce_scalars([float(args.scenes * (10 if args.train else V_OUT) * args.steps), ok], "cpu", "sum")
+    same = None
+    if ddp is not None and world > 1:                             # DDP keeps the replicas identical: the parameter checksum agrees on all ranks
+        chk = float(sum(p.detach().double().sum() for p in ddp.parameters()))
+        lo, hi = fdist.all_reduce_scalars([chk], "cpu", "min")[0], fdist.all_reduce_scalars([chk], "cpu", "max")[0]
+        same = abs(hi - lo) < 1e-9 * max(1.0, abs(hi))
     if rank == 0:
         print(json.dumps({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "views_counted": units, "ms_per_step": dt / args.steps * 1e3,
-                          "scaling": "weak", "config": {"workload": "dry run: no HIP work, launch + rendezvous + reductions only"}}), flush=True)
+                          "scaling": "weak", "ranks_ok": int(ranks_ok), "train": bool(args.train), "replicas_identical": same, "error": err,
+                          "config": {"workload": "dry run: no HIP work, launch + rendezvous + reductions only"}}), flush=True)
+    fdist.barrier()
+    fdist.shutdown()
+
+
+def floor_of(gflop, ms):
+    """A step against its own executed-FLOP time floor on the fp32 MFMA pipe."""
+    floor_ms = gflop / FP32_MFMA_PEAK_TF
+    return {"executed_gflop": gflop, "floor_ms": floor_ms, "executed_frac": floor_ms / ms if ms > 0 else None, "step_over_floor": ms / floor_ms if floor_ms > 0 else None}
+
+
+def _timed(fn, steps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def timed_region(fn, steps, warmup):
+    """W untimed + EXACTLY K timed steps between (barrier, synchronize) pairs; a rank that fails keeps the barrier count."""
+    good, msg, out, dt = 1.0, None, None, 0.0
+    try:
+        for _ in range(warmup):
+            out = fn()
+        torch.cuda.synchronize()
+    except Exception as e:
+        good, msg = 0.0, repr(e)[:400]
+    fdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:
+        if good:
+            for _ in range(steps):
+                out = fn()
+            torch.cuda.synchronize()
+    except Exception as e:
+        good, msg = 0.0, repr(e)[:400]
+    fdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return good, msg, out, dt
+
+
+def extra_configs(dev, steps=5):
+    """The other BASELINE configurations on this GPU, bounded (<= `steps` timed steps each), AFTER the headline timed region (N = 1):
+    configs[2] (8 scenes), the 128^3-voxel grid (n1 / configs[3]-[4] grid), FORGE_poseEstimator3D inference, one GT-pose training step
+    (configs[3] per-GPU step at the reference-native grid) and one pose-refinement iteration (row f2). Each entry: workload, ms_per_step,
+    views_per_s and `roofline` = the FLOPs the step's matrix-core launches execute (FlopMeter around one eager pass) as a time floor on the
+    157.3 TF fp32 MFMA pipe. A configuration that fails reports its error and the others still run."""
+    from forge_amd import geo_utils, refine
+    from forge_amd.flopmeter import FlopMeter
+    from forge_amd.graph import GraphedCall, GraphedForward
+    from forge_amd.model import FORGE
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    from forge_amd.train import grouped_mse
+    out = []
+    ds = syn.SyntheticDataset(1.5)
+    cfg = syn.kubric_config()
+
+    def build(cls, train=False):
+        m = cls(cfg)
+        m.load_state_dict(syn.seeded_state_dict(m.state_dict(), 0))
+        m = m.to(dev)
+        return m.train() if train else m.eval()
+
+    def entry(name, workload, views, fn_eager, fn_timed, n=steps):
+        try:
+            with FlopMeter() as fm:
+                fn_eager()
+            torch.cuda.synchronize()
+            ms = _timed(fn_timed, n)
+            out.append({"name": name, "workload": workload, "steps": n, "ms_per_step": ms, "views_per_s": views / ms * 1e3,
+                        "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms,
+                                         launches=fm.launches)})
+        except Exception as e:
+            out.append({"name": name, "workload": workload, "error": repr(e)[:300]})
+        torch.cuda.empty_cache()
+
+    model = build(FORGE)
+    # --- configs[2]: 8 scenes per GPU
+    s8 = {k: v.to(dev) for k, v in syn.make_sample(8, T_IN, 256, 1.5, seed=1000).items()}
+    holder = {}
+
+    def eager8():
+        with torch.no_grad():
+            model(s8, ds, dev)
+
+    def timed8():
+        if "g" not in holder:
+            holder["g"] = GraphedForward(model, s8, ds, dev)
+        holder["g"](s8)
+    entry("configs[2]", "BASELINE configs[2]: FORGE hot path, 8 scenes/GPU x 5 views -> 40 rendered views per step (hipGraph replay)", 40, eager8, timed8)
+    holder.clear()
+    del s8
+    # --- 128^3-voxel scenes (synthetic 64^3 feature volumes through reconstruct)
+    s1 = {k: v.to(dev) for k, v in syn.make_sample(1, T_IN, 256, 1.5, seed=1000).items()}
+    gen = torch.Generator(device=dev).manual_seed(77)
+    f64 = torch.randn(1, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+    p64 = s1["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
+    c64 = geo_utils.camera_dict(s1["cam_extrinsics_cv2_canonicalized"][:, :V_OUT], s1["K_cv2"][:, :V_OUT])
+
+    def eager64():
+        with torch.no_grad():
+            return model.reconstruct(f64, p64, c64)[:2]
+
+    def timed64():
+        if "g" not in holder:
+            holder["g"] = GraphedCall(eager64, dev)
+        holder["g"]()
+    entry("grid64", "128^3-voxel scenes (configs[3]/[4] grid): 1 scene x 5 synthetic [128,64^3] feature volumes -> rotate(D=64) -> fusion at "
+          "M=262144 -> heads -> 128^3 x 17 volume -> 5 views (hipGraph replay)", 5, eager64, timed64)
+    holder.clear()
+    del f64
+    # --- pose refinement iteration (row f2): t = 5 views, 4 free poses, hipGraph replay inside refine_poses
+    try:
+        with torch.no_grad():
+            feats = model.encoder_3d.get_feat3D(s1["images"][0, :T_IN]).reshape(1, T_IN, 128, 32, 32, 32)
+            gt7 = geo_utils.mat2quat(s1["cam_poses_rel_cv2"][0, 1:T_IN])
+            tgt_i, tgt_m, _, _, _ = refine._render_views(model, cfg, ds, feats, gt7, s1["K_cv2"][:, :T_IN], dev)
+        init = gt7.clone()
+        init[:, 4:] += 0.02
+        with FlopMeter() as fm:                                    # eager iterations only (one here): forward + data-gradient backward
+            refine.refine_poses(model, cfg, ds, feats, init, tgt_i, tgt_m, s1["K_cv2"][:, :T_IN], dev, iter_num=0, use_graph=False)
+        _, _, dt = refine.refine_poses(model, cfg, ds, feats, init, tgt_i, tgt_m, s1["K_cv2"][:, :T_IN], dev, iter_num=2 * steps + 3, use_graph=True)
+        ms = dt * 1e3
+        out.append({"name": "refinement", "workload": "pose-refinement iteration (kubric_eval.py:412-530): 1 scene, 5 views, 4 free 7-D poses; rotate -> fuse "
+                    "-> heads -> ray-march -> conv_rgb forward + data-gradient backward + Adam, hipGraph replay", "steps": 2 * steps,
+                    "ms_per_step": ms, "views_per_s": T_IN / ms * 1e3,
+                    "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches)})
+    except Exception as e:
+        out.append({"name": "refinement", "error": repr(e)[:300]})
+    del model
+    torch.cuda.empty_cache()
+    # --- FORGE_poseEstimator3D inference: three fusions, 10 rendered views per scene
+    m3 = build(FORGE_poseEstimator3D)
+
+    def eager3():
+        with torch.no_grad():
+            m3(s1, ds, dev)
+
+    def timed3():
+        if "g" not in holder:
+            holder["g"] = GraphedForward(m3, s1, ds, dev)
+        holder["g"](s1)
+    entry("pose3d_inference", "FORGE_poseEstimator3D inference (GT poses): 1 scene x 5 views -> 3 fusions (shared input halves) -> 10 rendered views "
+          "(hipGraph replay)", 10, eager3, timed3)
+    holder.clear()
+    # --- one GT-pose training step (configs[3] per-GPU step at the reference-native 32^3 / 64^3 grids): forward + backward + clip + Adam, eager
+    m3 = m3.train()
+    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=1e-4)
+
+    def train_step():
+        imgs, masks = m3(s1, ds, dev)
+        mi = grouped_mse(imgs.reshape(1, 10, 3, 256, 256), s1["images"][:, :T_IN], T_IN)
+        mm = grouped_mse(masks.reshape(1, 10, 1, 256, 256), s1["fg_probabilities"][:, :T_IN], T_IN)
+        loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+        opt.step()
+    entry("train_step", "GT-pose training step (kubric_train_pose_3D.py; scripts/kubric_trainer.py:47-59): FORGE_poseEstimator3D, 1 scene x 5 views, "
+          "3 fusions, 10 rendered views, fused MSE, backward, clip 10, Adam; train-mode BatchNorm on the HIP kernels; eager launch", 10, train_step, train_step)
+    return out
+
+
+def train_bench(args, rank, world, dev, affinity):
+    """`--train`: BASELINE configs[3] as a scaling measurement - FORGE_poseEstimator3D (GT poses), args.scenes scenes per GPU x 5 views ->
+    10 rendered views per scene, SyncBatchNorm (HIP kernels, one RCCL all-reduce of the float64 statistics per layer and direction) +
+    DistributedDataParallel (bucketed RCCL gradient all-reduce overlapped with the backward), loss, clip 10, Adam: the iteration of
+    scripts/kubric_trainer.py:47-59 as kubric_train_pose_3D.py:119-124 wraps the model. Prints its own metric string."""
+    from forge_amd import train
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    cfg = syn.kubric_config()
+    B = args.scenes
+    ok, err, dt, loss = 1.0, None, 0.0, float("nan")
+    fdist.init()
+    try:
+        model = FORGE_poseEstimator3D(cfg)
+        model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+        model = model.to(dev).train()
+        if world > 1:
+            model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)     # kubric_train_pose_3D.py:124
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.train.lr)
+        sample = {k: v.to(dev) for k, v in syn.make_sample(B, T_IN, 256, 1.5, seed=1000 + rank).items()}
+        ds = syn.SyntheticDataset(1.5)
+
+        def step():
+            return train.train_step(cfg, sample, ds, model, opt, dev)[0]
+    except Exception as e:
+        ok, err = 0.0, repr(e)[:400]
+        import traceback
+        traceback.print_exc()
+    if ok:
+        ok, err, lt, dt = timed_region(step, args.steps, args.warmup)
+        loss = float(lt) if ok else float("nan")
+    else:
+        fdist.barrier()
+        fdist.barrier()
+    dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
+    views, ranks_ok, loss_sum = fdist.all_reduce_scalars([B * 10.0 * ok, ok, loss if ok else 0.0], dev, "sum")
+    errs = fdist.gather_strings(err)
+    if rank == 0:
+        ms = dt / args.steps * 1e3 if dt > 0 else None
+        print(json.dumps({
+            "metric": "rendered views/sec incl. backward (GT-pose training step, 10 views/scene, 64^3 voxel)", "value": views * args.steps / dt if dt > 0 else None,
+            "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_ok": int(ranks_ok), "errors": [e for e in errs if e],
+            "mean_loss_all_ranks": loss_sum / max(ranks_ok, 1.0),
+            "config": {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered "
+                                   "views/scene, reference-native 32^3 / 64^3 grids, SyncBatchNorm + DDP" % B, "scenes_per_gpu": B,
+                       "global_batch": B * world, "parallelism": "dp%d (DDP bucketed RCCL all-reduce of 221 MB fp32 gradients; HIP SyncBatchNorm)" % world,
+                       "rank0_affinity": affinity}}), flush=True)
     fdist.barrier()
     fdist.shutdown()
 
@@ -474,10 +753,12 @@ def main():
     ap.add_argument("--grid", type=int, default=32, choices=(32, 64),
                     help="feature grid: 32 = the metric's configuration (64^3 render volume); 64 = BASELINE configs[3]/[4] 128^3-voxel "
                          "scenes: synthetic [b,5,128,64^3] feature volumes through rotate -> fuse -> heads -> ray-march (the encoder cannot produce them)")
+    ap.add_argument("--train", action="store_true", help="time the data-parallel training step (SyncBatchNorm + DDP) instead of inference")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--dump-conv", action="store_true", help="print every conv launch of one step (shape, ms, TFLOP/s) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra_configs / strong_scaling (the other BASELINE configurations)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank launch path (no HIP work)")
     ap.add_argument("--cpu-worker", nargs=3, type=int, metavar=("THREADS", "N", "SEED"), help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -499,85 +780,123 @@ def main():
                          "(set FORGE_BENCH_ALLOW_SHARED_GPUS=1 for a functional rehearsal)" % (world, ndev))
     dev = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(dev)
+    affinity = pin_rank_to_gpu_numa(dev) if world > 1 else {"pinned": False, "reason": "single rank"}
     _lib.lib()
+    if args.train:
+        return train_bench(args, rank, world, dev, affinity)
 
     from forge_amd.model import FORGE
     cfg = syn.kubric_config()
-    model = FORGE(cfg)
-    weights = syn.seeded_state_dict(model.state_dict(), 0)
-    model.load_state_dict(weights)
-    model = model.to(dev).eval()
     B = args.scenes
-    sample_cpu = syn.make_sample(B, T_IN, 256, 1.5, seed=1000 + rank)
-    sample = {k: v.to(dev) for k, v in sample_cpu.items()}      # inputs resident in HBM
-    dataset = syn.SyntheticDataset(1.5)
+    ok, err = 1.0, None
+    graphed = step = eager_step = strong = None
+    B_strong = max(1, 8 // world) if (world > 1 and not args.no_extra and args.grid == 32 and not args.no_graph) else 0
+    try:
+        model = FORGE(cfg)
+        weights = syn.seeded_state_dict(model.state_dict(), 0)
+        model.load_state_dict(weights)
+        model = model.to(dev).eval()
+        sample_cpu = syn.make_sample(B, T_IN, 256, 1.5, seed=1000 + rank)
+        sample = {k: v.to(dev) for k, v in sample_cpu.items()}      # inputs resident in HBM
+        dataset = syn.SyntheticDataset(1.5)
 
-    if args.grid == 32:
-        def eager_step():
-            with torch.no_grad():
-                return model(sample, dataset, dev)
-    else:
-        # 128^3-voxel scenes: per-view feature volumes [B,5,128,64^3] (671 MB per scene) resident in HBM, GT poses / cameras of the sample
-        from forge_amd import geo_utils
-        gen = torch.Generator(device=dev).manual_seed(77 + rank)
-        feats64 = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
-        poses64 = sample["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
-        cams64 = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"][:, :V_OUT], sample["K_cv2"][:, :V_OUT])
+        if args.grid == 32:
+            def eager_step():
+                with torch.no_grad():
+                    return model(sample, dataset, dev)
+        else:
+            # 128^3-voxel scenes: per-view feature volumes [B,5,128,64^3] (671 MB per scene) resident in HBM, GT poses / cameras of the sample
+            from forge_amd import geo_utils
+            gen = torch.Generator(device=dev).manual_seed(77 + rank)
+            feats64 = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+            poses64 = sample["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
+            cams64 = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"][:, :V_OUT], sample["K_cv2"][:, :V_OUT])
 
-        def eager_step():
-            with torch.no_grad():
-                return model.reconstruct(feats64, poses64, cams64)[:2]
+            def eager_step():
+                with torch.no_grad():
+                    return model.reconstruct(feats64, poses64, cams64)[:2]
 
-    # hipGraph capture happens BEFORE the process group exists: no RCCL communicator / watchdog thread is alive while the stream is
-    # capturing, so the capture cannot be invalidated by collective-library activity; the barrier / all-reduce below never run inside it.
-    graphed = None
-    if args.no_graph:
-        step = eager_step
-    elif args.grid == 32:
-        from forge_amd.graph import GraphedForward
-        graphed = GraphedForward(model, sample, dataset, dev)      # hipGraph of the whole step; replays do all the work
-        step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the static buffers)
-    else:
-        from forge_amd.graph import GraphedCall
-        step = GraphedCall(eager_step, dev)
+        # hipGraph capture happens BEFORE the process group exists: no RCCL communicator / watchdog thread is alive while the stream is
+        # capturing, so the capture cannot be invalidated by collective-library activity; the barrier / all-reduce below never run inside it.
+        if args.no_graph:
+            step = eager_step
+        elif args.grid == 32:
+            from forge_amd.graph import GraphedForward
+            graphed = GraphedForward(model, sample, dataset, dev)      # hipGraph of the whole step; replays do all the work
+            step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the static buffers)
+        else:
+            from forge_amd.graph import GraphedCall
+            step = GraphedCall(eager_step, dev)
+        if B_strong and B_strong != B:                                   # strong scaling: 8 scenes in total over the N ranks
+            from forge_amd.graph import GraphedForward
+            s_strong = {k: v.to(dev) for k, v in syn.make_sample(B_strong, T_IN, 256, 1.5, seed=2000 + rank).items()}
+            g_strong = GraphedForward(model, s_strong, dataset, dev)
+            strong = lambda: g_strong(s_strong)                          # noqa: E731
+        elif B_strong:
+            strong = step
+    except Exception as e:                                                # this rank still joins the rendezvous and the reductions: no hang
+        ok, err = 0.0, repr(e)[:400]
+        import traceback
+        traceback.print_exc()
 
     fdist.init()                                                    # RCCL (backend "nccl") over xGMI when world > 1
     fdist.barrier()
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    fdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    fdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    if ok:
+        ok, err, out, dt = timed_region(step, args.steps, args.warmup)
+    else:
+        fdist.barrier()
+        fdist.barrier()
+        out, dt = None, 0.0
     dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
     # the one exchange of the inference path: (SSE to the target views, pixel count, views rendered) summed over ranks
-    # (RCCL all-reduce, 3 doubles) -> whole-job PSNR / view count
-    tgt_dev = sample["images"][:, :V_OUT].reshape(B * V_OUT, 3, 256, 256)
-    sse_local = float(((out[0] - tgt_dev) ** 2).sum())
-    sse, npix, views_per_step = fdist.all_reduce_scalars([sse_local, float(tgt_dev.numel()), float(B * V_OUT)], dev, "sum")
-    assert int(views_per_step) == world * B * V_OUT
+    # (RCCL all-reduce of a few doubles) -> whole-job PSNR / view count; ranks_ok rides along
+    if ok:
+        tgt_dev = sample["images"][:, :V_OUT].reshape(B * V_OUT, 3, 256, 256)
+        sse_local, npix_local = float(((out[0] - tgt_dev) ** 2).sum()), float(tgt_dev.numel())
+    else:
+        sse_local = npix_local = 0.0
+    sse, npix, views_per_step, ranks_ok = fdist.all_reduce_scalars([sse_local, npix_local, float(B * V_OUT) * ok, ok], dev, "sum")
+    errors = [e for e in fdist.gather_strings(err) if e]
     views = int(views_per_step) * args.steps
+
+    strong_res = None
+    if B_strong:                                                     # bounded: <= 5 steps
+        n_s = min(5, args.steps)
+        if strong is not None and ok:
+            ok_s, err_s, _, dt_s = timed_region(strong, n_s, 1)
+        else:
+            fdist.barrier()
+            fdist.barrier()
+            ok_s, dt_s = 0.0, 0.0
+        dt_s = fdist.all_reduce_scalars([dt_s], dev, "max")[0]
+        v_s, r_s = fdist.all_reduce_scalars([float(B_strong * V_OUT) * ok_s, ok_s], dev, "sum")
+        strong_res = {"scaling": "strong", "total_scenes": B_strong * world, "scenes_per_gpu": B_strong, "steps": n_s, "ms_per_step": dt_s / n_s * 1e3,
+                      "views_per_s": v_s * n_s / dt_s if dt_s > 0 else None, "ranks_ok": int(r_s),
+                      "note": "8 scenes in total split over the ranks; the N = 1 point of this curve is extra_configs['configs[2]'] of the --gpus 1 line"}
+
+    # every rank is done with collectives: tear the process group down NOW, so that rank 0's per-kernel measurements, the other
+    # configurations and the CPU baseline below never keep the other ranks (or an RCCL watchdog) waiting
+    fdist.barrier()
+    fdist.shutdown()
+    if rank != 0:
+        return None
+    if not ok:
+        print(json.dumps({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks_ok": int(ranks_ok), "errors": errors, "error": err}), flush=True)
+        return None
 
     # ---- the same steps with the sample handed over as (pinned) HOST buffers, as a DataLoader would: PCIe-inclusive rate (never `value`)
     pcie_views_per_s = None
-    if rank == 0 and world == 1:
+    if world == 1 and graphed is not None:
         host = {k: v.pin_memory() for k, v in sample_cpu.items()}
-        feed = (lambda: graphed(host)) if graphed is not None else None
-        if feed is not None:
-            feed()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                feed()
-            torch.cuda.synchronize()
-            pcie_views_per_s = B * V_OUT * args.steps / (time.perf_counter() - t1)
+        graphed(host)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            graphed(host)
+        torch.cuda.synchronize()
+        pcie_views_per_s = B * V_OUT * args.steps / (time.perf_counter() - t1)
 
     # ---- per-stage HIP-event split of one more step (outside the timed region)
     rec, undo = stage_timers(model)
@@ -594,7 +913,7 @@ def main():
                    for k, v in conv_rec.items()}
     for u in undo:
         u()
-    if args.dump_conv and rank == 0:
+    if args.dump_conv:
         for k, v in conv_rec.items():
             for x in v:
                 ms = x[0].elapsed_time(x[1])
@@ -603,87 +922,91 @@ def main():
         stages["encoder_conv1(+layout)"] = stages.pop("encoder_total") - stages.get("encoder_resnet", 0.0)
     stages["render_march(+cam pack)"] = stages.pop("render_total") - stages.get("conv_rgb", 0.0)
 
-    result = None
-    if rank == 0:
-        kern = {} if args.no_microbench else kernel_rooflines(dev, B, args.grid)
-        for k, v in wino_rec.items():          # Winograd transform kernels of the fusion, as launched inside the step
-            ms, by = sum(x[0].elapsed_time(x[1]) for x in v), sum(x[2] for x in v)
-            kern[k] = {"bound": "hbm", "launches_per_step": len(v), "ms_total": ms, "bytes": by, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic(k),
-                       "note": "HIP events around the eager launches of one step (each includes the host launch gap); the transformed operands "
-                               "(67-134 MB per launch at one scene) are partly served by the 256 MB Infinity Cache"}
-        # dominant kernel of the step: conv_igemm_kernel<BM, BN, waves> - ONE kernel (csrc/conv_igemm.hip) whose tile shape is picked per
-        # launch by the plan model, so rocprofv3 lists it under several instantiation names; together they are ~95 % of the step.
-        # achieved = sum of the FLOPs of all its launches in one step / sum of their HIP-event durations - the FLOPs the launches execute:
-        # direct convolutions count 2 M N taps Cin, the Winograd point-GEMM launches of the fusion 2 x 16 R N x 3 Cin (2.25x fewer than the
-        # direct convolution they replace; the step's direct-convolution FLOPs are `gflop_per_step_algorithmic`). The
-        # per-instantiation avg_launch_ms are directly comparable with rocprofv3's per-name AverageNs in profiles/.
-        convs = {k: v for k, v in conv_launch.items() if k.startswith("conv_igemm_kernel<")}
-        step_ms = dt / args.steps * 1e3
-        tot_ms = sum(v["total_ms"] for v in convs.values())
-        tot_gf = sum(v["gflop"] for v in convs.values())
-        n_launch = sum(v["launches_per_step"] for v in convs.values())
-        alg_gf = sum(v["gflop_direct_equivalent"] for v in convs.values())
-        wino_ms = sum(x[0].elapsed_time(x[1]) for v in wino_rec.values() for x in v)
-        inst = {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["total_ms"] / v["launches_per_step"],
-                    "achieved": v["gflop"] / v["total_ms"], "frac": v["gflop"] / v["total_ms"] / FP32_MFMA_PEAK_TF,
-                    "gflop_per_step": v["gflop"], "share_of_step": v["total_ms"] / step_ms}
-                for k, v in sorted(convs.items(), key=lambda kv: -kv[1]["total_ms"])}
-        roofline = {"kernel": "conv_igemm_kernel<BM, BN, waves> (fp32 MFMA implicit-GEMM conv; all %d launches of one step, %d tile instantiations)"
-                              % (n_launch, len(convs)),
-                    "bound": "mfma", "achieved": tot_gf / tot_ms, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TF,
-                    "traffic": pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
-                    "gflop_per_step": tot_gf, "share_of_step": tot_ms / step_ms, "instantiations": inst,
-                    # the same launches in SURVEY.md 8(d)'s ALGORITHMIC FLOPs (the direct convolutions the reference computes), the Winograd
-                    # transform kernels' time charged to them: above 1.0 where 2.25x of the 3x3x3 work is never executed
-                    "algorithmic": {"gflop_per_step": alg_gf, "ms_incl_winograd_transforms": tot_ms + wino_ms,
-                                    "achieved": alg_gf / (tot_ms + wino_ms), "frac": alg_gf / (tot_ms + wino_ms) / FP32_MFMA_PEAK_TF},
-                    "note": "achieved / frac count the FLOPs the launches EXECUTE (Winograd point-GEMM launches: 2.25x fewer than the direct "
-                            "convolution they replace; `algorithmic` restates them in the reference's direct-convolution FLOPs); durations are HIP events around each launch on the launch stream in an eager (non-graph) pass, so each includes "
-                            "the host launch gap (and, for split-K launches, the reduction kernel); traffic is the PMC pass of the "
-                            "ConvGRU-gates launch (the Winograd point-GEMM launch when the fusion runs it)"}
-        if args.grid == 32:
-            metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
-            workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
-                        "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
-                        "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU (Winograd F(2x2,3x3) x 3 depth taps) / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
-                        "eval BN, random-init seeded weights" % (1 if B == 1 else 2, B))
-            gflop = B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB)
-        else:
-            metric = "rendered views/sec (5 views, 128^2 px, 128^3 voxel)"
-            workload = ("BASELINE configs[3]/[4] grid (synthetic up-scale, SURVEY.md 8d): %d scene(s)/GPU x 5 synthetic feature volumes "
-                        "[128,64^3] resident in HBM (the encoder cannot produce them from 256^2 images, models/encoder.py:49) -> HIP rotate at "
-                        "D=64 (1.07 GB/scene) -> ConvGRU fusion at M=262144 -> heads -> 128^3 x 17 render volume (142.6 MB) -> 5 views x "
-                        "128^2 rays x 64 samples -> conv_rgb -> 5 RGB 256^2; eval BN, random-init seeded weights" % B)
-            gflop = B * (8 * (GF_FUSE + GF_HEADS) + GF_CONVRGB)
-        result = {
-            "metric": metric, "value": views / dt, "unit": "views/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
-                       "render_grid": 2 * args.grid, "launch": "eager" if args.no_graph else "hipGraph replay",
-                       "parallelism": "dp%d (scene-sharded, no data-path collective; 3-scalar RCCL all-reduce of SSE/pixels/views for the PSNR report)" % world},
-            "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
-            "gflop_per_step_algorithmic": gflop, "direct_equivalent_tflops": gflop / (dt / args.steps) / 1e3,
-            "views_per_s_with_host_to_device_copy": pcie_views_per_s,
-            "psnr_to_target_db_all_ranks": fdist.psnr_from_sse(sse, npix),
-        }
-        if world == 1 and not args.no_cpu_baseline and args.grid == 32:
-            cb, ref = cpu_baseline(sample_cpu, weights, cfg)
-            result["cpu_baseline"] = cb
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import forge_oracle as fo
-            result["psnr_vs_oracle_db"] = fo.psnr(out[0][:V_OUT].cpu(), ref[0])
-            result["max_abs_err_vs_oracle"] = (out[0][:V_OUT].cpu() - ref[0]).abs().max().item()
-            # north_star: "PSNR within 0.1 dB of reference" - PSNR of both against the same target images (the scene's input views; with
-            # random-init weights the absolute value is meaningless, the DIFFERENCE is the criterion)
-            tgt = sample_cpu["images"][0, :V_OUT]
-            p_build, p_oracle = fo.psnr(out[0][:V_OUT].cpu(), tgt), fo.psnr(ref[0], tgt)
-            result["psnr_to_target_db"] = {"build": p_build, "oracle": p_oracle, "abs_diff": abs(p_build - p_oracle)}
-            result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
-        print(json.dumps(result), flush=True)
-    fdist.barrier()
-    fdist.shutdown()
+    kern = {} if args.no_microbench else kernel_rooflines(dev, B, args.grid)
+    for k, v in wino_rec.items():          # Winograd transform kernels of the fusion, as launched inside the step
+        ms, by = sum(x[0].elapsed_time(x[1]) for x in v), sum(x[2] for x in v)
+        kern[k] = {"bound": "hbm", "launches_per_step": len(v), "ms_total": ms, "bytes": by, "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "traffic": pmc_traffic(k),
+                   "note": "HIP events around the eager launches of one step (each includes the host launch gap); the transformed operands "
+                           "(67-134 MB per launch at one scene) are partly served by the 256 MB Infinity Cache"}
+    # dominant kernel of the step: conv_igemm_kernel<BM, BN, waves> - ONE kernel (csrc/conv_igemm.hip) whose tile shape is picked per
+    # launch by the plan model, so rocprofv3 lists it under several instantiation names; together they are ~85 % of the step.
+    # achieved = sum of the FLOPs its launches EXECUTE in one step (direct convolutions 2 M N taps Cin, Winograd point-GEMM launches
+    # 2 x 16 R N kd Cin) / sum of their HIP-event durations. The per-instantiation avg_launch_ms are directly comparable with
+    # rocprofv3's per-name AverageNs in profiles/. floor_ms = the same executed FLOPs at the 157.3 TF pipe peak: the step's own time floor.
+    convs = {k: v for k, v in conv_launch.items() if k.startswith("conv_igemm_kernel<")}
+    step_ms = dt / args.steps * 1e3
+    tot_ms = sum(v["total_ms"] for v in convs.values())
+    tot_gf = sum(v["gflop"] for v in convs.values())
+    n_launch = sum(v["launches_per_step"] for v in convs.values())
+    alg_gf = sum(v["gflop_direct_equivalent"] for v in convs.values())
+    n16_gf = sum(v["gflop"] for k, v in conv_launch.items() if not k.startswith("conv_igemm_kernel<"))
+    inst = {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["total_ms"] / v["launches_per_step"],
+                "achieved": v["gflop"] / v["total_ms"], "frac": v["gflop"] / v["total_ms"] / FP32_MFMA_PEAK_TF,
+                "gflop_per_step": v["gflop"], "share_of_step": v["total_ms"] / step_ms}
+            for k, v in sorted(convs.items(), key=lambda kv: -kv[1]["total_ms"])}
+    fl = floor_of(tot_gf + n16_gf, step_ms)
+    roofline = {"kernel": "conv_igemm_kernel<BM, BN, waves> (fp32 MFMA implicit-GEMM conv; all %d launches of one step, %d tile instantiations)"
+                          % (n_launch, len(convs)),
+                "bound": "mfma", "achieved": tot_gf / tot_ms, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TF,
+                "traffic": pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
+                "executed_gflop": fl["executed_gflop"], "executed_frac": fl["executed_frac"], "floor_ms": fl["floor_ms"], "step_over_floor": fl["step_over_floor"],
+                "kernel_ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms, "instantiations": inst,
+                "note": "frac = FLOPs the dominant kernel's launches EXECUTE / their HIP-event time / peak (a statement about the kernel; eager pass, each "
+                        "event pair includes the host launch gap and, for split-K launches, the reduction). executed_frac = floor_ms / ms_per_step = the "
+                        "WHOLE step (all kernels, hipGraph replay) against the time its executed matrix-core FLOPs need at peak (a statement about the "
+                        "step). In SURVEY.md 8(d)'s direct-convolution FLOPs the same launches are %.0f GF (the Winograd launches execute 2.25x fewer "
+                        "multiplies than the convolutions they replace), so a fraction in those units can exceed 1 and is not reported as one; "
+                        "traffic = PMC pass of the fusion's point-GEMM launch" % alg_gf}
+    if args.grid == 32:
+        metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
+        workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
+                    "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
+                    "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU (Winograd F(2x2,3x3) x 3 depth taps) / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
+                    "eval BN, random-init seeded weights" % (1 if B == 1 else 2, B))
+        gflop = B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB)
+    else:
+        metric = "rendered views/sec (5 views, 128^2 px, 128^3 voxel)"
+        workload = ("BASELINE configs[3]/[4] grid (synthetic up-scale, SURVEY.md 8d): %d scene(s)/GPU x 5 synthetic feature volumes "
+                    "[128,64^3] resident in HBM (the encoder cannot produce them from 256^2 images, models/encoder.py:49) -> HIP rotate at "
+                    "D=64 (1.07 GB/scene) -> ConvGRU fusion at M=262144 -> heads -> 128^3 x 17 render volume (142.6 MB) -> 5 views x "
+                    "128^2 rays x 64 samples -> conv_rgb -> 5 RGB 256^2; eval BN, random-init seeded weights" % B)
+        gflop = B * (8 * (GF_FUSE + GF_HEADS) + GF_CONVRGB)
+    result = {
+        "metric": metric, "value": views / dt, "unit": "views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ranks_ok": int(ranks_ok), "errors": errors,
+        "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
+                   "render_grid": 2 * args.grid, "launch": "eager" if args.no_graph else "hipGraph replay", "rank0_affinity": affinity,
+                   "parallelism": "dp%d (scene-sharded, no data-path collective; 4-scalar RCCL all-reduce of SSE/pixels/views/ok for the PSNR report)" % world},
+        "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        "gflop_per_step_algorithmic": gflop,
+        "views_per_s_with_host_to_device_copy": pcie_views_per_s,
+        "psnr_to_target_db_all_ranks": fdist.psnr_from_sse(sse, npix),
+    }
+    if strong_res is not None:
+        result["strong_scaling"] = strong_res
+    ref = None
+    if world == 1 and not args.no_cpu_baseline and args.grid == 32:
+        cb, ref = cpu_baseline(sample_cpu, weights, cfg)
+        result["cpu_baseline"] = cb
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import forge_oracle as fo
+        img0 = out[0][:V_OUT].cpu()
+        result["psnr_vs_oracle_db"] = fo.psnr(img0, ref[0])
+        result["max_abs_err_vs_oracle"] = (img0 - ref[0]).abs().max().item()
+        # north_star: "PSNR within 0.1 dB of reference" - PSNR of both against the same target images (the scene's input views; with
+        # random-init weights the absolute value is meaningless, the DIFFERENCE is the criterion)
+        tgt = sample_cpu["images"][0, :V_OUT]
+        p_build, p_oracle = fo.psnr(img0, tgt), fo.psnr(ref[0], tgt)
+        result["psnr_to_target_db"] = {"build": p_build, "oracle": p_oracle, "abs_diff": abs(p_build - p_oracle)}
+        result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
+    if world == 1 and not args.no_extra and args.grid == 32:
+        del graphed, step
+        torch.cuda.empty_cache()
+        result["extra_configs"] = extra_configs(dev, steps=min(5, max(2, args.steps)))
+    print(json.dumps(result), flush=True)
     return result
 
 

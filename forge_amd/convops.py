@@ -153,7 +153,15 @@ SPLITK_WS_BYTES = 128 << 20          # cap the plan model may assume for split-K
 TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
 _PLAN_CACHE = {}
-_PLAN_OVERRIDE = [None]               # (tile letter or None, ksplit or None): set by force_plan() only (tools/conv_plan_sweep.py, tests)
+
+
+class _State:
+    """Process-wide measurement switches (defaults = the product). Set through force_plan() / winograd(), or monkeypatched by tests."""
+    plan_override = None              # (tile letter or None, ksplit or None): set by force_plan() only (tools/conv_plan_sweep.py, tests)
+    winograd = True                   # False: the direct implicit-GEMM kernel for every 3x3(x3) convolution
+
+
+STATE = _State()
 
 
 class force_plan:
@@ -165,12 +173,12 @@ class force_plan:
         self.val = (tile, ksplit)
 
     def __enter__(self):
-        self.prev = _PLAN_OVERRIDE[0]
-        _PLAN_OVERRIDE[0] = self.val
+        self.prev = STATE.plan_override
+        STATE.plan_override = self.val
         return self
 
     def __exit__(self, *exc):
-        _PLAN_OVERRIDE[0] = self.prev
+        STATE.plan_override = self.prev
         return False
 
 
@@ -185,7 +193,7 @@ def conv_plan(M, Cout, Cin, ntaps, epilogue, ldo, nphase=1):
         _lib.check(_lib.lib().forge_conv_igemm_plan(int(M), int(Cout), int(Cin), int(ntaps), int(nphase), int(epilogue), int(ldo), SPLITK_WS_BYTES,
                                                     ctypes.byref(tile), ctypes.byref(ks)), "forge_conv_igemm_plan")
         pl = _PLAN_CACHE[key] = (chr(tile.value), ks.value)
-    ov = _PLAN_OVERRIDE[0]
+    ov = STATE.plan_override
     if ov is not None and pl[0] != "N":
         tile = ov[0] or pl[0]
         ks = ov[1] if ov[1] is not None else (pl[1] if ov[0] is None else 1)
@@ -354,13 +362,10 @@ def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
             and C1 + C2 >= 64 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
 
 
-_WINOGRAD = [True]
-
-
 def wino_enabled():
     """The stride-1 3x3(x3) convolutions take the Winograd launches unless a tool / test asked for the direct implicit-GEMM kernel
     (`with convops.winograd(False): ...`; A/B: tools/wino_ab.py, bit-equality tests of launcher mechanics)."""
-    return _WINOGRAD[0]
+    return STATE.winograd
 
 
 class winograd:
@@ -370,12 +375,12 @@ class winograd:
         self.on = bool(on)
 
     def __enter__(self):
-        self.prev = _WINOGRAD[0]
-        _WINOGRAD[0] = self.on
+        self.prev = STATE.winograd
+        STATE.winograd = self.on
         return self
 
     def __exit__(self, *exc):
-        _WINOGRAD[0] = self.prev
+        STATE.winograd = self.prev
         return False
 
 
@@ -419,7 +424,7 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
 
 def wino_gemm_tile(R, Cout):
     """Tile letter forge_wino_gemm uses for R tile rows per point (names the kernel instantiation for profilers, bench.py)."""
-    ov = _PLAN_OVERRIDE[0]
+    ov = STATE.plan_override
     if ov is not None and ov[0]:
         return ov[0]
     return chr(_lib.lib().forge_wino_gemm_tile(int(R), int(Cout)))

@@ -60,6 +60,16 @@ def all_reduce_mean_(t):
     return t
 
 
+def gather_strings(msg):
+    """Every rank's (short) message or None on every rank - per-rank failure reports of the bench harness. Uses all_gather_object (pickled
+    through the backend); the list is [msg] for a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, msg)
+        return out
+    return [msg]
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -1,0 +1,65 @@
+"""Executed-FLOP meter for the matrix-core launches of libforge_hip.so (measurement aid for bench.py / tools; not on the product path).
+
+`with FlopMeter() as m: step()` wraps the ctypes entry points whose work runs on the fp32 MFMA pipe - forge_conv_igemm, forge_wino_gemm,
+forge_conv_wgrad, forge_wino_wgrad - for the duration of the block and sums the FLOPs each launch EXECUTES, computed from the call's own
+arguments (2 M N taps Cin for a direct / data-gradient / weight-gradient convolution, 2 x 16 R N kd Cin for the 16 Winograd point problems).
+Only eager launches made by this process are seen (a hipGraph replay makes no Python calls): meter one eager pass, time the replay.
+"""
+from . import _lib
+
+
+def _v(a):
+    return a.value if hasattr(a, "value") else a
+
+
+def _igemm(a):          # forge_conv_igemm(in1,C1,ld1,bs1,in2,C2,ld2,bs2,wp,bias,scale,shift,slope,residual,aux_h,aux_z,out,out2,out3,n,D,H,W,is,Di,Hi,Wi,Cout,ldo,taps,ntaps,...)
+    C1, C2 = _v(a[1]), _v(a[5])
+    n, D, H, W, Cout, ntaps = _v(a[19]), _v(a[20]), _v(a[21]), _v(a[22]), _v(a[27]), _v(a[30])
+    return 2.0 * n * D * H * W * Cout * ntaps * (C1 + C2)          # merged transposed-conv phases: M rows x ntaps / P taps x P phases = the same product
+
+
+def _wino_gemm(a):      # forge_wino_gemm(V1,C1,ld1,bs1,pt1,V2,C2,ld2,bs2,pt2,U,Mm,n,D,Ht,Wt,Cout,kd,tile,stream)
+    return 2.0 * 16 * _v(a[12]) * _v(a[13]) * _v(a[14]) * _v(a[15]) * _v(a[16]) * _v(a[17]) * (_v(a[1]) + _v(a[6]))
+
+
+def _wgrad(a):          # forge_conv_wgrad(dy,ldy,x1,C1,ld1,bs1,x2,C2,ld2,bs2,dwp,n,D,H,W,is,Di,Hi,Wi,Cout,taps,ntaps,stream)
+    return 2.0 * _v(a[11]) * _v(a[12]) * _v(a[13]) * _v(a[14]) * _v(a[19]) * _v(a[21]) * (_v(a[3]) + _v(a[7]))
+
+
+def _wino_wgrad(a):     # forge_wino_wgrad(dMm,V1,C1,bs1,pt1,V2,C2,bs2,pt2,dU,n,D,Ht,Wt,Cout,kd,stream)
+    return 2.0 * 16 * _v(a[10]) * _v(a[11]) * _v(a[12]) * _v(a[13]) * _v(a[14]) * _v(a[15]) * (_v(a[2]) + _v(a[6]))
+
+
+_ENTRIES = {"forge_conv_igemm": _igemm, "forge_wino_gemm": _wino_gemm, "forge_conv_wgrad": _wgrad, "forge_wino_wgrad": _wino_wgrad}
+
+
+class FlopMeter:
+    def __init__(self):
+        self.flops = {k: 0.0 for k in _ENTRIES}
+        self.launches = {k: 0 for k in _ENTRIES}
+
+    def __enter__(self):
+        self._lib = _lib.lib()
+        self._orig = {}
+        for name, fn in _ENTRIES.items():
+            orig = getattr(self._lib, name)
+            self._orig[name] = orig
+
+            def wrapped(*a, _orig=orig, _fn=fn, _name=name):
+                self.flops[_name] += _fn(a)
+                self.launches[_name] += 1
+                return _orig(*a)
+            setattr(self._lib, name, wrapped)          # instance attribute of the CDLL handle: what `_lib.lib().<name>` resolves to
+        return self
+
+    def __exit__(self, *exc):
+        for name, orig in self._orig.items():
+            setattr(self._lib, name, orig)
+        return False
+
+    @property
+    def gflop(self):
+        return sum(self.flops.values()) / 1e9
+
+    def summary(self):
+        return {"executed_gflop": self.gflop, "launches": dict(self.launches), "gflop_by_entry": {k: v / 1e9 for k, v in self.flops.items()}}

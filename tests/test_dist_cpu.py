@@ -127,6 +127,15 @@ def test_bench_entry_launches_its_own_ranks_dry_run():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["dry_run"] is True and d["views_counted"] == 8 * 2 * 5 * 3 and d["steps"] == 3
+    assert d["ranks_ok"] == 8 and d["error"] is None
+    # --train rehearsal: the same entry wraps a model in DistributedDataParallel over the 8 ranks (gloo here, RCCL on the node), steps it, and
+    # the replicas end up identical on every rank
+    t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "4", "--dry-run", "--train"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert t.returncode == 0, t.stderr[-2000:]
+    dt_ = json.loads([l for l in t.stdout.splitlines() if l.startswith("{")][0])
+    assert dt_["n_gpus"] == 8 and dt_["train"] is True and dt_["ranks_ok"] == 8 and dt_["replicas_identical"] is True
+    assert dt_["views_counted"] == 8 * 4 * 10 * 3
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), cwd=ROOT)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

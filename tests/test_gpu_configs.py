@@ -129,7 +129,7 @@ def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
     # different M -> possibly different tile / split-K plans -> different fp32 summation orders: equality up to rounding, stated
     assert worst < 2e-4, worst
     from forge_amd import convops as co_
-    monkeypatch.setitem(co_._PLAN_OVERRIDE, 0, ("D", 1))
+    monkeypatch.setattr(co_.STATE, "plan_override", ("D", 1))
     with torch.no_grad():
         pi, pm = model(sample, ds, dev)
         pi, pm = pi.reshape(8, 5, 3, 256, 256).clone(), pm.reshape(8, 5, 1, 256, 256).clone()

@@ -201,7 +201,8 @@ def test_bench_entry_two_ranks_on_the_shared_gpu():
     lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d and d["ranks_ok"] == 2 and not d["errors"]
+    assert d["strong_scaling"]["total_scenes"] == 8 and d["strong_scaling"]["scenes_per_gpu"] == 4 and d["strong_scaling"]["ranks_ok"] == 2
     assert abs(d["value"] - 2 * 5 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]          # whole-job views / max-over-ranks time
 
 
@@ -339,14 +340,19 @@ def test_joint_finetune_step_ray_sharded_two_ranks_equal_one_process():
     import numpy as np
     res = _spawn2(_joint_worker, timeout=600)
     ref_loss, ref_terms, ref_g = _joint_step(torch.device("cuda:0"), False)
+    _, _, ref_g2 = _joint_step(torch.device("cuda:0"), False)
+    rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-20))
     for r in (0, 1):
         loss, terms, g = res[r]
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (r, loss, ref_loss)
         for k, v in ref_terms.items():
             assert abs(terms[k] - v) <= 1e-5 * max(1.0, abs(v)), (r, k)
         for k, ref in ref_g.items():
-            rel = float(np.linalg.norm((g[k] - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-20))
-            assert rel <= 2e-4, (r, k, rel)
+            # the step's parameter gradients are not bit-reproducible run to run (fp32 atomics in the ray-march / weight-gradient kernels feed
+            # ill-conditioned sums: tools/debug/joint_shard_noise.py measures 3e-5 ... 4e-3 relative L2 between two SINGLE-process runs), so the
+            # bound is that measured noise floor, not zero; the exact hand-over (d volume, d cameras at 1e-5) is pinned by the test above
+            floor = rel(ref_g2[k], ref)
+            assert rel(g[k], ref) <= max(5e-4, 5.0 * floor), (r, k, rel(g[k], ref), floor)
 
 
 def _syncbn_worker(rank, world, port, q):
@@ -403,3 +409,28 @@ def test_hip_sync_batchnorm_two_ranks_equal_one_process_batch():
     for r in (0, 1):
         assert np.abs(res[r]["rm"] - bn.running_mean.cpu().numpy()).max() < 1e-6
         assert np.abs(res[r]["rv"] - bn.running_var.cpu().numpy()).max() < 1e-6
+
+
+def test_bench_train_mode_two_ranks_and_n1_paths_agree():
+    """(i) `bench.py --train --gpus 2` - FORGE_poseEstimator3D under SyncBatchNorm (HIP kernels) + DDP on two ranks
+    sharing the GPU - prints one line with n_gpus = 2, both ranks ok; (ii) the N = 1 line is the same measurement whether bench.py runs
+    plainly or under torch.distributed.run with one rank (same views counted, values within the noise of a 3-step run)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    tr = subprocess.run([sys.executable, bench, "--gpus", "2", "--train", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=1200,
+                        env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=ROOT)
+    assert tr.returncode == 0, tr.stderr[-3000:]
+    d = json.loads([l for l in tr.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["ranks_ok"] == 2 and not d["errors"] and d["value"] > 0 and d["config"]["global_batch"] == 2
+    quick = ["--steps", "3", "--warmup", "1", "--no-microbench", "--no-cpu-baseline", "--no-extra"]
+    plain = subprocess.run([sys.executable, bench, "--gpus", "1"] + quick, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    port = _free_port()
+    launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                               "--master-port", str(port), bench, "--gpus", "1"] + quick, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert launched.returncode == 0, launched.stderr[-2000:]
+    a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]) for r in (plain, launched))
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
+    assert abs(a["value"] - b["value"]) < 0.15 * a["value"], (a["value"], b["value"])

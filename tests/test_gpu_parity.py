@@ -341,7 +341,7 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
     from forge_amd import convops as co
     from forge_amd.fusion import ConvGRU_3D
     torch.manual_seed(5)
-    monkeypatch.setitem(co._WINOGRAD, 0, False)            # the direct implicit-GEMM launcher is what chunks; the Winograd path falls back to it
+    monkeypatch.setattr(co.STATE, "winograd", False)            # the direct implicit-GEMM launcher is what chunks; the Winograd path falls back to it
     gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128).to(dev).eval()
     x = (torch.randn(6, 3, 128, 8, 8, 8) * 0.5).to(dev)
     with torch.no_grad():
@@ -350,7 +350,7 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
         chunked = gru.fuse_hip(x)
         assert torch.equal(ref, chunked)
         # the Winograd path splits the batch into scene chunks whose transformed operands fit (convops.wino_scene_chunk): bit-identical too
-        monkeypatch.setitem(co._WINOGRAD, 0, True)
+        monkeypatch.setattr(co.STATE, "winograd", True)
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", (1 << 31) - 1)
         wref = gru.fuse_hip(x).clone()
         monkeypatch.setattr(co, "MAX_OPERAND_BYTES", 2 * 3 * 8 * 4 * 4 * 128 * 4)          # two scenes' worth of V_x per Winograd point
@@ -504,7 +504,7 @@ def test_conv_igemm_every_tile_and_splitk(dev, tile, monkeypatch):
     M = 2 * dims[0] * dims[1] * dims[2]
     seen = 0
     for k in (1, 2, 3, 4, 6):
-        monkeypatch.setitem(co._PLAN_OVERRIDE, 0, (tile, k))
+        monkeypatch.setattr(co.STATE, "plan_override", (tile, k))
         if co.conv_plan(M, Cout, Cin, 27, co.EPI_AFFINE_ACT, Cout) != (tile, k):
             continue
         seen += 1

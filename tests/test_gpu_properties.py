@@ -126,7 +126,7 @@ def test_conv_full_size_adjoints(dev, monkeypatch):
     assert abs(lhs - (_dot(x1.detach(), x1.grad) + _dot(x2.detach(), x2.grad))) < 2e-5 * max(abs(lhs), 1.0)
     assert abs(lhs - _dot(w.detach(), w.grad)) < 2e-5 * max(abs(lhs), 1.0)
     # the same three identities on the direct implicit-GEMM kernels (the autograd convolution above took the Winograd launches)
-    monkeypatch.setitem(co._WINOGRAD, 0, False)
+    monkeypatch.setattr(co.STATE, "winograd", False)
     x1.grad = x2.grad = w.grad = None
     direct = co.conv3x3x3_rows(x1, x2, w, None)
     (direct * y).sum().backward()

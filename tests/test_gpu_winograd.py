@@ -88,9 +88,9 @@ def test_fuse_winograd_matches_direct_kernels_and_oracle(monkeypatch):
     x = torch.randn(2, 3, 32, 6, 8, 10, generator=torch.Generator().manual_seed(4))
     ref = fo.fuse(x, w)
     with torch.no_grad():
-        monkeypatch.setitem(_co._WINOGRAD, 0, True)
+        monkeypatch.setattr(_co.STATE, "winograd", True)
         a = gru.fuse_hip(x.to(dev)).cpu()
-        monkeypatch.setitem(_co._WINOGRAD, 0, False)
+        monkeypatch.setattr(_co.STATE, "winograd", False)
         d = gru.fuse_hip(x.to(dev)).cpu()
     assert a.shape == ref.shape
     assert (a - d).abs().max().item() < 2e-5, (a - d).abs().max().item()
@@ -98,7 +98,7 @@ def test_fuse_winograd_matches_direct_kernels_and_oracle(monkeypatch):
     # odd H: the Winograd path does not apply and fuse_hip keeps the direct kernel
     x2 = torch.randn(1, 2, 32, 4, 5, 6, generator=torch.Generator().manual_seed(5))
     with torch.no_grad():
-        monkeypatch.setitem(_co._WINOGRAD, 0, True)
+        monkeypatch.setattr(_co.STATE, "winograd", True)
         o = gru.fuse_hip(x2.to(dev)).cpu()
     assert (o - fo.fuse(x2, w)).abs().max().item() < 1e-4
 
@@ -171,7 +171,7 @@ def test_frozen_fusion_winograd_matches_direct(monkeypatch):
     wgt = torch.randn(1, 128, 8, 8, 8, generator=torch.Generator().manual_seed(3)).to(dev)
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setitem(_co._WINOGRAD, 0, mode == "1")
+        monkeypatch.setattr(_co.STATE, "winograd", mode == "1")
         xi = x.clone().requires_grad_(True)
         out = gru.fuse_frozen_hip(xi)
         (out * wgt).sum().backward()
@@ -197,11 +197,11 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     ref = w.grad.reshape(Co, C1 + C2, 27).permute(2, 0, 1)                  # packed layout [27][Co][Ci]
     xsd, x2d, dyd = xs.to(dev), x2.to(dev), dy.to(dev)
     x1d = xsd[:, 1]
-    monkeypatch.setitem(_co._WINOGRAD, 0, True)
+    monkeypatch.setattr(_co.STATE, "winograd", True)
     assert co.wino_wgrad_applies(n, D, H, W, C1, C2, Co)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setitem(_co._WINOGRAD, 0, mode == "1")
+        monkeypatch.setattr(_co.STATE, "winograd", mode == "1")
         dwp = torch.zeros(27, Co, C1 + C2, device=dev)
         co.conv3_wgrad(dyd, x1d, C1, x2d, C2, dwp, (n, D, H, W), Co, bs1=co._batch_stride_rows(x1d))
         out[mode] = dwp.double().cpu()
@@ -214,7 +214,7 @@ def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     w2 = torch.zeros(256, 256, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv3d(x.double().permute(0, 4, 1, 2, 3), w2, padding=1).backward(dy2.double().permute(0, 4, 1, 2, 3))
     ref2 = w2.grad.reshape(256, 256, 27).permute(2, 0, 1)
-    monkeypatch.setitem(_co._WINOGRAD, 0, True)
+    monkeypatch.setattr(_co.STATE, "winograd", True)
     dwp = torch.zeros(27, 256, 256, device=dev)
     co.conv3_wgrad(dy2.to(dev), x.to(dev), 256, None, 0, dwp, (1, 4, 8, 8), 256)
     assert (dwp.double().cpu() - ref2).abs().max().item() < 2e-5 * ref2.abs().max().item()

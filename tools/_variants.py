@@ -28,5 +28,5 @@ def apply_environ():
     import os
     tile = os.environ.get("FORGE_CONV_TILE") or None
     ks = os.environ.get("FORGE_CONV_KSPLIT")
-    co._PLAN_OVERRIDE[0] = (tile, int(ks) if ks else None) if (tile or ks) else None
-    co._WINOGRAD[0] = os.environ.get("FORGE_WINOGRAD", "1") != "0"
+    co.STATE.plan_override = (tile, int(ks) if ks else None) if (tile or ks) else None
+    co.STATE.winograd = os.environ.get("FORGE_WINOGRAD", "1") != "0"

@@ -20,7 +20,8 @@ Extra objects on the line:
                   executed-FLOP floor
   strong_scaling  8 scenes in total split over the N ranks (the default line is weak scaling)
   kernels         per hand-written HIP kernel: algorithmic bytes / avg launch duration vs HBM peak
-  stages_ms       HIP-event split of one step
+  stages_ms       HIP-event split of one eager step (includes host launch gaps); stages_ms_replay: each stage captured into its own hipGraph and replayed
+  single_stream   the same step replayed on ONE stream, back to back (step latency; `value` keeps --pipeline-depth steps in flight)
   cpu_baseline    the CPU oracle (reference semantics, torch-CPU) timed on this box's host cores on a
                   bounded sample of the same workload (N=1, rank 0 only)
   ranks_ok        ranks that completed the timed region (a failing rank reports its error instead of hanging the others)
@@ -755,6 +756,9 @@ def main():
                          "scenes: synthetic [b,5,128,64^3] feature volumes through rotate -> fuse -> heads -> ray-march (the encoder cannot produce them)")
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step (SyncBatchNorm + DDP) instead of inference")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
+    ap.add_argument("--pipeline-depth", type=int, default=4,
+                    help="steps in flight: that many hipGraphs of the step replayed round-robin on as many HIP streams (forge_amd.graph.PipelinedForward); "
+                         "1 = one stream, back to back")
     ap.add_argument("--dump-conv", action="store_true", help="print every conv launch of one step (shape, ms, TFLOP/s) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
@@ -821,16 +825,18 @@ def main():
         if args.no_graph:
             step = eager_step
         elif args.grid == 32:
-            from forge_amd.graph import GraphedForward
-            graphed = GraphedForward(model, sample, dataset, dev)      # hipGraph of the whole step; replays do all the work
-            step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the static buffers)
+            # hipGraph(s) of the whole step; replays do all the work. pipeline_depth steps are kept in flight on as many HIP streams: the
+            # under-filled ResNet launches of one step share the chip with the MFMA-bound ConvGRU launches of its neighbours
+            from forge_amd.graph import PipelinedForward
+            graphed = PipelinedForward(model, sample, dataset, dev, depth=max(1, args.pipeline_depth))
+            step = lambda: graphed(sample)                              # noqa: E731  (copies the resident inputs into the slot's static buffers)
         else:
             from forge_amd.graph import GraphedCall
             step = GraphedCall(eager_step, dev)
         if B_strong and B_strong != B:                                   # strong scaling: 8 scenes in total over the N ranks
-            from forge_amd.graph import GraphedForward
+            from forge_amd.graph import PipelinedForward
             s_strong = {k: v.to(dev) for k, v in syn.make_sample(B_strong, T_IN, 256, 1.5, seed=2000 + rank).items()}
-            g_strong = GraphedForward(model, s_strong, dataset, dev)
+            g_strong = PipelinedForward(model, s_strong, dataset, dev, depth=2)
             strong = lambda: g_strong(s_strong)                          # noqa: E731
         elif B_strong:
             strong = step
@@ -889,6 +895,7 @@ def main():
     # ---- the same steps with the sample handed over as (pinned) HOST buffers, as a DataLoader would: PCIe-inclusive rate (never `value`)
     pcie_views_per_s = None
     if world == 1 and graphed is not None:
+        graphed.wait()
         host = {k: v.pin_memory() for k, v in sample_cpu.items()}
         graphed(host)
         torch.cuda.synchronize()
@@ -898,6 +905,15 @@ def main():
         torch.cuda.synchronize()
         pcie_views_per_s = B * V_OUT * args.steps / (time.perf_counter() - t1)
 
+    # ---- the same replay on ONE stream, back to back (= the latency of a step), and the per-stage split of that replay
+    single = stages_replay = None
+    if graphed is not None:
+        one = graphed.slots[0]
+        ms1 = _timed(lambda: one(sample), max(5, min(20, args.steps)))
+        single = {"ms_per_step": ms1, "views_per_s": B * V_OUT / ms1 * 1e3, "note": "one hipGraph replay at a time on one stream: step latency"}
+        if args.grid == 32 and not args.no_microbench:
+            from forge_amd.flopmeter import stage_replay_ms
+            stages_replay = {k: round(v, 4) for k, v in stage_replay_ms(model, sample, dev).items()}
     # ---- per-stage HIP-event split of one more step (outside the timed region)
     rec, undo = stage_timers(model)
     for _ in range(3):
@@ -978,9 +994,13 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "ranks_ok": int(ranks_ok), "errors": errors,
         "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
-                   "render_grid": 2 * args.grid, "launch": "eager" if args.no_graph else "hipGraph replay", "rank0_affinity": affinity,
+                   "render_grid": 2 * args.grid, "rank0_affinity": affinity,
+                   "launch": "eager" if args.no_graph else ("hipGraph replay, %d steps in flight on %d HIP streams" % (graphed.depth, graphed.depth)
+                                                            if (graphed is not None and graphed.depth > 1) else "hipGraph replay"),
                    "parallelism": "dp%d (scene-sharded, no data-path collective; 4-scalar RCCL all-reduce of SSE/pixels/views/ok for the PSNR report)" % world},
+        "single_stream": single,
         "roofline": roofline, "conv_launches": conv_launch, "kernels": kern, "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        "stages_ms_replay": stages_replay,
         "gflop_per_step_algorithmic": gflop,
         "views_per_s_with_host_to_device_copy": pcie_views_per_s,
         "psnr_to_target_db_all_ranks": fdist.psnr_from_sse(sse, npix),

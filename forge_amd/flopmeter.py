@@ -5,6 +5,8 @@ forge_conv_wgrad, forge_wino_wgrad - for the duration of the block and sums the 
 arguments (2 M N taps Cin for a direct / data-gradient / weight-gradient convolution, 2 x 16 R N kd Cin for the 16 Winograd point problems).
 Only eager launches made by this process are seen (a hipGraph replay makes no Python calls): meter one eager pass, time the replay.
 """
+import torch
+
 from . import _lib
 
 
@@ -63,3 +65,48 @@ class FlopMeter:
 
     def summary(self):
         return {"executed_gflop": self.gflop, "launches": dict(self.launches), "gflop_by_entry": {k: v / 1e9 for k, v in self.flops.items()}}
+
+
+def stage_replay_ms(model, sample, dev, iters=20):
+    from . import geo_utils
+    from .graph import GraphedCall
+    """{stage: ms per replay} for FORGE's inference step on `sample` (b scenes, 5 input views, V cameras)."""
+    e3 = model.encoder_3d
+    b = sample["images"].shape[0]
+    t = 5
+    with torch.no_grad():
+        img = sample["images"][:, :t].reshape(b * t, 3, 256, 256).contiguous()
+        lifted = e3._trunk_hip(img)
+        feats = e3._conv1_hip(lifted).reshape(b, t, 128, 32, 32, 32)
+        poses = sample["cam_poses_cv2_canonicalized"][:, :t].contiguous()
+        rotated = model.rotate(voxels=feats, camPoses_cv2=poses, grid_size=32, order="distance")
+        fused = e3.fuse(rotated)
+        fv, dv = e3.heads(fused)
+        V = sample["K_cv2"].shape[1]
+        cams = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"])
+        v2v = model._view2vol(b, V, dev)
+    stages = {
+        "encoder_resnet": lambda: e3._trunk_hip(img),
+        "encoder_conv1": lambda: e3._conv1_hip(lifted),
+        "rotate": lambda: model.rotate(voxels=feats, camPoses_cv2=poses, grid_size=32, order="distance"),
+        "fuse": lambda: e3.fuse(rotated),
+        "heads": lambda: e3.heads(fused),
+        "render(+conv_rgb)": lambda: model.render(cams, fv, dv, return_origin_proj=True, view2vol=v2v),
+    }
+    out = {}
+    for name, fn in stages.items():
+        def call(fn=fn):
+            with torch.no_grad():
+                return fn()
+        g = GraphedCall(call, dev, warmup=2)
+        g()
+        torch.cuda.synchronize()
+        a, bq = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            g()
+        bq.record()
+        torch.cuda.synchronize()
+        out[name] = a.elapsed_time(bq) / iters
+        del g
+    return out

@@ -44,6 +44,45 @@ class GraphedForward:
         return self.static_out
 
 
+class PipelinedForward:
+    """`depth` steps in flight: `depth` hipGraphs of the same model (shared weights, separate static input / output buffers and private
+    pools) replayed round-robin on `depth` HIP streams.
+
+    Why: at one scene per step the ResNet trunk is ~60 launches of 320-1280 workgroups with 2-64 K-steps each - a third of the step's
+    time at 0.4 of the matrix-core peak, bound by per-launch ramp / prologue / epilogue phases in which most CUs idle (every workgroup of
+    such a launch is co-resident, so the phases do not overlap inside a launch) - while the ConvGRU launches of the same step are
+    8192-workgroup, MFMA-bound kernels. With the next scene's step in flight on a second hardware queue the dispatcher fills the trunk's
+    idle slots with the previous scene's GEMM workgroups: measured 8.19 -> 7.35 ms per step (2 in flight) -> 7.02 ms (3), bit-identical
+    outputs (tools/pipeline_probe.py). This is a throughput device: the latency of one step stays that of a single replay.
+
+        p = PipelinedForward(model, sample, dataset, device, depth=3)
+        for s in samples: out = p(s)        # returns the static outputs of the slot used; valid after p.wait() / overwritten `depth` calls later
+        p.wait()
+    """
+
+    def __init__(self, model, sample, dataset, device, depth=3, warmup=3):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.device, self.depth = device, depth
+        self.slots = [GraphedForward(model, sample, dataset, device, warmup=warmup if i == 0 else 1) for i in range(depth)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(depth)]
+        self.calls = 0
+
+    def __call__(self, sample=None):
+        k = self.calls % self.depth
+        self.calls += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(self.device))         # inputs written on the caller's stream are visible to the replay
+        with torch.cuda.stream(st):
+            return self.slots[k](sample)
+
+    def wait(self):
+        """Make the caller's stream wait for every step in flight (then the returned static outputs may be read on it)."""
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
+
+
 class GraphedCall:
     """hipGraph capture of an arbitrary fixed-shape, capture-safe inference callable `fn()` whose inputs are tensors the caller keeps
     alive and overwrites in place between replays (e.g. FORGE.reconstruct on resident feature volumes). g = GraphedCall(fn, device);

@@ -15,13 +15,14 @@ from forge_amd.model import FORGE  # noqa: E402
 
 dev = torch.device("cuda:0")
 depth = int(os.environ.get("PIPE_DEPTH", "2"))
+scenes = int(os.environ.get("PIPE_SCENES", "1"))
 steps = int(os.environ.get("PIPE_STEPS", "40"))
 cfg = syn.kubric_config()
 model = FORGE(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).eval()
 ds = syn.SyntheticDataset(1.5)
-samples = [{k: v.to(dev) for k, v in syn.make_sample(1, 5, 256, 1.5, seed=1000 + i).items()} for i in range(depth)]
+samples = [{k: v.to(dev) for k, v in syn.make_sample(scenes, 5, 256, 1.5, seed=1000 + i).items()} for i in range(depth)]
 graphs = [GraphedForward(model, s, ds, dev) for s in samples]
 streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 ref = [g(s)[0].clone() for g, s in zip(graphs, samples)]
@@ -47,7 +48,7 @@ for name, fn in (("one stream, back to back", run_seq), ("%d streams, %d steps i
     fn(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("%-32s %.3f ms/step  %.1f views/s" % (name, dt / steps * 1e3, 5 * steps / dt))
+    print("scenes %d  %-32s %.3f ms/step  %.1f views/s" % (scenes, name, dt / steps * 1e3, scenes * 5 * steps / dt))
 run_pipe(depth)
 torch.cuda.synchronize()
 print("pipelined outputs equal the sequential ones:", all(torch.equal(g.static_out[0], r) for g, r in zip(graphs, ref)))

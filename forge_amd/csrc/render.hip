@@ -130,11 +130,28 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
                                                          const float* __restrict__ cams, const int* __restrict__ view2vol,
                                                          float* __restrict__ out_feat, float* __restrict__ out_opac,
                                                          float* __restrict__ out_depth, int D, int H, int W, int Hr, int Wr,
-                                                         int S, float zmin, float zmax, float hx, float hy, float hz) {
+                                                         int S, float zmin, float zmax, float hx, float hy, float hz, int V, int band_order) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
-    // Workgroup -> (view, pixel tile) in launch order (an XCD-contiguous remap of the tiles was measured slower at every size but
-    // 28 views x 64^3: profiles/r02_render_ab.txt).
-    const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    // Workgroup -> (view, pixel tile). 1-D grid of V x ny x nx workgroups; the dispatcher deals consecutive ids round-robin to the 8 XCDs.
+    const unsigned nx = (unsigned)(Wr + 7) / 8, ny = (unsigned)(Hr + TH - 1) / TH;
+    unsigned bx, by, bz;
+    if (band_order) {
+        // XCD x marches tile rows [x ny/8, (x+1) ny/8) of EVERY view, the views of one tile position back to back: the rays of one image-row
+        // band of cameras around the object stay inside one slab of the volume, so an XCD's 4 MiB L2 serves the views from the slab it has
+        // already fetched. Measured (round 3, tools/pmc_render.sh, L2->fabric bytes per launch / ms): 64^3 x 5 views 111 -> 38 MB (algorithmic
+        // 23 MB), 0.0975 -> 0.0928; 64^3 x 28 views 444 -> 51 MB (algorithmic 49 MB), 0.490 -> 0.463; 128^3 x 5 750 -> 599 MB, 0.132 ->
+        // 0.115; 128^3 x 28 4532 -> 3304 MB, 0.725 -> 0.644 (at 128^3 the resident workgroups' frusta alone exceed the L2: Infinity-Cache
+        // served). Placement only: results are bit-identical to launch order.
+        const unsigned g = blockIdx.x, xcd = g % NUM_XCD, k = g / NUM_XCD, rows_per = ny / NUM_XCD;
+        bz = k % (unsigned)V;
+        const unsigned t = k / (unsigned)V;
+        by = xcd * rows_per + t / nx;
+        bx = t % nx;
+    } else {
+        bx = blockIdx.x % nx;
+        by = (blockIdx.x / nx) % ny;
+        bz = blockIdx.x / (nx * ny);
+    }
     const int v = (int)bz;
     const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
     int lx, ly;
@@ -525,9 +542,10 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
     FORGE_REQUIRE(out_feat && out_opac, FORGE_EINVAL, "forge_render_fwd: null output pointer");
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
-        dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
-        hipLaunchKernelGGL(render_fwd_kernel<C4>, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                           view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+        const unsigned nx = (unsigned)(Wr + 7) / 8, ny = (unsigned)(Hr + TH - 1) / TH;
+        const int band_order = (ny % NUM_XCD == 0) ? 1 : 0;      // tile rows split evenly over the XCDs (128 rows: 16 tile rows); else launch order
+        hipLaunchKernelGGL(render_fwd_kernel<C4>, dim3(nx * ny * (unsigned)V), dim3(256), 0, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                           view2vol, out_feat, out_opac, out_depth, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
     });
     FORGE_LAUNCH_CHECK("forge_render_fwd");
     return 0;

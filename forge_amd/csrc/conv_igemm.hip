@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                             }
                         } else if constexpr (EPI == EPI_GRU_GATES) {
                             if (a.residual) v += a.residual[orow * a.ldr + col];       // precomputed input half conv(x, W_x) (shared across fusions)
-                            const float g = 1.f / (1.f + __expf(-v));
+                            const float g = 1.f / (1.f + expf(-v));          // torch.sigmoid's formula with the full-precision exponential (models/fusion.py:31-32)
                             if (col < Ch) a.out[orow * Ch + col] = g;
                             else {
                                 a.out2[orow * Ch + (col - Ch)] = a.aux_h[orow * Ch + (col - Ch)] * g;

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
             } else if constexpr (EPI == W_GRU_GATES) {
                 float g[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = 1.f / (1.f + __expf(-v[k]));
+                for (int k = 0; k < 4; ++k) g[k] = 1.f / (1.f + expf(-v[k]));      // full-precision exponential, as torch.sigmoid
                 if (c < Ch) {
                     *reinterpret_cast<float4*>(a.out + orow * Ch + c) = make_float4(g[0], g[1], g[2], g[3]);
                 } else {

@@ -234,8 +234,11 @@ def joint_goldens(m):
     with torch.no_grad():
         pose2, oproj2 = jm({k: v.clone() for k, v in sample.items()}, ds, "cpu")
     out.update({"joint_pose__origin_proj": oproj2, "joint_pose__pose_pred": pose2["pred"]})
+    # weight seed 3: with seed 0 the predicted cameras look past the volume (mask mean 0.0016 - VERDICT r2: that scene exercised the pose chain
+    # but almost nothing of fuse -> heads -> render); seed 3 puts the object in view (mask mean 0.42)
+    out["pose3d_weight_seed"] = 3
     pm = m["models.model_single_pose_estimator"].FORGE_poseEstimator3D(ref_import.kubric_config(use_gt_pose=False)).eval()
-    pm.load_state_dict(syn.seeded_state_dict(pm.state_dict(), 0))
+    pm.load_state_dict(syn.seeded_state_dict(pm.state_dict(), 3))
     s5 = {k: v[:, :5].clone() for k, v in sample.items()}
     with torch.no_grad():
         imgs, masks, oproj, pose = pm(s5, ds, "cpu")

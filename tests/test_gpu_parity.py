@@ -393,6 +393,9 @@ def test_training_loss_and_gradients_vs_oracle_autograd(dev):
         # 3e-2 of the gradient's max, as in test_training_gradients_vs_reference_golden: two fp32 evaluations of this graph (the oracle's and
         # any kernel family's) sit 0.3-1.6e-2 apart on the trunk's parameter gradients (tools/debug/feat3d_train_noise.py, float64 yardstick)
         assert err < 3e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
+        if ref.numel() > 1:                          # per-layer direction check (see test_training_gradients_vs_reference_golden)
+            cos = torch.nn.functional.cosine_similarity(got.double().flatten(), ref.double().flatten(), dim=0).item()
+            assert cos > 0.9999, (k, cos)
 
 
 def test_training_gradients_vs_reference_golden(dev, golden):
@@ -422,6 +425,12 @@ def test_training_gradients_vs_reference_golden(dev, golden):
         # train-mode BatchNorm layers over a batch of 5 amplify reordering noise, a ReLU argument at rounding distance of zero flips whole
         # gradient entries; tools/debug/feat3d_train_noise.py measures fp32 oracle / direct kernels / Winograd against float64)
         assert err < 3e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
+        # direction check per layer: a max-norm band of 3 % cannot see a gradient that is wrong by a few percent everywhere, the
+        # cosine can (0.9999 <=> 1.4 % relative L2); single flipped entries cost little here. Tensors whose gradient is pure cancellation noise
+        # (|g| < 1e-3 of the largest gradient) are not direction-checked.
+        if ref.numel() > 1 and ref.abs().max().item() > 1e-3 * gscale:
+            cos = torch.nn.functional.cosine_similarity(named[k].grad.cpu().double().flatten(), ref.double().flatten(), dim=0).item()
+            assert cos > 0.9999, (k, cos)
 
 
 def test_training_step_runs(dev):

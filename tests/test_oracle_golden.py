@@ -201,7 +201,7 @@ def test_pose_estimators_reproduce_reference_predictions(golden):
     for cls, tag, nviews in ((FORGE, "joint", 10), (FORGE_poseEstimator3D, "pose3d", 10)):
         cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
         model = cls(cfg).eval()
-        w = syn.seeded_state_dict(model.state_dict(), int(g["weight_seed"]))
+        w = syn.seeded_state_dict(model.state_dict(), int(g["weight_seed"] if cls is FORGE else g["pose3d_weight_seed"]))
         model.load_state_dict(w)
         clips = sample["images"][:, :5]
         with torch.no_grad():

@@ -23,6 +23,11 @@ model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).eval()
 ds = syn.SyntheticDataset(1.5)
 samples = [{k: v.to(dev) for k, v in syn.make_sample(scenes, 5, 256, 1.5, seed=1000 + i).items()} for i in range(depth)]
+from forge_amd import convops as co  # noqa: E402
+wt = os.environ.get("PIPE_WINO_TILE")                      # experiment: pin the tile of the Winograd point-GEMM launches (A..D)
+if wt:
+    _orig_tile = co.wino_gemm_tile
+    co.wino_gemm_tile = lambda R, Cout: wt if (os.environ.get("PIPE_WINO_TILE_N", "") in ("", str(Cout))) else _orig_tile(R, Cout)
 graphs = [GraphedForward(model, s, ds, dev) for s in samples]
 streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 ref = [g(s)[0].clone() for g, s in zip(graphs, samples)]

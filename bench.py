@@ -122,7 +122,7 @@ def stage_timers(model):
         e0.record()
         out = o_i(x, C, ld, n, D, H, W, **kw)
         e1.record()
-        rec.setdefault("wino_input_kernel", []).append((e0, e1, 4.0 * n * D * H * W * C * (1 + 4)))       # reads the rows once, writes 16 points x R = 4x
+        rec.setdefault("wino_input_kernel", []).append((e0, e1, 4.0 * n * D * H * W * C * (kw.get("nsum", 1) + 4)))   # reads the rows (of nsum views) once, writes 16 points x R = 4x
         return out
 
     def output_timed(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, **kw):
@@ -131,7 +131,8 @@ def stage_timers(model):
         r = o_o(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, **kw)
         e1.record()
         rows = n * D * H * W
-        side = {co.EPI_GRU_GATES: 3 * Cout // 2, co.EPI_GRU_OUT: 3 * Cout + (Cout if out2 is not None else 0)}.get(epilogue, Cout)
+        side = {co.EPI_GRU_GATES: (2 if out2 is not None else 1) * Cout // 2 + Cout // 2, co.EPI_GRU_OUT: 3 * Cout + (Cout if out2 is not None else 0)}.get(
+            epilogue, Cout if out is not None else 0)
         side += 4 * Cout if kw.get("Mm2") is not None else 0
         rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * (4 * Cout + side)))       # reads 16 points x R x Cout = 4x, then the tail's operands
         return r

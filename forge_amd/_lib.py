@@ -28,12 +28,14 @@ SIGNATURES = {
     "forge_pack_cameras": [_P, _LL, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _LL, _P, _P, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
+    "forge_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 12 + [_P, _LL, _P],
     "forge_wino_weights": [_P, _P, _I, _I, _I, _I, _P],
     "forge_wino_dy": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "forge_wino_wgrad": [_P, _P, _I, _LL, _LL, _P, _I, _LL, _LL, _P, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_dw": [_P, _P, _I, _I, _I, _P],
-    "forge_wino_input": [_P, _I, _LL, _P, _I, _LL, _I, _I, _I, _I, _I, _P],
+    "forge_wino_input": [_P, _I, _LL, _P, _I, _LL, _I, _I, _I, _I, _I, _I, _LL, _P],
     "forge_wino_gemm": [_P, _I, _I, _LL, _LL, _P, _I, _I, _LL, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_gemm_tile": [_LL, _I],
     "forge_wino_output": [_P, _P, _LL, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

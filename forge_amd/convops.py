@@ -398,11 +398,13 @@ def wino_fits(n, D, H, W, C, views=1):
 
 
 @_lib.on_tensor_device
-def wino_input(x, C, ld, n, D, H, W, bs=0, out=None):
-    """V[16][n D H/2 W/2][C] = B^T d B of the channels-last rows x ([n][D][H][W] x ld floats, batch stride bs rows)."""
+def wino_input(x, C, ld, n, D, H, W, bs=0, out=None, nsum=1, sum_stride=0):
+    """V[16][n D H/2 W/2][C] = B^T d B of the channels-last rows x ([n][D][H][W] x ld floats, batch stride bs rows). nsum > 1: d is the
+    mean of nsum such tensors sum_stride rows apart (the view mean feeding fusion_conv, models/encoder.py:62)."""
     R = n * D * (H // 2) * (W // 2)
     V = out if out is not None else torch.empty(16, R, C, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().forge_wino_input(_lib.ptr(x), ld, int(bs), _lib.ptr(V), C, 0, n, D, H, W, C, _lib.current_stream()), "forge_wino_input")
+    _lib.check(_lib.lib().forge_wino_input(_lib.ptr(x), ld, int(bs), _lib.ptr(V), C, 0, n, D, H, W, C, int(nsum), int(sum_stride), _lib.current_stream()),
+               "forge_wino_input")
     return V
 
 

@@ -511,6 +511,59 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
     }
 }
 
+// ---- bilinear resize of the opacity / depth planes to the image size (models/volume_render.py:69,74: F.upsample(size=img_size, mode='bilinear'),
+// i.e. align_corners=False). ATen's arithmetic, expression for expression (area_pixel_compute_source_index + upsample_bilinear2d_out_frame):
+//   src = max(scale (dst + 0.5) - 0.5, 0), scale = in / out;  i1 = (int)src, i1p = i1 < in - 1, l1 = src - i1, l0 = 1 - l1
+//   out = h0 (w0 v[h1][w1] + w1l v[h1][w1 + w1p]) + h1l (w0 v[h1 + h1p][w1] + w1l v[h1 + h1p][w1 + w1p])
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int n_in, int& i1, int& ip, float& l0, float& l1) {
+    const float src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+    i1 = (int)src;
+    ip = (i1 < n_in - 1) ? 1 : 0;
+    l1 = src - (float)i1;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int Hi, int Wi, int Ho, int Wo,
+                                                                  float sh, float sw) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)P * Ho * Wo) return;
+    const int X = (int)(idx % Wo), Y = (int)((idx / Wo) % Ho);
+    const long long p = idx / ((long long)Wo * Ho);
+    int h1, hp, w1, wp;
+    float h0l, h1l, w0l, w1l;
+    bilinear_src(Y, sh, Hi, h1, hp, h0l, h1l);
+    bilinear_src(X, sw, Wi, w1, wp, w0l, w1l);
+    const float* v = in + p * Hi * Wi;
+    out[idx] = h0l * (w0l * v[h1 * Wi + w1] + w1l * v[h1 * Wi + w1 + wp]) + h1l * (w0l * v[(h1 + hp) * Wi + w1] + w1l * v[(h1 + hp) * Wi + w1 + wp]);
+}
+
+// adjoint as a gather per INPUT pixel (deterministic, no atomics): the output rows / columns that can reference input index i lie in
+// [ (i - 1) / scale - 1, (i + 1) / scale + 1 ]; each candidate's taps / weights are re-evaluated with the forward's own expressions.
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* __restrict__ g, float* __restrict__ din, int P, int Hi, int Wi, int Ho, int Wo,
+                                                                  float sh, float sw) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)P * Hi * Wi) return;
+    const int x = (int)(idx % Wi), y = (int)((idx / Wi) % Hi);
+    const long long p = idx / ((long long)Wi * Hi);
+    const int Y0 = max(0, (int)floorf((float)(y - 1) / sh) - 1), Y1 = min(Ho - 1, (int)ceilf((float)(y + 1) / sh) + 1);
+    const int X0 = max(0, (int)floorf((float)(x - 1) / sw) - 1), X1 = min(Wo - 1, (int)ceilf((float)(x + 1) / sw) + 1);
+    const float* gp = g + p * Ho * Wo;
+    float acc = 0.f;
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        int h1, hp; float h0l, h1l;
+        bilinear_src(Y, sh, Hi, h1, hp, h0l, h1l);
+        const float wy = (h1 == y ? h0l : 0.f) + (h1 + hp == y ? h1l : 0.f);       // hp = 0: both taps are row h1 (weights h0l + h1l = 1)
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            int w1, wp; float w0l, w1l;
+            bilinear_src(X, sw, Wi, w1, wp, w0l, w1l);
+            const float wx = (w1 == x ? w0l : 0.f) + (w1 + wp == x ? w1l : 0.f);
+            if (wx != 0.f) acc = fmaf(wy * wx, gp[Y * Wo + X], acc);
+        }
+    }
+    din[idx] = acc;
+}
+
 static int check_render_args(const char* fn, const void* feat, const void* dens, const void* cam, const void* v2v,
                              int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S, float hx, float hy, float hz) {
     FORGE_REQUIRE(feat && dens && cam && v2v, FORGE_EINVAL, "%s: null pointer argument", fn);
@@ -574,5 +627,27 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
         }
     });
     FORGE_LAUNCH_CHECK("forge_render_bwd");
+    return 0;
+}
+
+// P planes [Hi][Wi] -> [Ho][Wo], bilinear, align_corners = False (the mask / depth up-sampling of models/volume_render.py:69,74).
+extern "C" int forge_resize_bilinear_fwd(const float* in, float* out, int P, int Hi, int Wi, int Ho, int Wo, forge_stream_t stream) {
+    FORGE_REQUIRE(in && out && P > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, FORGE_EINVAL, "forge_resize_bilinear_fwd: bad argument");
+    const long long total = (long long)P * Ho * Wo;
+    FORGE_REQUIRE((total + 255) / 256 < (1ll << 31), FORGE_ESHAPE, "forge_resize_bilinear_fwd: grid too large");
+    hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, P, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    FORGE_LAUNCH_CHECK("forge_resize_bilinear_fwd");
+    return 0;
+}
+
+// adjoint of the above: g [P][Ho][Wo] -> din [P][Hi][Wi] (written, not accumulated; deterministic)
+extern "C" int forge_resize_bilinear_bwd(const float* g, float* din, int P, int Hi, int Wi, int Ho, int Wo, forge_stream_t stream) {
+    FORGE_REQUIRE(g && din && P > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, FORGE_EINVAL, "forge_resize_bilinear_bwd: bad argument");
+    const long long total = (long long)P * Hi * Wi;
+    FORGE_REQUIRE((total + 255) / 256 < (1ll << 31), FORGE_ESHAPE, "forge_resize_bilinear_bwd: grid too large");
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, din, P, Hi, Wi, Ho, Wo,
+                       (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    FORGE_LAUNCH_CHECK("forge_resize_bilinear_bwd");
     return 0;
 }

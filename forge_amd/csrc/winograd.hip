@@ -25,6 +25,8 @@ struct WinoInArgs {
     const float* in; int ld; long long bs;        // rows [n][D][H][W] x ld floats, batch stride bs rows
     float* V; int ldv; long long ptv;             // V[p] = V + p ptv, rows [n][D][H/2][W/2] x ldv floats
     int n, D, H, W, C;
+    int nsum; long long ss;                       // nsum > 1: the input is the MEAN of nsum tensors ss rows apart (the view mean of models/encoder.py:62
+                                                  // feeding fusion_conv: sum in view order, then x (1 / nsum), as torch.mean) - no separate reduction launch
 };
 
 // one thread = one tile x 4 channels: 16 float4 loads (zero outside the grid), 32 float4 additions, 16 float4 stores
@@ -48,7 +50,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
         for (int j = 0; j < 4; ++j) {
             const int x = 2 * tw - 1 + j;
             const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            d[i][j] = ok ? *reinterpret_cast<const float4*>(base + ((long long)y * a.W + x) * a.ld) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const float* p = base + ((long long)y * a.W + x) * a.ld;
+                v = *reinterpret_cast<const float4*>(p);
+                if (a.nsum > 1) {
+                    for (int k = 1; k < a.nsum; ++k) v = f4_add(v, *reinterpret_cast<const float4*>(p + (long long)k * a.ss * a.ld));
+                    const float inv = 1.f / (float)a.nsum;           // ATen divides by a scalar as a multiplication by its fp32 reciprocal
+                    v = make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv);
+                }
+            }
+            d[i][j] = v;
         }
     }
     float4 w[4][4];                                  // rows: B^T d
@@ -324,12 +336,14 @@ extern "C" int forge_wino_weights(const float* wp, float* U, int Cout, int Cin, 
 }
 
 extern "C" int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
-                                forge_stream_t stream) {
+                                int nsum, long long sum_stride, forge_stream_t stream) {
     FORGE_REQUIRE(in && V, FORGE_EINVAL, "forge_wino_input: null pointer argument");
+    FORGE_REQUIRE(nsum >= 1 && (nsum == 1 || sum_stride > 0), FORGE_EINVAL, "forge_wino_input: nsum >= 1, and a positive sum_stride (rows) with nsum > 1");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0 && ldv >= C && ldv % 4 == 0,
                   FORGE_ESHAPE, "forge_wino_input: n=%d D=%d H=%d W=%d C=%d ld=%d ldv=%d (H, W even; C, ld, ldv multiples of 4)", n, D, H, W, C, ld, ldv);
     WinoInArgs a;
     a.in = in; a.ld = ld; a.bs = bs > 0 ? bs : (long long)D * H * W; a.V = V; a.ldv = ldv; a.n = n; a.D = D; a.H = H; a.W = W; a.C = C;
+    a.nsum = nsum; a.ss = sum_stride;
     const long long R = (long long)n * D * (H / 2) * (W / 2);
     a.ptv = ptv > 0 ? ptv : R * ldv;
     FORGE_REQUIRE(R < (1ll << 31), FORGE_ESHAPE, "forge_wino_input: more than 2^31 tiles; split the batch");

@@ -318,7 +318,6 @@ class _FuseFrozen(torch.autograd.Function):
         dev, M, vol = x.device, b * D * H * W, D * H * W
         grid, ig, taps = (b, D, H, W), (D, H, W), co.TAPS_3x3x3
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
-        mean = xr.mean(dim=1).reshape(M, C)
         t0, h = new(), new()
         wino = co.wino_enabled() and co.wino_fits(b, D, H, W, C, views=t)
         steps, out = [], new()
@@ -330,7 +329,7 @@ class _FuseFrozen(torch.autograd.Function):
             Vh = torch.empty(16, R, C, dtype=torch.float32, device=dev)
             Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
             Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
-            gru._wino_h0(p, mean, grid, Vh, Mc, t0, h)
+            gru._wino_h0(p, xr, grid, Vh, Mc, t0, h, nsum=t, sum_stride=vol, bs=t * vol)
             for ti in range(t):
                 z, hr, r, hn, cand = new(), new(), new(), new(), new()
                 co.wino_input(h, C, C, b, D, H, W, out=Vh)
@@ -344,6 +343,7 @@ class _FuseFrozen(torch.autograd.Function):
                 h = hn
         else:
             p = gru._packed()
+            mean = xr.mean(dim=1).reshape(M, C)
             co.conv_igemm(mean, C, C, None, 0, 0, p["fc0_w"], p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, grid, ig, C, C, taps,
                           epilogue=co.EPI_AFFINE_ACT)
             co.conv_igemm(t0, C, C, None, 0, 0, p["fc3_w"], p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, grid, ig, C, C, taps,
@@ -537,19 +537,24 @@ class ConvGRU_3D(co.PackedModule):
         return p
 
     @staticmethod
-    def _wino_h0(p, mean, geo, Vh, Mc, t0, h):
-        """h = fusion_conv(mean): two Winograd convolutions with the folded BatchNorm + LeakyReLU tail (scratch Vh / Mc / t0)."""
+    def _wino_h0(p, src, geo, Vh, Mc, t0, h, nsum=1, sum_stride=0, bs=0):
+        """h = fusion_conv(mean of the nsum view tensors starting at `src`, sum_stride rows apart): two Winograd convolutions with the folded
+        BatchNorm + LeakyReLU tail (scratch Vh / Mc / t0); the view mean of models/encoder.py:62 is taken inside the first input transform."""
         b, D, H, W = geo
-        C = mean.shape[-1]
-        for src, dst, k, bn in ((mean, t0, "fc0", "bn1"), (t0, h, "fc3", "bn4")):
-            co.wino_input(src, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vh, C, None, 0, p[k + "_U"], Mc, b, D, H // 2, W // 2, C)
-            co.wino_output(Mc, p[k + "_b"], p[bn][0], p[bn][1], 0.01, None, None, None, dst, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
+        C = h.shape[-1]
+        co.wino_input(src, C, C, b, D, H, W, bs=bs, out=Vh, nsum=nsum, sum_stride=sum_stride)
+        co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, H // 2, W // 2, C)
+        co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
+        co.wino_input(t0, C, C, b, D, H, W, out=Vh)
+        co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, H // 2, W // 2, C)
+        co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
 
     def _fuse_wino(self, xr, h0=None):
         """fuse_hip with every 3x3x3 convolution as Winograd F(2x2, 3x3) x 3 depth taps (csrc/winograd.hip): 2.25x fewer MFMA FLOPs.
-        The views are transformed once, by one launch; per GRU step: transform h, 16 point GEMMs over [V_x | V_h] (K = 3 x 256), inverse
-        transform fused with the gate epilogue; transform h*r, point GEMMs, inverse transform fused with the state update."""
+        The views are transformed once, by one launch; the view mean is taken inside the input transform that feeds fusion_conv; per GRU step:
+        transform h, 16 point GEMMs over [V_x | V_h] (K = 3 x 256), inverse transform fused with the gate epilogue; transform h*r, point GEMMs,
+        inverse transform fused with the state update. (Fusing each inverse transform with the next input transform through LDS was built and
+        measured slower - tools/experiments/wino_output_input_kernel.hip.)"""
         b, t, D, H, W, C = xr.shape
         p = self._packed_wino()
         dev, M, Ht, Wt = xr.device, b * D * H * W, H // 2, W // 2
@@ -561,8 +566,9 @@ class ConvGRU_3D(co.PackedModule):
         Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)                        # the C-column problems reuse the front of the buffer
         t0, h = new(), new()
+        vol = D * H * W
         if h0 is None:
-            self._wino_h0(p, xr.mean(dim=1).reshape(M, C), geo, Vh, Mc, t0, h)
+            self._wino_h0(p, xr, geo, Vh, Mc, t0, h, nsum=t, sum_stride=vol, bs=t * vol)
         else:
             h.copy_(h0.permute(0, 2, 3, 4, 1).reshape(M, C))
         z, hr, h2, out = new(), new(), t0, new()
@@ -602,12 +608,13 @@ class ConvGRU_3D(co.PackedModule):
         outs = []
         for grp in groups:
             grp = list(grp)
-            if grp == list(range(grp[0], grp[0] + len(grp))):          # a run of views: a slice (no index tensor: capturable into a hipGraph)
-                mean = xr[:, grp[0]:grp[0] + len(grp)].mean(dim=1).reshape(M, C)
-            else:
-                mean = torch.stack([xr[:, ti] for ti in grp], dim=1).mean(dim=1).reshape(M, C)
+            run = grp == list(range(grp[0], grp[0] + len(grp)))       # a run of views: the mean is taken inside the input transform
+            mean = None if run else torch.stack([xr[:, ti] for ti in grp], dim=1).mean(dim=1).reshape(M, C)
             t0, h = new(), new()
-            self._wino_h0(p, mean, geo, Vh, Mc, t0, h)
+            if run:
+                self._wino_h0(p, xr[:, grp[0]:], geo, Vh, Mc, t0, h, nsum=len(grp), sum_stride=D * H * W, bs=t * D * H * W)
+            else:
+                self._wino_h0(p, mean, geo, Vh, Mc, t0, h)
             z, hr, h2, out = new(), new(), t0, new()
             for k, ti in enumerate(grp):
                 co.wino_input(h, C, C, b, D, H, W, out=Vh)

@@ -124,3 +124,35 @@ def render_rays(feat, dens, cam, view2vol, Hr, Wr, S, zmin, zmax, half, want_dep
     view2vol [V] int32 -> (feat [V,C,Hr,Wr], opacity [V,1,Hr,Wr][, depth [V,1,Hr,Wr]])."""
     return _RenderRays.apply(feat, dens, cam, view2vol, int(Hr), int(Wr), int(S), float(zmin), float(zmax),
                              tuple(float(h) for h in half), bool(want_depth))
+
+
+class _ResizeBilinear(torch.autograd.Function):
+    """forge_resize_bilinear_fwd / _bwd: planes [..., Hi, Wi] -> [..., Ho, Wo], bilinear, align_corners=False (models/volume_render.py:69,74)."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, Ho, Wo):
+        _require_cuda(x)
+        if x.dtype != torch.float32:
+            raise TypeError("forge_amd ops are fp32 (got %s)" % x.dtype)
+        xc = x.contiguous()
+        Hi, Wi = xc.shape[-2:]
+        P = xc.numel() // (Hi * Wi)
+        out = torch.empty(xc.shape[:-2] + (Ho, Wo), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().forge_resize_bilinear_fwd(_lib.ptr(xc), _lib.ptr(out), P, Hi, Wi, Ho, Wo, _lib.current_stream()), "forge_resize_bilinear_fwd")
+        ctx.dims = (P, Hi, Wi, Ho, Wo, tuple(x.shape))
+        return out
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, g):
+        P, Hi, Wi, Ho, Wo, shape = ctx.dims
+        gc = g.contiguous()
+        din = torch.empty(shape, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().forge_resize_bilinear_bwd(_lib.ptr(gc), _lib.ptr(din), P, Hi, Wi, Ho, Wo, _lib.current_stream()), "forge_resize_bilinear_bwd")
+        return din, None, None
+
+
+def resize_bilinear(x, Ho, Wo):
+    """F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) on the HIP kernels (forward and adjoint)."""
+    return _ResizeBilinear.apply(x, int(Ho), int(Wo))

@@ -15,7 +15,6 @@ Differences that are deliberate:
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib, convops as co, ops
 from .fusion import affine_act_bwd, bn_act_rows, frozen_eval, hip_inference
@@ -164,10 +163,10 @@ class VolRender(co.PackedModule):
             rendered_imgs = _ConvRgbFrozen.apply(outs[0], self)      # refinement: fused forward, data-gradient-only backward
         else:
             rendered_imgs = self._conv_rgb_autograd_hip(outs[0])      # ops.render_rays has already refused non-HIP tensors
-        rendered_silhouettes = F.interpolate(outs[1], size=[self.img_size] * 2, mode="bilinear", align_corners=False)
+        rendered_silhouettes = ops.resize_bilinear(outs[1], self.img_size, self.img_size)          # :74, HIP kernel (forward + adjoint)
         result = [rendered_imgs, rendered_silhouettes]
         if render_depth:
-            result.append(F.interpolate(outs[2], size=[self.img_size] * 2, mode="bilinear", align_corners=False))
+            result.append(ops.resize_bilinear(outs[2], self.img_size, self.img_size))              # :69
         if return_origin_proj:
             result.append(origin if origin is not None else self._origin_proj(T, K))
         return tuple(result)

@@ -129,6 +129,11 @@ int forge_render_bwd(const float* feat, const float* dens, const float* cam, con
                      float zmin, float zmax, float hx, float hy, float hz,
                      forge_stream_t stream);
 
+/* a7  mask / depth up-sampling (models/volume_render.py:69,74: F.upsample(size=img_size, mode='bilinear') = align_corners False): P planes
+ * [Hi][Wi] -> [Ho][Wo] with ATen's source-index / weight arithmetic; _bwd is the adjoint (a deterministic gather per input pixel, written). */
+int forge_resize_bilinear_fwd(const float* in, float* out, int P, int Hi, int Wi, int Ho, int Wo, forge_stream_t stream);
+int forge_resize_bilinear_bwd(const float* g, float* din, int P, int Hi, int Wi, int Ho, int Wo, forge_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a1/a4/a5  implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32)
  * with fused element-wise tails — replaces the cuDNN convolutions + separate element-wise ops of
@@ -224,6 +229,7 @@ int forge_wino_wgrad(const float* dMm, const float* V1, int C1, long long bs1, l
                      long long pt2, float* dU, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);
 int forge_wino_dw(const float* dU, float* dw, int Cout, int Cin, int kd, forge_stream_t stream);
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
+                     int nsum /* >1: transform the MEAN of nsum tensors sum_stride rows apart (models/encoder.py:62 view mean) */, long long sum_stride,
                      forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                     long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile /* 0 = forge_wino_gemm_tile's rule */,

@@ -402,7 +402,7 @@ def test_hip_sync_batchnorm_two_ranks_equal_one_process_batch():
     y = bn_act_rows(bn, xr, 0.01)
     y.backward(dy.to(dev))
     cat = lambda k: np.concatenate([res[0][k], res[1][k]], axis=0)
-    assert np.abs(cat("y") - y.detach().cpu().numpy()).max() < 1e-6 * max(1.0, float(y.abs().max()))
+    assert np.abs(cat("y") - y.detach().cpu().numpy()).max() < 1e-6 * max(1.0, float(y.detach().abs().max()))
     assert np.abs(cat("dx") - xr.grad.cpu().numpy()).max() < 1e-6 * max(1.0, float(xr.grad.abs().max()))
     for k, ref in (("dw", bn.weight.grad), ("db", bn.bias.grad)):
         assert np.abs(res[0][k] + res[1][k] - ref.cpu().numpy()).max() < 2e-6 * max(1.0, float(ref.abs().max())), k

@@ -155,3 +155,24 @@ def test_graph_replay_is_deterministic(dev):
         a = [t.clone() for t in model(s, syn.SyntheticDataset(1.5), dev)]
         b = [t.clone() for t in model(s, syn.SyntheticDataset(1.5), dev)]
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo", [(128, 128, 256, 256), (32, 32, 64, 64), (12, 20, 24, 40), (16, 16, 33, 47), (9, 7, 9, 7), (5, 6, 3, 11)])
+def test_resize_bilinear_equals_f_interpolate_forward_and_adjoint(hi, wi, ho, wo):
+    """forge_resize_bilinear_{fwd,bwd} (the mask / depth up-sampling of models/volume_render.py:69,74) against F.interpolate(mode='bilinear',
+    align_corners=False) - the forward to fp32 rounding (ATen's own expressions), the adjoint against autograd (1e-6: ATen scatters with atomics, the
+    HIP adjoint gathers per input pixel), plus the <A x, y> = <x, A^T y> identity."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(hi * 7 + wo)
+    x = torch.randn(3, 2, hi, wi, generator=g).to(dev)
+    y = torch.randn(3, 2, ho, wo, generator=g).to(dev)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xr, size=(ho, wo), mode="bilinear", align_corners=False)
+    ref.backward(y)
+    xh = x.clone().requires_grad_(True)
+    out = ops.resize_bilinear(xh, ho, wo)
+    out.backward(y)
+    assert (out.detach() - ref.detach()).abs().max().item() < 1e-6 * max(1.0, ref.abs().max().item())      # same expressions; fma contraction may differ by an ulp
+    assert (xh.grad - xr.grad).abs().max().item() < 1e-6 * max(1.0, xr.grad.abs().max().item())
+    lhs, rhs = (out.detach().double() * y.double()).sum().item(), (x.double() * xh.grad.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))

@@ -238,3 +238,24 @@ def test_encoder_odd_and_even_trunk_grids_vs_oracle(hw):
         ref = fo.get_feat3D(img, w)
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 5e-6 * ref.abs().max().item()
+
+
+def test_input_transform_of_the_view_mean_equals_mean_then_transform():
+    """forge_wino_input with nsum views (the mean of models/encoder.py:62 taken inside the transform) == torch.mean over the views followed by
+    the plain transform, bit for bit (sum in view order, then / nsum)."""
+    from forge_amd import convops as co
+    dev = _dev()
+    b, t, D, H, W, C = 2, 5, 3, 8, 12, 32
+    x = torch.randn(b, t, D, H, W, C, generator=torch.Generator().manual_seed(8)).to(dev)
+    vol = D * H * W
+    got = co.wino_input(x, C, C, b, D, H, W, bs=t * vol, nsum=t, sum_stride=vol)
+    acc = x[:, 0].clone()
+    for k in range(1, t):
+        acc = acc + x[:, k]
+    ref = co.wino_input((acc / float(t)).contiguous(), C, C, b, D, H, W)
+    assert torch.equal(got, ref)
+    ref_mean = co.wino_input(x.mean(dim=1).contiguous(), C, C, b, D, H, W)          # torch's own reduction order: equal up to rounding
+    assert (got - ref_mean).abs().max().item() < 1e-5
+    sub = co.wino_input(x[:, 1:], C, C, b, D, H, W, bs=t * vol, nsum=3, sum_stride=vol)    # a run of views 1..3
+    ref3 = co.wino_input(((x[:, 1] + x[:, 2] + x[:, 3]) / 3.0).contiguous(), C, C, b, D, H, W)
+    assert torch.equal(sub, ref3)

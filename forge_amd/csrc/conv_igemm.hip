@@ -176,15 +176,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     // inside the input grid; the input row of tap t is base + delta(t) with the uniform delta(t) = (dz Hi + dy) Wi + dx (LDS table),
     // so a tap switch costs a shift, a test and an add per row. The other tiles switch taps once per Cin / 32 K-steps and compute it directly.
     constexpr bool KC_OUTER = (BM == 128 && BN == 128);
-    __shared__ int sdelta[KC_OUTER ? MAX_TAPS : 1];
+    __shared__ int sdelta[KC_OUTER ? 2 * MAX_TAPS : 1];             // byte deltas of the taps for in1 / in2
     unsigned long long vmask[KC_OUTER ? ACH : 1];
-    int base1[KC_OUTER ? ACH : 1], base2[KC_OUTER ? ACH : 1];
+    unsigned base1[KC_OUTER ? ACH : 1], base2[KC_OUTER ? ACH : 1];  // byte offset of (row of tap (0,0,0), this thread's 16-byte chunk) in in1 / in2
     if constexpr (KC_OUTER) {
 #pragma unroll
         for (int j = 0; j < ACH; ++j) {
             const int sp = (az[j] * a.Hi + ay[j]) * a.Wi + ax[j];
-            base1[j] = an[j] * (int)a.bs1r + sp;
-            base2[j] = an[j] * (int)a.bs2r + sp;
+            base1[j] = (unsigned)(((an[j] * (int)a.bs1r + sp) * a.ld1 + asrc[j]) * 4);
+            base2[j] = (unsigned)(((an[j] * (int)a.bs2r + sp) * a.ld2 + asrc[j]) * 4);
             vmask[j] = 0ull;
         }
         for (int tt = 0; tt < a.ntaps; ++tt) {
@@ -196,18 +196,24 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                 vmask[j] |= (unsigned long long)ok << tt;
             }
         }
-        if (tid < a.ntaps) sdelta[tid] = (a.tap[tid][0] * a.Hi + a.tap[tid][1]) * a.Wi + a.tap[tid][2];
+        if (tid < a.ntaps) {
+            const int d = (a.tap[tid][0] * a.Hi + a.tap[tid][1]) * a.Wi + a.tap[tid][2];
+            sdelta[tid] = d * a.ld1 * 4;
+            sdelta[MAX_TAPS + tid] = d * a.ld2 * 4;
+        }
         __syncthreads();
     }
-    int erow[ACH], erow2[ACH];                                   // input row index (in1 / in2) of each A row for the current tap (-1: outside)
+    // Byte offset of each A row's chunk for the current tap, OOB (>= 2^31) when the tap falls outside the grid: a K-step's load address is then
+    // ONE add (offset + 4 c0) per chunk - no multiply, no select (OOB + anything < 2^31 stays out of the buffer's range and reads 0).
+    unsigned eoff[ACH], eoff2[ACH];
     auto prep_tap = [&](int t) {
         if constexpr (KC_OUTER) {
-            const int delta = sdelta[t];
+            const unsigned d1 = (unsigned)sdelta[t], d2 = (unsigned)sdelta[MAX_TAPS + t];
 #pragma unroll
             for (int j = 0; j < ACH; ++j) {
                 const bool ok = (vmask[j] >> t) & 1ull;
-                erow[j] = ok ? base1[j] + delta : -1;
-                erow2[j] = ok ? base2[j] + delta : -1;
+                eoff[j] = ok ? base1[j] + d1 : OOB;
+                eoff2[j] = ok ? base2[j] + d2 : OOB;
             }
         } else {
             const int dz = a.tap[t][0], dy = a.tap[t][1], dx = a.tap[t][2];
@@ -216,8 +222,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                 const int zi = az[j] + dz, yi = ay[j] + dy, xi = ax[j] + dx;
                 const bool ok = aval[j] && (unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi;
                 const int sp = (zi * a.Hi + yi) * a.Wi + xi;
-                erow[j] = ok ? an[j] * (int)a.bs1r + sp : -1;
-                erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
+                eoff[j] = ok ? (unsigned)(((an[j] * (int)a.bs1r + sp) * a.ld1 + asrc[j]) * 4) : OOB;
+                eoff2[j] = ok ? (unsigned)(((an[j] * (int)a.bs2r + sp) * a.ld2 + asrc[j]) * 4) : OOB;
             }
         }
     };
@@ -226,16 +232,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         const int c0 = kc * BK;
         if (c0 < a.C1) {
 #pragma unroll
-            for (int j = 0; j < ACH; ++j)
-                ra[j] = buf_load16(r1, erow[j] < 0 ? OOB : (unsigned)((erow[j] * a.ld1 + c0 + asrc[j]) * 4));
+            for (int j = 0; j < ACH; ++j) ra[j] = buf_load16(r1, eoff[j] + (unsigned)(c0 * 4));
         } else {
 #pragma unroll
-            for (int j = 0; j < ACH; ++j)
-                ra[j] = buf_load16(r2, erow2[j] < 0 ? OOB : (unsigned)((erow2[j] * a.ld2 + (c0 - a.C1) + asrc[j]) * 4));
+            for (int j = 0; j < ACH; ++j) ra[j] = buf_load16(r2, eoff2[j] + (unsigned)((c0 - a.C1) * 4));
         }
         const unsigned wbase = (unsigned)((t * a.Cout * Cin + c0) * 4);
 #pragma unroll
-        for (int j = 0; j < BCH; ++j) rb[j] = buf_load16(rw, boff[j] == OOB ? OOB : boff[j] + wbase);
+        for (int j = 0; j < BCH; ++j) rb[j] = buf_load16(rw, boff[j] + wbase);            // boff = OOB for columns beyond Cout: stays out of range
     };
     auto store_step = [&](int buf) {
         float* sa = smem + buf * (A_FLOATS + B_FLOATS);
@@ -299,7 +303,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         const bool more = s + 1 < nsteps;
         const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         const float* sb = sa + A_FLOATS;
-        if (more) {
+#if defined(FORGE_EXP_NOGLOBAL) || defined(FORGE_EXP_NOLOAD)   // debug builds (tools/debug/gemm_ceiling.py): no global loads after the first step
+        const bool stage = more && s == 0;
+#else
+        const bool stage = more;
+#endif
+        if (stage) {
             if constexpr (KC_OUTER) {
                 if (++t == t_lo + a.tpp) { t = t_lo; ++kc; }
                 prep_tap(t);
@@ -310,10 +319,21 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) mfma_group(sa, sb, g);
+#ifdef FORGE_EXP_NOSTORE      // debug: global loads issued, LDS never rewritten (the loads' registers are kept alive by a dummy store to buffer 0 at the end)
+        if (stage && s == 0) store_step(buf ^ 1);
+#elif defined(FORGE_EXP_NOLOAD) // debug: LDS rewritten every step from stale registers, no global loads after the first step
         if (more) store_step(buf ^ 1);
+#else
+        if (stage) store_step(buf ^ 1);
+#endif
+#ifndef FORGE_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
 
+#ifdef FORGE_EXP_NOSTORE
+    if (a.n < 0) store_step(0);                                     // never true: keeps the loop's global loads from being optimised away
+#endif
     FORGE_STAMP(2);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     // The output-row mapping (identity, strided / phase remap of a transposed convolution, or the 2D->3D lift) is computed ONCE per

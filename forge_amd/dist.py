@@ -72,7 +72,10 @@ def gather_strings(msg):
 
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl" and torch.cuda.is_available():
+            dist.barrier(device_ids=[torch.cuda.current_device()])      # RCCL: barrier on THIS rank's GPU (not a guess from the rank number)
+        else:
+            dist.barrier()
 
 
 def shutdown():

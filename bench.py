@@ -580,11 +580,12 @@ def extra_configs(dev, steps=5):
     157.3 TF fp32 MFMA pipe. A configuration that fails reports its error and the others still run."""
     from forge_amd import geo_utils, refine
     from forge_amd.flopmeter import FlopMeter
-    from forge_amd.graph import GraphedCall, GraphedForward
+    from forge_amd.graph import GraphedCall, GraphedForward, PipelinedForward
     from forge_amd.model import FORGE
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
     from forge_amd.train import grouped_mse
     out = []
+    holder = {}
     ds = syn.SyntheticDataset(1.5)
     cfg = syn.kubric_config()
 
@@ -594,15 +595,22 @@ def extra_configs(dev, steps=5):
         m = m.to(dev)
         return m.train() if train else m.eval()
 
-    def entry(name, workload, views, fn_eager, fn_timed, n=steps):
+    def entry(name, workload, views, fn_eager, fn_timed, n=steps, make_pipe=None):
         try:
             with FlopMeter() as fm:
                 fn_eager()
             torch.cuda.synchronize()
             ms = _timed(fn_timed, n)
-            out.append({"name": name, "workload": workload, "steps": n, "ms_per_step": ms, "views_per_s": views / ms * 1e3,
-                        "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms,
-                                         launches=fm.launches)})
+            e = {"name": name, "workload": workload, "steps": n, "ms_per_step": ms, "views_per_s": views / ms * 1e3,
+                 "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches)}
+            if make_pipe is not None:                          # the same step with several replays in flight (PipelinedForward), as the headline runs it
+                holder.clear()
+                torch.cuda.empty_cache()
+                pipe, depth = make_pipe()
+                msp = _timed(pipe, 2 * n, warm=depth)
+                e["pipelined"] = dict(floor_of(fm.gflop, msp), depth=depth, ms_per_step=msp, views_per_s=views / msp * 1e3)
+                del pipe
+            out.append(e)
         except Exception as e:
             out.append({"name": name, "workload": workload, "error": repr(e)[:300]})
         torch.cuda.empty_cache()
@@ -610,7 +618,6 @@ def extra_configs(dev, steps=5):
     model = build(FORGE)
     # --- configs[2]: 8 scenes per GPU
     s8 = {k: v.to(dev) for k, v in syn.make_sample(8, T_IN, 256, 1.5, seed=1000).items()}
-    holder = {}
 
     def eager8():
         with torch.no_grad():
@@ -620,7 +627,11 @@ def extra_configs(dev, steps=5):
         if "g" not in holder:
             holder["g"] = GraphedForward(model, s8, ds, dev)
         holder["g"](s8)
-    entry("configs[2]", "BASELINE configs[2]: FORGE hot path, 8 scenes/GPU x 5 views -> 40 rendered views per step (hipGraph replay)", 40, eager8, timed8)
+    def pipe8():
+        p = PipelinedForward(model, s8, ds, dev, depth=2, warmup=1)
+        return (lambda: p(s8)), 2
+    entry("configs[2]", "BASELINE configs[2]: FORGE hot path, 8 scenes/GPU x 5 views -> 40 rendered views per step (hipGraph replay)", 40, eager8, timed8,
+          make_pipe=pipe8)
     holder.clear()
     del s8
     # --- 128^3-voxel scenes (synthetic 64^3 feature volumes through reconstruct)
@@ -673,8 +684,11 @@ def extra_configs(dev, steps=5):
         if "g" not in holder:
             holder["g"] = GraphedForward(m3, s1, ds, dev)
         holder["g"](s1)
+    def pipe3():
+        p = PipelinedForward(m3, s1, ds, dev, depth=4, warmup=1)
+        return (lambda: p(s1)), 4
     entry("pose3d_inference", "FORGE_poseEstimator3D inference (GT poses): 1 scene x 5 views -> 3 fusions (shared input halves) -> 10 rendered views "
-          "(hipGraph replay)", 10, eager3, timed3)
+          "(hipGraph replay)", 10, eager3, timed3, make_pipe=pipe3)
     holder.clear()
     # --- one GT-pose training step (configs[3] per-GPU step at the reference-native 32^3 / 64^3 grids): forward + backward + clip + Adam, eager
     m3 = m3.train()
@@ -749,8 +763,8 @@ def train_bench(args, rank, world, dev, affinity):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step (BASELINE configs[1]: 1, configs[2]: 8)")
     ap.add_argument("--grid", type=int, default=32, choices=(32, 64),
                     help="feature grid: 32 = the metric's configuration (64^3 render volume); 64 = BASELINE configs[3]/[4] 128^3-voxel "

@@ -713,6 +713,9 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
     return best;
 }
 
+#ifndef FORGE_EXP_LDSPAD
+#define FORGE_EXP_LDSPAD 0      // debug builds only: extra dynamic LDS per workgroup to cap the occupancy (tools/debug/gemm_ceiling.py)
+#endif
 // Launch conv_igemm_kernel with the planned tile: ceil(M / BM) x ceil(Cout / BN) workgroups per (K slice, phase, batched problem).
 static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st) {
     const long long M = (long long)a.n * a.D * a.H * a.W;
@@ -721,7 +724,7 @@ static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st) {
     do {                                                                                                                   \
         const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase * a.nbat;                                              \
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
-        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                       \
+        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float) + FORGE_EXP_LDSPAD;                                    \
         FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv>), lds);                                                    \
         hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);           \
     } while (0)

@@ -1,6 +1,6 @@
-# Round-2 PMC passes over tools/probe_kernels.py (rotate / ray-march / ConvGRU gates + state launches at the b=1 bench shapes), each counter
+# PMC passes (rounds 2, 3) over tools/probe_kernels.py (rotate / ray-march / ConvGRU gates + state launches at the b=1 bench shapes), each counter
 # group in its own rocprofv3 run (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised into
-# gpurun_out/r02_pmc_summary.json (copied to profiles/ by hand; bench.py reads profiles/*pmc_summary.json for roofline.traffic).
+# gpurun_out/pmc_summary.json (copied to profiles/ by hand; bench.py reads profiles/*pmc_summary.json for roofline.traffic).
 cd /tmp && export TMPDIR=/tmp
 run() { PROBE_KERNELS=$3 timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcall_$1 -o p -- python $GRAFT_REPO_ROOT/tools/probe_kernels.py > /dev/null 2>&1; }
 run FETCH FETCH_SIZE rotate,render,conv
@@ -58,7 +58,7 @@ for sub, label, abytes, F, W, S in jobs:
         if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
             e["wait_any_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     summary[label] = e
-json.dump(summary, open("gpurun_out/r02_pmc_summary.json", "w"), indent=1)
+json.dump(summary, open("gpurun_out/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summary, indent=1))
 PY
 rm -rf gpurun_out/pmcall_FETCH gpurun_out/pmcall_WRITE gpurun_out/pmcall_SQ gpurun_out/pmcall_WFETCH gpurun_out/pmcall_WWRITE gpurun_out/pmcall_WSQ

@@ -101,14 +101,15 @@ class _HeadsFrozen(torch.autograd.Function):
     @_lib.on_tensor_device
     def forward(ctx, z, enc):
         feat, dens, up, d8 = enc._heads_hip(z, "both", keep=True)
-        ctx.enc, ctx.saved, ctx.zshape = enc, (up, d8, dens), z.shape
+        ctx.enc, ctx.zshape = enc, z.shape
+        ctx.save_for_backward(up, d8, dens)            # dens is an output of this node: autograd records it without a reference cycle
         return feat, dens
 
     @staticmethod
     @_lib.on_tensor_device
     def backward(ctx, dfeat, ddens):
         enc = ctx.enc
-        up, d8, dens = ctx.saved
+        up, d8, dens = ctx.saved_tensors
         n, C, D, H, W = ctx.zshape
         p = enc._heads_packed_T()
         dev = up.device
@@ -133,7 +134,6 @@ class _HeadsFrozen(torch.autograd.Function):
         dz = torch.empty(n, D, H, W, C, dtype=torch.float32, device=dev)
         co.conv_igemm(gu, 64, 64, None, 0, 0, p["ct_wT"], None, None, None, 1.0, None, None, None, dz, None, (n, D, H, W), (D2, H2, W2), C, C,
                       p["ct_taps"], istride=2, epilogue=co.EPI_BIAS)
-        ctx.saved = None
         return dz.permute(0, 4, 1, 2, 3), None
 
 

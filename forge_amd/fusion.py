@@ -358,7 +358,7 @@ class _FuseFrozen(torch.autograd.Function):
                 steps.append((h, z, r, cand))
                 h = hn
         ctx.gru, ctx.shape = gru, (b, t, C, D, H, W)
-        ctx.steps, ctx.h0 = steps, (t0, steps[0][0])
+        ctx.save_for_backward(t0, *[v for st in steps for v in st])          # per step (h, z, r, cand); steps[0][0] is h0
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
     @staticmethod
@@ -366,6 +366,8 @@ class _FuseFrozen(torch.autograd.Function):
     def backward(ctx, dout):
         gru = ctx.gru
         b, t, C, D, H, W = ctx.shape
+        saved = ctx.saved_tensors
+        t0, steps = saved[0], [saved[1 + 4 * i:5 + 4 * i] for i in range(t)]
         p = gru._packed_T()
         dev, M = dout.device, b * D * H * W
         grid = (b, D, H, W)
@@ -380,7 +382,7 @@ class _FuseFrozen(torch.autograd.Function):
         ld_dhn = C
         dx = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
         for ti in reversed(range(t)):
-            h, z, r, cand = ctx.steps[ti]
+            h, z, r, cand = steps[ti]
             dh, dz, dc, dg = new(), new(), new(), new(2 * C)
             _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, st()), "forge_gru_state_bwd")
             dxh = new(2 * C)                                                 # (d x_t | d (h r)) of the candidate conv
@@ -393,7 +395,7 @@ class _FuseFrozen(torch.autograd.Function):
             dx[:, ti] = tot.view(b, D, H, W, 2 * C)[..., :C]
             dhn, ld_dhn = tot[:, C:], 2 * C
         # h0 = lrelu(bn4(conv(lrelu(bn1(conv(mean_t x))))))
-        t0, h0 = ctx.h0
+        h0 = steps[0][0]
         g = torch.empty(M, C, dtype=torch.float32, device=dev)
         affine_act_bwd(dhn, h0, p["bn4_scale"], 0.01, out=g)
         g2 = new()
@@ -401,7 +403,6 @@ class _FuseFrozen(torch.autograd.Function):
         affine_act_bwd(g2, t0, p["bn1_scale"], 0.01, out=g)
         dgrad(g, C, "fc0", g2, C)
         dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
-        ctx.steps = ctx.h0 = None
         return dx.permute(0, 1, 5, 2, 3, 4), None
 
 

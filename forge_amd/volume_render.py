@@ -28,14 +28,15 @@ class _ConvRgbFrozen(torch.autograd.Function):
     @_lib.on_tensor_device
     def forward(ctx, x, vr):
         rgb, up, mid = vr._conv_rgb_hip(x, keep=True)
-        ctx.vr, ctx.saved, ctx.xshape = vr, (up, mid, rgb), x.shape
+        ctx.vr, ctx.xshape = vr, x.shape
+        ctx.save_for_backward(up, mid, rgb)
         return rgb
 
     @staticmethod
     @_lib.on_tensor_device
     def backward(ctx, drgb):
         vr = ctx.vr
-        up, mid, rgb = ctx.saved
+        up, mid, rgb = ctx.saved_tensors
         V, C, Hr, Wr = ctx.xshape
         p = vr._conv_rgb_packed_T()
         dev = up.device
@@ -54,7 +55,6 @@ class _ConvRgbFrozen(torch.autograd.Function):
         dx = torch.empty(V, 1, Hr, Wr, C, dtype=torch.float32, device=dev)
         co.conv_igemm(gu, 16, 16, None, 0, 0, p["ctT"], None, None, None, 1.0, None, None, None, dx, None, (V, 1, Hr, Wr), (1, H2, W2), C, C,
                       p["ct_taps"], istride=2, epilogue=co.EPI_BIAS)
-        ctx.saved = None
         return dx.reshape(V, Hr, Wr, C).permute(0, 3, 1, 2), None
 
 

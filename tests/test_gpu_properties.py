@@ -176,3 +176,33 @@ def test_resize_bilinear_equals_f_interpolate_forward_and_adjoint(hi, wi, ho, wo
     assert (xh.grad - xr.grad).abs().max().item() < 1e-6 * max(1.0, xr.grad.abs().max().item())
     lhs, rhs = (out.detach().double() * y.double()).sum().item(), (x.double() * xh.grad.double()).sum().item()
     assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+
+
+def test_launch_guard_follows_keyword_tensors_to_their_device():
+    """_lib.on_tensor_device must find the operands' device among KEYWORD arguments too (the models call rotate / render with
+    keywords). Single-GPU boxes: the decorator is exercised with a spy on torch.cuda.device; with two GPUs the rotate module on cuda:1 is run
+    while cuda:0 is current and compared with the same call under `with torch.cuda.device(1)`."""
+    from forge_amd import _lib
+    seen = []
+
+    @_lib.on_tensor_device
+    def probe(self_like, voxels=None, poses=None):
+        seen.append(torch.cuda.current_device())
+        return voxels
+    x = torch.zeros(2, device="cuda:0")
+    probe(object(), voxels=x)
+    assert seen == [0]
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: the cross-device half needs cuda:1")
+    from forge_amd.rotate import Rotate_world
+    rot = Rotate_world(syn.kubric_config()).to("cuda:1")
+    poses, _, _ = syn.orbit_cameras(3, 1.5, 10.0)
+    vox = torch.rand(1, 3, 8, 16, 16, 16, device="cuda:1")
+    torch.cuda.set_device(0)
+    got = rot(voxels=vox, camPoses_cv2=poses[None].to("cuda:1"), grid_size=16)
+    with torch.cuda.device(1):
+        ref = rot(voxels=vox, camPoses_cv2=poses[None].to("cuda:1"), grid_size=16)
+    assert got.device == vox.device and torch.equal(got, ref)
+    y = torch.zeros(2, device="cuda:1")
+    probe(object(), poses=y)
+    assert seen[-1] == 1

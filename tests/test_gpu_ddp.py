@@ -434,3 +434,35 @@ def test_bench_train_mode_two_ranks_and_n1_paths_agree():
     a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]) for r in (plain, launched))
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
     assert abs(a["value"] - b["value"]) < 0.15 * a["value"], (a["value"], b["value"])
+
+
+def test_rccl_backend_single_rank_runs_the_collectives_this_package_issues():
+    """The test box has one GPU, so every multi-rank test above runs over gloo. This one at least drives RCCL itself (backend "nccl", world
+    size 1, in a subprocess): the collectives forge_amd issues - float64 all_reduce (SyncBatchNorm statistics, bench scalars), fp32 all_reduce /
+    all_gather on volume-sized tensors (ray-sharded render), broadcast / reduce (owner mode), all_gather_object (per-rank error strings), the
+    device-bound barrier - load the library, create a communicator and complete on the MI355X."""
+    import subprocess
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+from forge_amd import dist as fd
+dev = torch.device("cuda:0")
+a = torch.arange(257, dtype=torch.float64, device=dev); dist.all_reduce(a); assert float(a.sum()) == 257 * 256 / 2
+v = torch.randn(1, 16, 64, 64, 64, device=dev).permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)      # channels-last volume, 16.8 MB
+w = v.clone(); dist.all_reduce(fd._dense_view(w)); assert torch.equal(w, v)
+parts = [torch.empty(3, 4, 64, 128, device=dev)]; dist.all_gather(parts, torch.ones(3, 4, 64, 128, device=dev)); assert float(parts[0].sum()) == 3 * 4 * 64 * 128
+b = torch.full((5,), 2.0, device=dev); dist.broadcast(b, src=0); dist.reduce(b, dst=0); assert float(b.sum()) == 10.0
+assert fd.gather_strings("rank0 ok") == ["rank0 ok"] or fd.gather_strings("x") == ["x"]
+out = [None]; dist.all_gather_object(out, {"err": None}); assert out == [{"err": None}]
+fd.barrier(); dist.barrier(device_ids=[0])
+torch.cuda.synchronize()
+print("RCCL_OK", dist.get_backend())
+dist.destroy_process_group()
+''' % (ROOT, str(_free_port()))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

@@ -705,6 +705,29 @@ def extra_configs(dev, steps=5):
         opt.step()
     entry("train_step", "GT-pose training step (kubric_train_pose_3D.py; scripts/kubric_trainer.py:47-59): FORGE_poseEstimator3D, 1 scene x 5 views, "
           "3 fusions, 10 rendered views, fused MSE, backward, clip 10, Adam; train-mode BatchNorm on the HIP kernels; eager launch", 10, train_step, train_step)
+    # the same step captured into ONE hipGraph (forge_amd.graph.GraphedStep: forward, loss, backward, clip, capturable Adam) - single-process
+    # training is host-bound at one scene (~1000 launches per step); reported beside the eager number, which is what a DDP wrapper runs
+    try:
+        from forge_amd.graph import GraphedStep
+        opt_g = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=1e-4, capturable=True)
+
+        def graph_fn():
+            imgs, masks = m3(s1, ds, dev)
+            mi = grouped_mse(imgs.reshape(1, 10, 3, 256, 256), s1["images"][:, :T_IN], T_IN)
+            mm = grouped_mse(masks.reshape(1, 10, 1, 256, 256), s1["fg_probabilities"][:, :T_IN], T_IN)
+            loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+            opt_g.step()
+            return loss.detach()
+        gs = GraphedStep(graph_fn, opt_g, warmup=2)
+        msg = _timed(gs, steps)
+        if out and out[-1].get("name") == "train_step" and "ms_per_step" in out[-1]:
+            out[-1]["hipgraph_replay"] = dict(floor_of(out[-1]["roofline"]["executed_gflop"], msg), ms_per_step=msg, views_per_s=10 / msg * 1e3)
+        del gs
+    except Exception as e:
+        if out:
+            out[-1]["hipgraph_replay"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -211,9 +211,12 @@ class _BroadcastFromOwner(torch.autograd.Function):
         rank, world = _group_info(group)
         outs = []
         for t in tensors:
-            o = t.detach().clone().contiguous()
+            o = t.detach().clone(memory_format=torch.preserve_format)          # channels-last volumes stay channels-last (no layout round trip)
             if world > 1:
-                dist.broadcast(o, src=src, group=group)
+                v = _dense_view(o)
+                dist.broadcast(v, src=src, group=group)
+                if v.data_ptr() != o.data_ptr():
+                    o.copy_(v)
             outs.append(o)
         return tuple(outs)
 
@@ -225,9 +228,12 @@ class _BroadcastFromOwner(torch.autograd.Function):
             if g is None:
                 res.append(None)
                 continue
-            g = g.contiguous().clone()
+            g = g.clone(memory_format=torch.preserve_format)
             if world > 1:
-                dist.reduce(g, dst=ctx.src, op=dist.ReduceOp.SUM, group=ctx.group)
+                v = _dense_view(g)
+                dist.reduce(v, dst=ctx.src, op=dist.ReduceOp.SUM, group=ctx.group)
+                if v.data_ptr() != g.data_ptr():
+                    g.copy_(v)
                 if rank != ctx.src:
                     g.zero_()
             res.append(g)
@@ -235,8 +241,8 @@ class _BroadcastFromOwner(torch.autograd.Function):
 
 
 def broadcast_from_owner(tensors, src, group=None):
-    """tensors (tuple) of the owner rank `src` -> the same values on every rank, differentiable (gradients are reduced to the owner).
-    Non-owners pass placeholders of the same shape / dtype / device."""
+    """tensors (tuple) of the owner rank `src` (GLOBAL rank, as torch.distributed.broadcast takes it) -> the same values on every rank,
+    differentiable (gradients are reduced to the owner). Non-owners pass placeholders of the same shape / dtype / device / memory format."""
     return _BroadcastFromOwner.apply(int(src), group, *tensors)
 
 

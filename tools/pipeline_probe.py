@@ -28,7 +28,11 @@ wt = os.environ.get("PIPE_WINO_TILE")                      # experiment: pin the
 if wt:
     _orig_tile = co.wino_gemm_tile
     co.wino_gemm_tile = lambda R, Cout: wt if (os.environ.get("PIPE_WINO_TILE_N", "") in ("", str(Cout))) else _orig_tile(R, Cout)
+ft = os.environ.get("PIPE_FORCE_TILE")                     # experiment: pin the tile of EVERY conv_igemm launch (and no split-K)
+if ft:
+    co.STATE.plan_override = (ft, 1)
 graphs = [GraphedForward(model, s, ds, dev) for s in samples]
+co.STATE.plan_override = None
 streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 ref = [g(s)[0].clone() for g, s in zip(graphs, samples)]
 torch.cuda.synchronize()

@@ -669,6 +669,12 @@ def extra_configs(dev, steps=5):
                     "-> heads -> ray-march -> conv_rgb forward + data-gradient backward + Adam, hipGraph replay", "steps": 2 * steps,
                     "ms_per_step": ms, "views_per_s": T_IN / ms * 1e3,
                     "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches)})
+        try:                                                       # two refinement problems in flight (refine_poses_many): per iteration AND instance
+            probs = [(feats, init, tgt_i, tgt_m, s1["K_cv2"][:, :T_IN]), (feats, init.clone(), tgt_i, tgt_m, s1["K_cv2"][:, :T_IN])]
+            _, dt2 = refine.refine_poses_many(model, cfg, ds, probs, dev, iter_num=2 * steps, depth=2)
+            out[-1]["pipelined"] = dict(floor_of(fm.gflop, dt2 * 1e3), depth=2, ms_per_step=dt2 * 1e3, views_per_s=T_IN / dt2)
+        except Exception as e:
+            out[-1]["pipelined"] = {"error": repr(e)[:200]}
     except Exception as e:
         out.append({"name": "refinement", "error": repr(e)[:300]})
     del model

@@ -39,6 +39,68 @@ def _render_views(model, config, dataset, features, pose7, K, device, canonical=
     return imgs, masks, depths, origin, poses
 
 
+class PoseRefiner:
+    """One instance of the refinement problem (kubric_eval.py:412-530): features [b,t,C,D,H,W] (detached encoder output), initial poses
+    [b(t-1),7] (quat, trans), targets, intrinsics. `iteration()` = forward, loss, backward through every HIP kernel, Adam step; `capture()`
+    records it into a hipGraph on `stream` (fixed shapes, no host synchronisation: closed-form pose inverses, device-side view ordering,
+    capturable Adam), `step()` replays it (or runs it eagerly). The model's weights must be frozen by the caller (refine_poses does)."""
+
+    def __init__(self, model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=True, stream=None):
+        self.model, self.config, self.dataset, self.device = model, config, dataset, device
+        self.features = features.detach().to(device)
+        self.target_imgs, self.target_masks, self.K = target_imgs.to(device), target_masks.to(device), K.to(device)
+        self.canonical = (dataset.get_canonical_pose_cv2(device=device), dataset.get_canonical_extrinsics_cv2(device=device))
+        self.rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
+        self.trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
+        lr = 0.001
+        self.opt = torch.optim.Adam([{"params": self.rot, "lr": lr}, {"params": self.trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
+        self.w_rgb, self.w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
+        self.use_graph, self.graph, self.static_loss = bool(use_graph), None, None
+        self.stream = stream
+
+    def iteration(self):
+        pose7 = torch.cat([F.normalize(self.rot), self.trans], dim=1)
+        imgs, masks, _, _, _ = _render_views(self.model, self.config, self.dataset, self.features, pose7, self.K, self.device, self.canonical)
+        loss = self.w_rgb * F.mse_loss(imgs, self.target_imgs) + self.w_mask * F.mse_loss(masks, self.target_masks)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def eager_step(self):
+        self.opt.zero_grad(set_to_none=True)
+        return self.iteration()
+
+    def capture(self):
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)             # gradients are (re)allocated inside the graph's private pool
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.static_loss = self.iteration()          # the capture pass does not execute: the first replay is the first iteration
+
+    def step(self):
+        """One optimisation iteration; on self.stream when one was given (several refiners in flight: refine_poses_many)."""
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                return self._step()
+        return self._step()
+
+    def _step(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_loss
+        return self.eager_step()
+
+    def poses(self):
+        return torch.cat([F.normalize(self.rot), self.trans], dim=1).detach()
+
+
+def _frozen(model):
+    frozen = [p for p in model.parameters() if p.requires_grad]
+    for p in frozen:                                   # no weight gradients: only the poses are optimised
+        p.requires_grad_(False)
+    return frozen
+
+
 def refine_poses(model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, iter_num=500, log_every=0,
                  use_graph=True):
     """features [b,t,C,D,H,W] (detached encoder output), poses_cam [b(t-1),7] initial (quat, trans), target_imgs [b*t,3,H,W],
@@ -48,52 +110,59 @@ def refine_poses(model, config, dataset, features, poses_cam, target_imgs, targe
     HIP kernel, Adam step - is captured into a hipGraph and replayed; the loop body is fixed-shape and free of host synchronisation
     (closed-form pose inverses, device-side view ordering, capturable Adam), so the replay does exactly what the eager iteration does."""
     model.eval()
-    frozen = [p for p in model.parameters() if p.requires_grad]
-    for p in frozen:                                   # no weight gradients: only the poses are optimised
-        p.requires_grad_(False)
+    frozen = _frozen(model)
     try:
-        features = features.detach().to(device)
-        target_imgs, target_masks, K = target_imgs.to(device), target_masks.to(device), K.to(device)
-        canonical = (dataset.get_canonical_pose_cv2(device=device), dataset.get_canonical_extrinsics_cv2(device=device))
-        rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
-        trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
-        lr = 0.001
-        opt = torch.optim.Adam([{"params": rot, "lr": lr}, {"params": trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
-        w_rgb, w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
-
-        def iteration():
-            pose7 = torch.cat([F.normalize(rot), trans], dim=1)
-            imgs, masks, _, _, _ = _render_views(model, config, dataset, features, pose7, K, device, canonical)
-            loss = w_rgb * F.mse_loss(imgs, target_imgs) + w_mask * F.mse_loss(masks, target_masks)
-            loss.backward()
-            opt.step()
-            return loss.detach()
-
+        r = PoseRefiner(model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=use_graph)
         history = []
         warm = min(3, iter_num)
-        graph, static_loss, t0 = None, None, None
+        t0 = None
         for it in range(iter_num + 1):
             if it == warm:                              # time the steady state (first iterations load kernels / warm the allocator)
                 if use_graph:
-                    torch.cuda.synchronize(device)
-                    graph = torch.cuda.CUDAGraph()
-                    opt.zero_grad(set_to_none=True)     # gradients are (re)allocated inside the graph's private pool
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        static_loss = iteration()
-                    # the capture pass did not execute: this iteration is the first replay below
+                    r.capture()
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()
-            if graph is not None:
-                graph.replay()
-                loss = static_loss
-            else:
-                opt.zero_grad(set_to_none=True)
-                loss = iteration()
+            loss = r.step() if it >= warm else r.eager_step()
             if log_every and it % log_every == 0:
                 history.append(loss.item())
         torch.cuda.synchronize(device)
         dt = (time.perf_counter() - t0) / max(iter_num + 1 - warm, 1)
-        return torch.cat([F.normalize(rot), trans], dim=1).detach(), history, dt
+        return r.poses(), history, dt
+    finally:
+        for p in frozen:
+            p.requires_grad_(True)
+
+
+def refine_poses_many(model, config, dataset, problems, device, iter_num=500, depth=2):
+    """Several refinement problems (kubric_eval.py refines every test instance independently) with `depth` of them IN FLIGHT: each problem's
+    iteration is its own hipGraph on its own HIP stream and the replays are issued round-robin, so that one instance's latency-bound
+    launches (pose algebra, rotate, heads, ray-march backward) share the chip with another's GEMMs - the refinement counterpart of
+    graph.PipelinedForward. problems = list of (features, poses_cam, target_imgs, target_masks, K). Returns ([refined poses], seconds per
+    iteration AND instance)."""
+    model.eval()
+    frozen = _frozen(model)
+    try:
+        done, dt_total, n_iter = [], 0.0, 0
+        for g0 in range(0, len(problems), depth):
+            group = problems[g0:g0 + depth]
+            cur = torch.cuda.current_stream(device)
+            refs = [PoseRefiner(model, config, dataset, *pr, device, use_graph=True, stream=torch.cuda.Stream(device=device)) for pr in group]
+            for r in refs:                               # warm-up + capture on the caller's stream, one refiner at a time
+                for _ in range(min(3, iter_num)):
+                    r.eager_step()
+                r.capture()
+            torch.cuda.synchronize(device)
+            for r in refs:
+                r.stream.wait_stream(cur)
+            t0 = time.perf_counter()
+            for _ in range(iter_num):
+                for r in refs:
+                    r.step()
+            torch.cuda.synchronize(device)
+            dt_total += time.perf_counter() - t0
+            n_iter += iter_num * len(refs)
+            done.extend(r.poses() for r in refs)
+        return done, dt_total / max(n_iter, 1)
     finally:
         for p in frozen:
             p.requires_grad_(True)

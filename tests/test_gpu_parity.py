@@ -1208,3 +1208,39 @@ def test_row_band_render_equals_full_render_rows(dev):
                 assert torch.equal(a, b[:, :, h0:h1])
     got = fd.render_rays_sharded(feat.to(dev), dens.to(dev), cam, v2v, 128, 128, 64, 0.5, 2.0, h, True)      # world size 1 path
     assert all(torch.equal(a, b) for a, b in zip(got, full))
+
+
+def test_pose_refinement_two_instances_in_flight_match_sequential_runs(dev):
+    """f2: refine_poses_many keeps two refinement problems in flight (one hipGraph + HIP stream each, replays issued round-robin); every
+    instance follows the trajectory of its own sequential refine_poses run (Adam on atomics-noisy gradients: a fraction of lr per step)
+    and both reduce their pose error."""
+    from forge_amd import geo_utils, refine
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+    ds = syn.SyntheticDataset(1.5)
+    problems, gts, inits = [], [], []
+    for seed in (21, 22):
+        sample = syn.make_sample(1, 3, 256, 1.5, seed=seed)
+        with torch.no_grad():
+            feats = model.encoder_3d.get_feat3D(sample["images"][0].to(dev)).reshape(1, 3, 128, 32, 32, 32)
+            gt7 = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][0, 1:]).to(dev)
+            tgt_i, tgt_m, _, _, _ = refine._render_views(model, cfg, ds, feats, gt7, sample["K_cv2"].to(dev), dev)
+        g = torch.Generator().manual_seed(seed)
+        init = gt7.clone()
+        init[:, :4] = torch.nn.functional.normalize(init[:, :4] + 0.03 * torch.randn(2, 4, generator=g).to(dev))
+        init[:, 4:] += 0.02 * torch.randn(2, 3, generator=g).to(dev)
+        problems.append((feats, init, tgt_i.clone(), tgt_m.clone(), sample["K_cv2"]))
+        gts.append(sample["cam_poses_rel_cv2"][0, 1:].to(dev))
+        inits.append(init)
+    n = 24
+    many, dt = refine.refine_poses_many(model, cfg, ds, problems, dev, iter_num=n, depth=2)
+    assert all(p.requires_grad for p in model.parameters())
+    for pr, got, gt, init in zip(problems, many, gts, inits):
+        seq, _, _ = refine.refine_poses(model, cfg, ds, *pr, dev, iter_num=n + 2, use_graph=True)     # warm-up 3 eager + n replays vs 3 + (n + 2 - 3 + 1)
+        assert (got - seq).abs().max().item() < 8e-3 and (got - init).abs().max().item() > 5e-3
+        e0, e1 = refine.pose_errors(init, gt), refine.pose_errors(got, gt)
+        assert e1[0].mean().item() < e0[0].mean().item()
+    print("refinement, 2 instances in flight: %.2f ms per iteration and instance (t = 3 views)" % (dt * 1e3))

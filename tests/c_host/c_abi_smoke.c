@@ -5,7 +5,9 @@
  *      align_corners mismatch (interior values shrink towards the centre) - checked against a scalar
  *      re-computation of the trilinear sample for one voxel;
  *   2. forge_render_fwd: an empty density volume renders exact zeros; a uniform density d renders opacity 1 - (1 - d)^k;
- *   3. error path: a NULL pointer returns FORGE_EINVAL and sets forge_last_error.
+ *   3. forge_conv_igemm (identity 1x1 convolution on the matrix cores, planned inside and with the caller's explicit plan), forge_conv_igemm_plan,
+ *      forge_resize_bilinear_fwd;
+ *   4. error path: a NULL pointer / an unknown tile returns FORGE_EINVAL and sets forge_last_error.
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -120,9 +122,60 @@ int main(void) {
                    "unit features must composite to (just below) the opacity, identically in every channel");
     }
 
+    /* ---------------- matrix-core convolution through the ABI: 1x1 conv, 64 -> 64 channels, identity weights, bias 0.25 on a 1 x 4 x 8 x 8 grid,
+     * once with the library's own launch plan (tile = 0) and once with the caller's plan ('D', no split-K); then the plan query */
+    {
+        const int Cc = 64, Mr = 4 * 8 * 8;
+        float* h_x = (float*)malloc((size_t)Mr * Cc * sizeof(float));
+        float* h_w = (float*)calloc((size_t)Cc * Cc, sizeof(float));
+        float* h_b = (float*)malloc(Cc * sizeof(float));
+        float* h_y = (float*)malloc((size_t)Mr * Cc * sizeof(float));
+        for (int i = 0; i < Mr * Cc; ++i) h_x[i] = (float)((i * 40503u) % 997u) / 997.0f - 0.5f;
+        for (int c = 0; c < Cc; ++c) { h_w[c * Cc + c] = 1.0f; h_b[c] = 0.25f; }
+        float *d_x, *d_w, *d_b, *d_y;
+        CHECK_HIP(hipMalloc((void**)&d_x, (size_t)Mr * Cc * sizeof(float)));
+        CHECK_HIP(hipMalloc((void**)&d_w, (size_t)Cc * Cc * sizeof(float)));
+        CHECK_HIP(hipMalloc((void**)&d_b, Cc * sizeof(float)));
+        CHECK_HIP(hipMalloc((void**)&d_y, (size_t)Mr * Cc * sizeof(float)));
+        CHECK_HIP(hipMemcpy(d_x, h_x, (size_t)Mr * Cc * sizeof(float), hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_w, h_w, (size_t)Cc * Cc * sizeof(float), hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_b, h_b, Cc * sizeof(float), hipMemcpyHostToDevice));
+        const int taps[3] = {0, 0, 0};
+        for (int pass = 0; pass < 2; ++pass) {
+            CHECK_HIP(hipMemset(d_y, 0xff, (size_t)Mr * Cc * sizeof(float)));
+            CHECK_FORGE(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL,
+                                         1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc, taps, 1, 1, 0, 0, 0, 4, 8, 8, /*epilogue*/ 0, /*lift*/ 0,
+                                         pass ? 'D' : 0, 1, NULL, 0, (forge_stream_t)st));
+            CHECK_HIP(hipStreamSynchronize(st));
+            CHECK_HIP(hipMemcpy(h_y, d_y, (size_t)Mr * Cc * sizeof(float), hipMemcpyDeviceToHost));
+            for (int i = 0; i < Mr * Cc; ++i) EXPECT(h_y[i] == h_x[i] + 0.25f, "identity 1x1 convolution + bias must reproduce x + 0.25 exactly");
+        }
+        int tile = 0, ks = 0;
+        CHECK_FORGE(forge_conv_igemm_plan(32768, 256, 256, 27, 1, 2, 128, 0, &tile, &ks));
+        EXPECT(tile >= 'A' && tile <= 'E' && ks == 1, "the plan query must name a tile A..E and no split-K without a workspace");
+        EXPECT(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL, 1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc,
+                                taps, 1, 1, 0, 0, 0, 4, 8, 8, 0, 0, 'Z', 1, NULL, 0, (forge_stream_t)st) == FORGE_EINVAL, "an unknown tile letter must be refused");
+    }
+    /* ---------------- bilinear x2 of a constant plane and of a column ramp (align_corners = False: interior values are the 0.25 / 0.75 blends) */
+    {
+        const int Hi = 4, Wi = 4, Ho = 8, Wo = 8;
+        float h_p[16], h_q[64];
+        for (int i = 0; i < 16; ++i) h_p[i] = (float)(i % Wi);
+        float *d_p, *d_q;
+        CHECK_HIP(hipMalloc((void**)&d_p, sizeof(h_p)));
+        CHECK_HIP(hipMalloc((void**)&d_q, sizeof(h_q)));
+        CHECK_HIP(hipMemcpy(d_p, h_p, sizeof(h_p), hipMemcpyHostToDevice));
+        CHECK_FORGE(forge_resize_bilinear_fwd(d_p, d_q, 1, Hi, Wi, Ho, Wo, (forge_stream_t)st));
+        CHECK_HIP(hipStreamSynchronize(st));
+        CHECK_HIP(hipMemcpy(h_q, d_q, sizeof(h_q), hipMemcpyDeviceToHost));
+        const float want[8] = {0.f, 0.25f, 0.75f, 1.25f, 1.75f, 2.25f, 2.75f, 3.f};
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) EXPECT(fabsf(h_q[y * Wo + x] - want[x]) < 1e-6f, "bilinear x2 of a column ramp");
+    }
+
     /* ---------------- error path */
     EXPECT(forge_rotate_fwd(NULL, d_xf, d_mode, d_out, n, C, D, D, D, (forge_stream_t)st) == FORGE_EINVAL, "NULL input must return FORGE_EINVAL");
     EXPECT(strlen(forge_last_error()) > 0, "forge_last_error must describe the failure");
-    printf("C host: rotate + render + error path OK (central opacity %.6f)\n", h_oo[(Hr / 2) * Wr + Wr / 2]);
+    printf("C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK (central opacity %.6f)\n", h_oo[(Hr / 2) * Wr + Wr / 2]);
     return 0;
 }

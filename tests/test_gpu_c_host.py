@@ -23,4 +23,4 @@ def test_c_host_program_builds_and_runs(tmp_path):
     assert build.returncode == 0, build.stdout + build.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "C host: rotate + render + error path OK" in run.stdout
+    assert "C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK" in run.stdout

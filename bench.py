@@ -1039,6 +1039,7 @@ def main():
         "ranks_ok": int(ranks_ok), "errors": errors,
         "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
                    "render_grid": 2 * args.grid, "rank0_affinity": affinity,
+                   "steps_in_flight": graphed.depth if graphed is not None else 1,
                    "launch": "eager" if args.no_graph else ("hipGraph replay, %d steps in flight on %d HIP streams" % (graphed.depth, graphed.depth)
                                                             if (graphed is not None and graphed.depth > 1) else "hipGraph replay"),
                    "parallelism": "dp%d (scene-sharded, no data-path collective; 4-scalar RCCL all-reduce of SSE/pixels/views/ok for the PSNR report)" % world},

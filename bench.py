@@ -114,7 +114,7 @@ def stage_timers(model):
         out = o_g(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw)
         e1.record()
         R = n * D * Ht * Wt
-        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout)], []).append((e0, e1, 2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2), 2.25))
+        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout, C1 + C2)], []).append((e0, e1, 2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2), 2.25))
         return out
 
     def input_timed(x, C, ld, n, D, H, W, **kw):

@@ -150,7 +150,7 @@ def invalidate_packed(module):
 
 SPLITK_WS_BYTES = 128 << 20          # cap the plan model may assume for split-K partial tiles (ksplit x M x Cout floats)
 
-TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
+TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1", "F": "64, 128, 8, 1, 3"}
 
 _PLAN_CACHE = {}
 
@@ -165,7 +165,7 @@ STATE = _State()
 
 
 class force_plan:
-    """Context manager for tools / tests: pin the workgroup tile ('A'..'E') and / or the split-K factor of every forge_conv_igemm and
+    """Context manager for tools / tests: pin the workgroup tile ('A'..'F') and / or the split-K factor of every forge_conv_igemm and
     forge_wino_gemm launch made inside it, instead of the library's plan model. The library itself reads no environment variables; the
     override travels as the explicit (tile, ksplit) arguments of the C-ABI calls."""
 
@@ -419,17 +419,17 @@ def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
     p1 = ctypes.c_void_p(V1.data_ptr() + 4 * view * vol * C1)
     _lib.check(_lib.lib().forge_wino_gemm(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
                                           0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd,
-                                          ord(wino_gemm_tile(n * vol, Cout)), _lib.current_stream()),
+                                          ord(wino_gemm_tile(n * vol, Cout, C1 + C2)), _lib.current_stream()),
                "forge_wino_gemm")
     return Mm
 
 
-def wino_gemm_tile(R, Cout):
-    """Tile letter forge_wino_gemm uses for R tile rows per point (names the kernel instantiation for profilers, bench.py)."""
+def wino_gemm_tile(R, Cout, Cin):
+    """Tile letter forge_wino_gemm uses for R tile rows per point, Cin input channels (names the kernel instantiation for profilers, bench.py)."""
     ov = STATE.plan_override
     if ov is not None and ov[0]:
         return ov[0]
-    return chr(_lib.lib().forge_wino_gemm_tile(int(R), int(Cout)))
+    return chr(_lib.lib().forge_wino_gemm_tile(int(R), int(Cout), int(Cin)))
 
 
 @_lib.on_tensor_device

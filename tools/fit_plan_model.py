@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Fit the (eff, ov) constants of NEW tiles of csrc/conv_igemm.hip: plan_conv on the sweeps tools/conv_plan_sweep.py wrote
+(gpurun_out/plan_sweep*.json). Python replica of plan_conv; a coordinate search over the constants of the tiles named in FIT_TILES with the
+others fixed; prints the loss of the chosen plans against the per-shape best (sum of microseconds) before and after."""
+import itertools, json, math, os, sys
+
+TILES = {  # id: [bm, bn, occ, eff, ov]
+    "A": [128, 128, 2, 1.000, 4.0], "B": [64, 128, 3, 0.983, 1.0], "C": [128, 64, 3, 0.969, 1.0], "D": [64, 64, 5, 0.980, 1.0], "E": [128, 32, 4, 0.915, 1.0],
+    "H": [64, 64, 3, 1.00, 1.5], "I": [64, 128, 2, 1.00, 1.5], "J": [128, 64, 2, 1.00, 1.5],
+}
+SPLITS = [1, 2, 3, 4, 6, 8]
+WS = 128 << 20
+
+
+def g(o):
+    return 0.8 if o <= 1 else 0.85 if o == 2 else 0.96 if o == 3 else 1.0
+
+
+def model_us(t, M, Cout, Cin, ntaps, k):
+    bm, bn, occ, eff, ov = t
+    nsteps = ntaps * (Cin // 32)
+    K = float(ntaps * Cin)
+    ntn = -(-Cout // bn)
+    nb = -(-M // bm) * ntn
+    wgs, slots = nb * k, 256 * occ
+    full, rem = divmod(wgs, slots)
+    tile_us = bm * bn * (-(-nsteps // k)) / (8000.0 * eff)
+    us = full * occ * tile_us
+    rounds = full
+    if rem > 0:
+        r = -(-rem // 256)
+        us += r * tile_us * g(occ) / g(r)
+        rounds += 1
+    us = max(us, (M * K * 4.0 * ntn + Cout * K * 4.0 + M * Cout * 4.0) / 4.0e6)
+    us += (rounds + 1) * ov * math.sqrt(bm * bn / 16384.0)
+    if k > 1:
+        us += 3.0 + (k + 1) * M * Cout * 4.0 / 2.0e6
+    return us
+
+
+def choose(tiles, shape, avail):
+    M, Cout, Cin, ntaps = shape
+    nsteps = ntaps * (Cin // 32)
+    best, bu = None, 1e300
+    for tid, t in tiles.items():
+        if tid == "E" and Cout > 32:
+            continue
+        for k in SPLITS:
+            if k > 1 and (nsteps // k < 8 or k * M * Cout * 4 > WS):
+                continue
+            if "%s%d" % (tid, k) not in avail:
+                continue
+            us = model_us(t, M, Cout, Cin, ntaps, k)
+            if us < bu:
+                bu, best = us, "%s%d" % (tid, k)
+    return best
+
+
+def loss(tiles, data):
+    tot = best = 0.0
+    for d in data:
+        c = choose(tiles, d["shape"], d["us"])
+        tot += d["us"][c]
+        best += min(d["us"].values())
+    return tot, best
+
+
+files = sys.argv[1:] or ["gpurun_out/plan_sweep_dma.json", "gpurun_out/plan_sweep_dma_s4.json"]
+sets = [json.load(open(f)) for f in files]
+fit = os.environ.get("FIT_TILES", "HIJ")
+old = {k: v for k, v in TILES.items() if k in "ABCDE"}
+for f, d in zip(files, sets):
+    print("%-44s A-E only: chosen %.1f us / best-of-A-E-H-I-J %.1f us" % (f, *loss(old, d)))
+# weight the sets equally (relative loss)
+def total(tiles):
+    return sum(loss(tiles, d)[0] / loss(tiles, d)[1] for d in sets)
+cur = {k: list(v) for k, v in TILES.items()}
+for it in range(4):
+    for tid in fit:
+        bestv, bl = None, 1e300
+        for eff, ov in itertools.product([0.94 + 0.01 * i for i in range(14)], [0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]):
+            cur[tid][3], cur[tid][4] = eff, ov
+            l = total(cur)
+            if l < bl - 1e-9:
+                bl, bestv = l, (eff, ov)
+        cur[tid][3], cur[tid][4] = bestv
+    print("pass", it, {t: cur[t][3:] for t in fit}, "rel loss sum %.4f" % total(cur))
+for f, d in zip(files, sets):
+    print("%-44s fitted:   chosen %.1f us / best %.1f us" % (f, *loss(cur, d)))
+    for x in d:
+        c = choose(cur, x["shape"], x["us"])
+        b = min(x["us"], key=x["us"].get)
+        if x["us"][c] > 1.03 * x["us"][b]:
+            print("   ", x["shape"], "chose", c, "%.1f" % x["us"][c], "best", b, "%.1f" % x["us"][b])

@@ -27,7 +27,18 @@ from forge_amd import convops as co  # noqa: E402
 wt = os.environ.get("PIPE_WINO_TILE")                      # experiment: pin the tile of the Winograd point-GEMM launches (A..D)
 if wt:
     _orig_tile = co.wino_gemm_tile
-    co.wino_gemm_tile = lambda R, Cout: wt if (os.environ.get("PIPE_WINO_TILE_N", "") in ("", str(Cout))) else _orig_tile(R, Cout)
+    co.wino_gemm_tile = lambda R, Cout, Cin: wt if (os.environ.get("PIPE_WINO_TILE_N", "") in ("", str(Cout))) else _orig_tile(R, Cout, Cin)
+rule = os.environ.get("PIPE_WINO_RULE")                    # experiment: a Python expression of (R, Cout, Cin) naming the tile, e.g. "'I' if Cout >= 256 else 'A'"
+if rule:
+    co.wino_gemm_tile = eval("lambda R, Cout, Cin: " + rule)
+tmap = dict(kv.split(":") for kv in os.environ.get("PIPE_TILE_MAP", "").split(",") if kv)   # experiment: rename planned tiles, e.g. "D:H,B:I"
+if tmap:
+    _orig_plan = co.conv_plan
+
+    def _mapped_plan(*a, **k):
+        t, ks = _orig_plan(*a, **k)
+        return tmap.get(t, t), ks
+    co.conv_plan = _mapped_plan
 ft = os.environ.get("PIPE_FORCE_TILE")                     # experiment: pin the tile of EVERY conv_igemm launch (and no split-K)
 if ft:
     co.STATE.plan_override = (ft, 1)

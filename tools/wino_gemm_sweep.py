@@ -35,7 +35,7 @@ for name, n, D_, C1, C2, N in shapes:
     U = torch.randn(16, 3, N, C1 + C2, device=dev) * 0.02
     Mm = torch.empty(16, R, N, device=dev)
     flops = 2.0 * 16 * R * N * 3 * (C1 + C2)
-    plan = co.wino_gemm_tile(R, N)
+    plan = co.wino_gemm_tile(R, N, C1 + C2)
     line = []
     for tile in os.environ.get("SWEEP_TILES", "A,B,C,D").split(","):
         with co.force_plan(tile=tile):

@@ -150,7 +150,7 @@ def invalidate_packed(module):
 
 SPLITK_WS_BYTES = 128 << 20          # cap the plan model may assume for split-K partial tiles (ksplit x M x Cout floats)
 
-TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1", "F": "64, 128, 8, 1, 3"}
+TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
 
 _PLAN_CACHE = {}
 
@@ -165,7 +165,7 @@ STATE = _State()
 
 
 class force_plan:
-    """Context manager for tools / tests: pin the workgroup tile ('A'..'F') and / or the split-K factor of every forge_conv_igemm and
+    """Context manager for tools / tests: pin the workgroup tile ('A'..'E') and / or the split-K factor of every forge_conv_igemm and
     forge_wino_gemm launch made inside it, instead of the library's plan model. The library itself reads no environment variables; the
     override travels as the explicit (tile, ksplit) arguments of the C-ABI calls."""
 

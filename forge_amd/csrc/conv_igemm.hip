@@ -108,14 +108,15 @@ __device__ __forceinline__ v4i32 make_rsrc_words(const void* base, long long byt
     return r;
 }
 
-// ST = LDS stages. ST = 2: register-staged double buffering (buffer_load -> VGPR -> ds_write). ST = 3: LDS-DMA staging -
-// `buffer_load_dwordx4 ... lds` written as inline assembly so that the compiler inserts no vmcnt(0) drain in front of the barrier: the loads of
-// K-step s+2 are issued at the start of step s into the third stage and the wave waits (vmcnt(ACH+BCH)) only for the loads of step s+1, which
-// have had a whole step to land; no staging VGPRs, no ds_write. Same K order as ST = 2, so the results are bitwise those of the register-staged
-// twin (tests/test_gpu_parity.py). Measured (profiles/TUNING_LOG.md, round 3): +4..8 % on the Winograd point GEMMs with the 64x128 tile;
-// the 64x64, 128x64, 128x32 and 128x128 tiles lose to their twins end to end (LDS 48..96 KB per workgroup costs them occupancy).
-// (Round 2's TWO-stage LDS-DMA variant lost 2-6 % to the drain in front of every barrier.)
-template <int BM, int BN, int NW, int MT = 1, int ST = 2>
+// Operand staging is LDS-DMA: `buffer_load_dwordx4 ... offen lds` (M0 = the wave's LDS byte address; lane L lands at + 16 L, out-of-range
+// lanes write zeros) puts a K-step's A / B rows straight into the other LDS stage - no staging VGPRs, no ds_write. The loads are inline
+// assembly because the compiler's own waitcnt insertion would drain them (vmcnt(0)) BEFORE the step's MFMAs (round 2's builtin-based variant
+// lost 2-6 % to that); here the loads of step s+1 are issued at the top of step s, fly under its 16 MFMAs per accumulator, and the hand-placed
+// `s_waitcnt vmcnt(0)` sits directly in front of the step's closing barrier. Against the register-staged loop this kernel replaced (same K
+// order, bitwise the same results): +5..21 % per launch (profiles/TUNING_LOG.md, round 3: 64x128 tile 106 -> 129 TF on the Winograd gates
+// GEMM, 128x128 tile 112 -> 135 TF on the K = 6912 direct launch). A third LDS stage (loads two steps ahead) was slower than two: the extra
+// LDS costs a resident workgroup per CU.
+template <int BM, int BN, int NW, int MT = 1>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int WM = BM / (32 * MT), WN = NW / WM; // NW waves as WM(M) x WN(N); wave tile (32 MT) x (BN / WN)
     constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
@@ -124,8 +125,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int RPP = NW * 8;                     // tile rows staged per pass (8 threads per 128-byte row)
     constexpr int ACH = BM / RPP, BCH = BN / RPP;   // 16-byte chunks per thread per K-step
     static_assert(ACH >= 1 && BCH >= 1, "tile too small for the workgroup");
-    constexpr bool DMA = ST >= 3;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [ST][A_FLOATS + B_FLOATS]
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A_FLOATS + B_FLOATS]
 
     FORGE_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,10 +158,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int nsteps_all = a.tpp * kchunks;
     const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
     const int nsteps = s_end - s_begin;
-
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in1 + pb * a.pt1), 0, (int)a.span1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 + pb * a.pt2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wp + pb * a.ptw), 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
 
     const v4i32 w1 = make_rsrc_words(a.in1 + pb * a.pt1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 + pb * a.pt2 : a.in1, a.in2 ? a.span2 : 0),
                 ww = make_rsrc_words(a.wp + pb * a.ptw, (long long)a.ntaps * a.Cout * Cin * 4);
@@ -249,20 +245,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
     };
-    float4 ra[ACH], rb[BCH];
-    auto load_step = [&](int t, int kc) {
-        const int c0 = kc * BK;
-        if (c0 < a.C1) {
-#pragma unroll
-            for (int j = 0; j < ACH; ++j) ra[j] = buf_load16(r1, eoff[j] + (unsigned)(c0 * 4));
-        } else {
-#pragma unroll
-            for (int j = 0; j < ACH; ++j) ra[j] = buf_load16(r2, eoff2[j] + (unsigned)((c0 - a.C1) * 4));
-        }
-        const unsigned wbase = (unsigned)((t * a.Cout * Cin + c0) * 4);
-#pragma unroll
-        for (int j = 0; j < BCH; ++j) rb[j] = buf_load16(rw, boff[j] + wbase);            // boff = OOB for columns beyond Cout: stays out of range
-    };
     // LDS-DMA: chunk j of this thread is row (tid >> 3) + RPP j = LDS bytes 16 tid + j NW 1024 -> per wave a lane-linear 1 KB block
     auto dma16 = [&](const v4i32& rs, unsigned voff, unsigned ldsaddr) {
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsaddr), "v"(voff), "s"(rs) : "memory");
@@ -281,15 +263,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < BCH; ++j) dma16(ww, boff[j] + wbase, stage + (unsigned)(A_FLOATS * 4 + j * NW * 1024));
     };
-    auto store_step = [&](int buf) {
-        float* sa = smem + buf * (A_FLOATS + B_FLOATS);
-        float* sb = sa + A_FLOATS;
-#pragma unroll
-        for (int j = 0; j < ACH; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK + (cp << 2)) = ra[j];
-#pragma unroll
-        for (int j = 0; j < BCH; ++j) *reinterpret_cast<float4*>(sb + br[j] * BK + (cp << 2)) = rb[j];
-    };
-
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -317,14 +290,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     prep_tap(t);
-    if constexpr (DMA) {
-        issue_step(t, kc, 0);
-        if (nsteps > 1) { advance(); issue_step(t, kc, 1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ACH + BCH) : "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        load_step(t, kc);
-        store_step(0);
-    }
+    issue_step(t, kc, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     FORGE_STAMP(1);
     // One K-step = 4 MFMA groups of 8 k-values. (A/B in round 1: issuing the next tile's global loads after group 0 and its LDS
@@ -352,55 +319,20 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
     };
-    if constexpr (DMA) {
-        int buf = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
-            const float* sb = sa + A_FLOATS;
-            const bool ahead = s + 2 < nsteps;
-            if (ahead) {                                              // stage (s + 2) % 3 was last read in step s - 1: every wave is past that barrier
-                advance();
-                issue_step(t, kc, buf == 0 ? 2 : buf - 1);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_group(sa, sb, g);
-            if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ACH + BCH) : "memory");     // step s + 1 has landed; step s + 2 may still be in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-    } else
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        const bool more = s + 1 < nsteps;
         const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         const float* sb = sa + A_FLOATS;
-#if defined(FORGE_EXP_NOGLOBAL) || defined(FORGE_EXP_NOLOAD)   // debug builds (tools/debug/gemm_ceiling.py): no global loads after the first step
-        const bool stage = more && s == 0;
-#else
-        const bool stage = more;
-#endif
-        if (stage) {
+        if (s + 1 < nsteps) {                                     // the other stage was last read in step s - 1: every wave is past that barrier
             advance();
-            load_step(t, kc);                                     // in flight under this step's MFMAs
+            issue_step(t, kc, buf ^ 1);                           // in flight under this step's MFMAs
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) mfma_group(sa, sb, g);
-#ifdef FORGE_EXP_NOSTORE      // debug: global loads issued, LDS never rewritten (the loads' registers are kept alive by a dummy store to buffer 0 at the end)
-        if (stage && s == 0) store_step(buf ^ 1);
-#elif defined(FORGE_EXP_NOLOAD) // debug: LDS rewritten every step from stale registers, no global loads after the first step
-        if (more) store_step(buf ^ 1);
-#else
-        if (stage) store_step(buf ^ 1);
-#endif
-#ifndef FORGE_EXP_NOBARRIER
-        __syncthreads();
-#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part of step s + 1 is in LDS ...
+        __syncthreads();                                          // ... and so is everybody else's
     }
 
-#ifdef FORGE_EXP_NOSTORE
-    if (a.n < 0) store_step(0);                                     // never true: keeps the loop's global loads from being optimised away
-#endif
     FORGE_STAMP(2);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     // The output-row mapping (identity, strided / phase remap of a transposed convolution, or the 2D->3D lift) is computed ONCE per
@@ -732,8 +664,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 
 // ------------------------------------------------------------------------------------------------
 // Launch plan: tile shape and split-K factor from a makespan model of the 256-CU chip (times in us).
-//   tiles      A 128x128 / 8 waves   B 64x128 / 8   C 128x64 / 8   D 64x64 / 4   E 128x32 / 4 (Cout <= 32)   [F = B with LDS-DMA staging: never
-//              planned here - it wins on the 16-problem Winograd launches only, forge_wino_gemm_tile]
+//   tiles      A 128x128 / 8 waves   B 64x128 / 8   C 128x64 / 8   D 64x64 / 4   E 128x32 / 4 (Cout <= 32)
 //   tile_us    = BM x BN x K-steps / (8000 x eff): CU-time of one tile with the CU's resident workgroups saturating the MFMA
 //                pipes; eff = measured rate of each tile on M = 131072 problems relative to tile A (130 TF)
 //   makespan   = full waves of 256 x occupancy workgroups, then the remainder with r = ceil(rem / 256) workgroups per CU running at
@@ -741,14 +672,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 //                operand/result traffic at 4 TB/s (short-K 1x1 convs are traffic-bound; narrow N tiles re-read A); plus a
 //                prologue/epilogue term per round, larger for tile A whose 2 resident workgroups overlap it worst
 //   split-K    slices K across workgroups when the chip is under-filled (M = 5120: ResNet, one scene); costs the reduction kernel
-// Constants fitted on tools/conv_plan_sweep.py (52 shapes x 30 plans, 1 and 4 scenes): chosen plans are within 0.2 % of the
-// per-shape best in total. Callers may pass an explicit (tile, ksplit) to forge_conv_igemm instead (tools/conv_plan_sweep.py, tests).
+// Constants fitted (tools/fit_plan_model.py) on tools/conv_plan_sweep.py (54 shapes x 30 plans, 1 and 4 scenes; re-fitted in round 3 for the
+// LDS-DMA loop, which moved the 64x128 tile from 0.98 to 1.06 of tile A): chosen plans are within 0.5 % / 0.1 % of the per-shape best in total. Callers may pass an explicit (tile, ksplit) to forge_conv_igemm instead (tools/conv_plan_sweep.py, tests).
 struct ConvPlan { char tile; int ksplit; };
 
 static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_split, long long ws_bytes) {
     struct Tile { char id; int bm, bn, occ; double eff, ov; };
-    static const Tile tiles[5] = {{'A', 128, 128, 2, 1.000, 4.0}, {'B', 64, 128, 3, 0.983, 1.0}, {'C', 128, 64, 3, 0.969, 1.0},
-                                  {'D', 64, 64, 5, 0.980, 1.0}, {'E', 128, 32, 4, 0.915, 1.0}};
+    static const Tile tiles[5] = {{'A', 128, 128, 2, 1.00, 1.0}, {'B', 64, 128, 3, 1.06, 0.5}, {'C', 128, 64, 3, 0.93, 0.5},
+                                  {'D', 64, 64, 5, 0.90, 1.0}, {'E', 128, 32, 4, 0.90, 0.5}};
     static const int splits[6] = {1, 2, 3, 4, 6, 8};
     auto g = [](long long o) { return o <= 1 ? 0.8 : o == 2 ? 0.85 : o == 3 ? 0.96 : 1.0; };
     const int nsteps = ntaps * (Cin / BK);
@@ -781,28 +712,24 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
     return best;
 }
 
-#ifndef FORGE_EXP_LDSPAD
-#define FORGE_EXP_LDSPAD 0      // debug builds only: extra dynamic LDS per workgroup to cap the occupancy (tools/debug/gemm_ceiling.py)
-#endif
 // Launch conv_igemm_kernel with the planned tile: ceil(M / BM) x ceil(Cout / BN) workgroups per (K slice, phase, batched problem).
 static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st) {
     const long long M = (long long)a.n * a.D * a.H * a.W;
     auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
-#define FORGE_LAUNCH_CONV(BMv, BNv, NWv, STv)                                                                              \
+#define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
     do {                                                                                                                   \
         const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase * a.nbat;                                              \
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");                                \
-        const size_t lds = STv * (BMv * BK + BNv * BK) * sizeof(float) + FORGE_EXP_LDSPAD;                                  \
-        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv, 1, STv>), lds);                                            \
-        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv, 1, STv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);   \
+        const size_t lds = 2 * (BMv * BK + BNv * BK) * sizeof(float);                                                      \
+        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<BMv, BNv, NWv>), lds);                                                   \
+        hipLaunchKernelGGL((conv_igemm_kernel<BMv, BNv, NWv>), dim3((unsigned)grid), dim3(NWv * 64), lds, st, a);          \
     } while (0)
     switch (tile) {
-        case 'A': FORGE_LAUNCH_CONV(128, 128, 8, 2); break;
-        case 'B': FORGE_LAUNCH_CONV(64, 128, 8, 2); break;
-        case 'C': FORGE_LAUNCH_CONV(128, 64, 8, 2); break;
-        case 'E': FORGE_LAUNCH_CONV(128, 32, 4, 2); break;
-        case 'F': FORGE_LAUNCH_CONV(64, 128, 8, 3); break;      // tile B's shape with three LDS stages filled by LDS-DMA (72 KB, 2 workgroups per CU)
-        default: FORGE_LAUNCH_CONV(64, 64, 4, 2); break;
+        case 'A': FORGE_LAUNCH_CONV(128, 128, 8); break;
+        case 'B': FORGE_LAUNCH_CONV(64, 128, 8); break;
+        case 'C': FORGE_LAUNCH_CONV(128, 64, 8); break;
+        case 'E': FORGE_LAUNCH_CONV(128, 32, 4); break;
+        default: FORGE_LAUNCH_CONV(64, 64, 4); break;
     }
 #undef FORGE_LAUNCH_CONV
     return 0;
@@ -886,7 +813,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
             pl = plan_conv(M * a.nphase, Cout, C1 + C2, a.tpp, can_split, splitk_ws_bytes);
         } else {                                                       // the caller's plan (forge_conv_igemm_plan's answer, or a sweep / test override)
             pl = ConvPlan{(char)tile, ksplit > 1 ? ksplit : 1};
-            FORGE_REQUIRE(tile >= 'A' && tile <= 'F', FORGE_EINVAL, "forge_conv_igemm: tile '%c' is not one of A..F (0 = planned here)", (char)tile);
+            FORGE_REQUIRE(tile >= 'A' && tile <= 'E', FORGE_EINVAL, "forge_conv_igemm: tile '%c' is not one of A..E (0 = planned here)", (char)tile);
             FORGE_REQUIRE(pl.ksplit == 1 || (can_split && pl.ksplit <= 8 && (long long)pl.ksplit * M * Cout * 4 <= splitk_ws_bytes &&
                                              pl.ksplit <= a.tpp * ((C1 + C2) / BK)), FORGE_EINVAL,
                           "forge_conv_igemm: ksplit=%d needs epilogue 0/1 without phases, Cout, ldo %% 4 == 0 and a workspace of ksplit M Cout floats", pl.ksplit);
@@ -903,13 +830,12 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
 }
 
 // Workgroup tile of forge_wino_gemm for R tile rows per point and K = kd Cin. The makespan model (plan_conv) was fitted on single-problem
-// launches; for the 16 short-K problems of one launch the measured optimum (tools/wino_gemm_sweep.py at 1, 2, 4 scenes and at the 64^3 grid,
-// two boxes, round 3) is the LDS-DMA 64x128 tile F for the wide, deep ConvGRU gates GEMM (Cout = Cin = 256: 120 TF against D 114 / B 106 / A 100
-// at one scene) and the 128x128 tile for everything else (Cout = 128 or Cin <= 128: A 1-4 % ahead of B and F). forge_wino_gemm's `tile` argument
-// overrides it (that tool).
+// launches; for the 16 short-K problems of one launch the measured optimum (tools/wino_gemm_sweep.py at 1 and 4 scenes, round 3, LDS-DMA loop)
+// is the 64x128 tile on every shape of the step (gates 129 TF against 127 / 122 for 128x128 / 64x64; state 128 / 125 / 121; conv1 102 / 98 / 93);
+// the 2-D trunk's tiny launches want many small workgroups. forge_wino_gemm's `tile` argument overrides it (that tool).
 extern "C" int forge_wino_gemm_tile(long long R, int Cout, int Cin) {
-    if (R < 2048) return 'D';                                   // the 2-D trunk's layer3/4 (R = 320 / 80): many small workgroups
-    return (Cout >= 256 && Cin >= 256) ? 'F' : 'A';
+    (void)Cout; (void)Cin;
+    return R < 2048 ? 'D' : 'B';                                // R < 2048: the 2-D trunk's layer3/4 (R = 320 / 80)
 }
 
 // The 16 point-GEMMs of a Winograd F(2x2, 3x3) x 3-depth-tap convolution (winograd.hip) in ONE launch: problem p = (i, j) multiplies
@@ -918,7 +844,7 @@ extern "C" int forge_wino_gemm_tile(long long R, int Cout, int Cin) {
 // kd = 3 for the 3x3x3 convolutions, kd = 1 for the 3x3 convolutions of a 2-D network (D = 1 or D = images: planes do not mix).
 extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                                long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile, forge_stream_t stream) {
-    FORGE_REQUIRE(tile == 0 || (tile >= 'A' && tile <= 'F'), FORGE_EINVAL, "forge_wino_gemm: tile must be 0 (default rule) or 'A'..'F'");
+    FORGE_REQUIRE(tile == 0 || (tile >= 'A' && tile <= 'E'), FORGE_EINVAL, "forge_wino_gemm: tile must be 0 (default rule) or 'A'..'E'");
     FORGE_REQUIRE(V1 && U && Mm && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_gemm: null pointer argument / kd not 1 or 3");
     FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 16, FORGE_EINVAL, "forge_wino_gemm: bad dims n=%d D=%d Ht=%d Wt=%d Cout=%d (Cout > 16)", n,
                   D, Ht, Wt, Cout);

@@ -173,7 +173,7 @@ int forge_resize_bilinear_bwd(const float* g, float* din, int P, int Hi, int Wi,
  *            GEMM column j = z*(Cout/lift) + c of row (n, h, w) is written to out[n][z][h][w][c] (a channels-last
  *            (n, lift, H, W) volume with Cout/lift channels). The caller orders the weight rows accordingly.
  *   tile / ksplit: the launch plan. tile = 0: planned inside the call (forge_conv_igemm_plan's model; split-K only if splitk_ws is given).
- *            tile = 'A'..'F' with ksplit >= 1: the caller's plan, taken verbatim (normally forge_conv_igemm_plan's answer, so that the
+ *            tile = 'A'..'E' with ksplit >= 1: the caller's plan, taken verbatim (normally forge_conv_igemm_plan's answer, so that the
  *            caller can size splitk_ws to ksplit M Cout floats; also how tools / tests pin a tile). Ignored for Cout <= 16.
  *   splitk_ws (nullable, splitk_ws_bytes): scratch for split-K. When the M x Cout tile grid alone cannot fill the chip
  *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
@@ -234,7 +234,7 @@ int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, l
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                     long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile /* 0 = forge_wino_gemm_tile's rule */,
                     forge_stream_t stream);
-int forge_wino_gemm_tile(long long R, int Cout, int Cin);   /* the workgroup tile letter ('A'..'F', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point, Cin = C1 + C2 */
+int forge_wino_gemm_tile(long long R, int Cout, int Cin);   /* the workgroup tile letter ('A'..'E', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point, Cin = C1 + C2 */
 int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
                       int ldo, int epilogue, forge_stream_t stream);

@@ -340,7 +340,7 @@ def test_joint_finetune_step_ray_sharded_two_ranks_equal_one_process():
     import numpy as np
     res = _spawn2(_joint_worker, timeout=600)
     ref_loss, ref_terms, ref_g = _joint_step(torch.device("cuda:0"), False)
-    _, _, ref_g2 = _joint_step(torch.device("cuda:0"), False)
+    more = [_joint_step(torch.device("cuda:0"), False)[2] for _ in range(2)]
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-20))
     for r in (0, 1):
         loss, terms, g = res[r]
@@ -350,9 +350,10 @@ def test_joint_finetune_step_ray_sharded_two_ranks_equal_one_process():
         for k, ref in ref_g.items():
             # the step's parameter gradients are not bit-reproducible run to run (fp32 atomics in the ray-march / weight-gradient kernels feed
             # ill-conditioned sums: tools/debug/joint_shard_noise.py measures 3e-5 ... 4e-3 relative L2 between two SINGLE-process runs), so the
-            # bound is that measured noise floor, not zero; the exact hand-over (d volume, d cameras at 1e-5) is pinned by the test above
-            floor = rel(ref_g2[k], ref)
-            assert rel(g[k], ref) <= max(5e-4, 5.0 * floor), (r, k, rel(g[k], ref), floor)
+            # bound is that noise floor - the largest distance among THREE single-process runs of this very process, the distribution is heavy-tailed -
+            # not zero; the exact hand-over (d volume, d cameras at 1e-5) is pinned by the test above
+            floor = max(rel(more[0][k], ref), rel(more[1][k], ref), rel(more[1][k], more[0][k]))
+            assert rel(g[k], ref) <= max(1e-3, 5.0 * floor), (r, k, rel(g[k], ref), floor)
 
 
 def _syncbn_worker(rank, world, port, q):

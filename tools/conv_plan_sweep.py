@@ -82,7 +82,7 @@ for (M, N, C, T) in SHAPES:
         t = timeit(run)
         res[("model",)] = min(res.get(("model",), 1e9), t)
         for tile in TILES:
-            if N <= 32 and tile in "ABIL":
+            if N <= 32 and tile in "ABGI":
                 continue
             for k in SPLITS:
                 with co.force_plan(tile, k):

@@ -1,5 +1,5 @@
-"""LDS-DMA tile F (64x128, three LDS stages) against its register-staged twin B: identical K order, so the
-results must be bitwise equal; then the time of the gates launches (tools/debug/gemm_ceiling.py)."""
+"""Every tile of conv_igemm_kernel (LDS-DMA staged K loop) on ragged direct and Winograd problems: all tiles must agree to fp32 summation-order
+noise; then the time of the gates launches (tools/debug/gemm_ceiling.py)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,7 +15,7 @@ for (B, D, C1, C2, Cout, taps) in ((1, 8, 32, 0, 32, co.TAPS_3x3x3), (1, 16, 128
     w = torch.randn(len(taps), Cout, C1 + C2, device=dev) * 0.05
     bias = torch.randn(Cout, device=dev)
     outs = {}
-    for tile in "BF":
+    for tile in "ABCDE":
         for ks in (1, 3):
             if ks > len(taps) * ((C1 + C2) // 32):
                 continue
@@ -24,10 +24,10 @@ for (B, D, C1, C2, Cout, taps) in ((1, 8, 32, 0, 32, co.TAPS_3x3x3), (1, 16, 128
                 co.conv_igemm(x, C1, C1, h, C2, C2, w, bias, None, None, 1.0, None, None, None, o, None, (B, D, D, D), (D, D, D), Cout, Cout, taps, epilogue=co.EPI_BIAS)
             outs[(tile, ks)] = o
     torch.cuda.synchronize()
-    for (a, b) in (("B", "F"),):
-        for ks in (1, 3):
-            if (a, ks) in outs:
-                eq = torch.equal(outs[(a, ks)], outs[(b, ks)])
-                bad += not eq
-                print("shape", (B, D, C1, C2, Cout, len(taps)), a, b, "ksplit", ks, "bitwise equal" if eq else "MISMATCH max %g" % (outs[(a, ks)] - outs[(b, ks)]).abs().max().item())
+    ref = outs[("A", 1)]
+    for k, o in outs.items():
+        err = (o - ref).abs().max().item()
+        ok = err < 2e-5 * ref.abs().max().item()
+        bad += not ok
+        print("shape", (B, D, C1, C2, Cout, len(taps)), k, "max diff vs A/1 %.2e" % err, "" if ok else "MISMATCH")
 print("dma_tile_check:", "OK" if not bad else "%d MISMATCHES" % bad)

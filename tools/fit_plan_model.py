@@ -1,13 +1,13 @@
 #!/usr/bin/env python
-"""Fit the (eff, ov) constants of NEW tiles of csrc/conv_igemm.hip: plan_conv on the sweeps tools/conv_plan_sweep.py wrote
+"""Fit the (eff, ov) constants of the tiles of csrc/conv_igemm.hip: plan_conv on the sweeps tools/conv_plan_sweep.py wrote
 (gpurun_out/plan_sweep*.json). Python replica of plan_conv; a coordinate search over the constants of the tiles named in FIT_TILES with the
 others fixed; prints the loss of the chosen plans against the per-shape best (sum of microseconds) before and after."""
 import itertools, json, math, os, sys
 
 TILES = {  # id: [bm, bn, occ, eff, ov]
     "A": [128, 128, 2, 1.000, 4.0], "B": [64, 128, 3, 0.983, 1.0], "C": [128, 64, 3, 0.969, 1.0], "D": [64, 64, 5, 0.980, 1.0], "E": [128, 32, 4, 0.915, 1.0],
-    "H": [64, 64, 3, 1.00, 1.5], "I": [64, 128, 2, 1.00, 1.5], "J": [128, 64, 2, 1.00, 1.5],
 }
+RENAME = dict(kv.split(":") for kv in os.environ.get("FIT_RENAME", "").split(",") if kv)   # e.g. G:A,H:D,I:B,J:C,K:E for sweeps that carried experimental letters
 SPLITS = [1, 2, 3, 4, 6, 8]
 WS = 128 << 20
 
@@ -67,10 +67,13 @@ def loss(tiles, data):
 
 files = sys.argv[1:] or ["gpurun_out/plan_sweep_dma.json", "gpurun_out/plan_sweep_dma_s4.json"]
 sets = [json.load(open(f)) for f in files]
-fit = os.environ.get("FIT_TILES", "HIJ")
-old = {k: v for k, v in TILES.items() if k in "ABCDE"}
+if RENAME:
+    for d in sets:
+        for x in d:
+            x["us"] = {RENAME[k[0]] + k[1:]: v for k, v in x["us"].items() if k[0] in RENAME}
+fit = os.environ.get("FIT_TILES", "ABCDE")
 for f, d in zip(files, sets):
-    print("%-44s A-E only: chosen %.1f us / best-of-A-E-H-I-J %.1f us" % (f, *loss(old, d)))
+    print("%-44s current constants: chosen %.1f us / best %.1f us" % (f, *loss(TILES, d)))
 # weight the sets equally (relative loss)
 def total(tiles):
     return sum(loss(tiles, d)[0] / loss(tiles, d)[1] for d in sets)
@@ -78,7 +81,7 @@ cur = {k: list(v) for k, v in TILES.items()}
 for it in range(4):
     for tid in fit:
         bestv, bl = None, 1e300
-        for eff, ov in itertools.product([0.94 + 0.01 * i for i in range(14)], [0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]):
+        for eff, ov in itertools.product([1.0] if tid == "A" else [0.90 + 0.01 * i for i in range(36)], [0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]):   # only ratios matter: A's eff stays 1
             cur[tid][3], cur[tid][4] = eff, ov
             l = total(cur)
             if l < bl - 1e-9:

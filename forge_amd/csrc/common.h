@@ -63,4 +63,29 @@ __device__ __forceinline__ float4 f4_fma(float w, float4 v, float4 a) {
 // hardware fp32 atomic add (global_atomic_add_f32), no CAS loop
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// ---- LDS-DMA (gfx950): global memory -> LDS without staging registers -------------------------------------------------------------
+// lds_dma16(rsrc, voff, lds): `buffer_load_dwordx4 v, s[rsrc], 0 offen lds` with M0 = lds. Every lane of the wave loads the 16 bytes at
+// buffer byte offset voff[lane] and the hardware writes them to LDS byte address lds + 16 lane (lds must be wave-uniform); lanes whose
+// offset lies outside the buffer's num_records write zeros (the halo / ragged-edge padding of every GEMM here). It is inline assembly
+// on purpose: the compiler's waitcnt insertion does not see these loads, so the K loops place their own `s_waitcnt vmcnt(0)` directly
+// in front of the barrier that publishes the stage, AFTER the step's MFMAs (the builtin form is drained before them).
+typedef int forge_v4i32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ forge_v4i32 make_rsrc_words(const void* base, long long bytes) {     // raw dword buffer, stride 0
+    const unsigned long long p = (unsigned long long)base;
+    forge_v4i32 r;
+    r.x = (int)(p & 0xffffffffull); r.y = (int)((p >> 32) & 0xffffull); r.z = (int)bytes; r.w = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ void lds_dma16(const forge_v4i32& rsrc, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory");
+}
+
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned lds_addr(const void* smem_ptr) {                             // LDS byte address of a __shared__ pointer
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)smem_ptr;
+}
+
 }  // namespace forge

@@ -98,16 +98,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
-typedef int v4i32 __attribute__((ext_vector_type(4)));
-
-// buffer resource words (base, stride 0, num_records, raw dword format) as four SGPRs for the hand-placed LDS-DMA loads below
-__device__ __forceinline__ v4i32 make_rsrc_words(const void* base, long long bytes) {
-    const unsigned long long p = (unsigned long long)base;
-    v4i32 r;
-    r.x = (int)(p & 0xffffffffull); r.y = (int)((p >> 32) & 0xffffull); r.z = (int)bytes; r.w = 0x00020000;
-    return r;
-}
-
 // Operand staging is LDS-DMA: `buffer_load_dwordx4 ... offen lds` (M0 = the wave's LDS byte address; lane L lands at + 16 L, out-of-range
 // lanes write zeros) puts a K-step's A / B rows straight into the other LDS stage - no staging VGPRs, no ds_write. The loads are inline
 // assembly because the compiler's own waitcnt insertion would drain them (vmcnt(0)) BEFORE the step's MFMAs (round 2's builtin-based variant
@@ -159,10 +149,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
     const int nsteps = s_end - s_begin;
 
-    const v4i32 w1 = make_rsrc_words(a.in1 + pb * a.pt1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 + pb * a.pt2 : a.in1, a.in2 ? a.span2 : 0),
+    const forge_v4i32 w1 = make_rsrc_words(a.in1 + pb * a.pt1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 + pb * a.pt2 : a.in1, a.in2 ? a.span2 : 0),
                 ww = make_rsrc_words(a.wp + pb * a.ptw, (long long)a.ntaps * a.Cout * Cin * 4);
     // LDS byte address of this WAVE's first 1 KB block of a stage (lane L lands at + 16 L: the row-major [row][32 k] image, 8 lanes per row)
-    const unsigned lds_wave = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    const unsigned lds_wave = lds_addr(smem) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     // ---- per-thread staging geometry: ACH A rows, BCH B rows, one 16-byte chunk each
     const int cp = tid & 7;                                      // physical chunk in the 128-byte LDS row
     int ar[ACH], az[ACH], ay[ACH], ax[ACH], an[ACH], asrc[ACH];
@@ -246,22 +236,19 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
     // LDS-DMA: chunk j of this thread is row (tid >> 3) + RPP j = LDS bytes 16 tid + j NW 1024 -> per wave a lane-linear 1 KB block
-    auto dma16 = [&](const v4i32& rs, unsigned voff, unsigned ldsaddr) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(ldsaddr), "v"(voff), "s"(rs) : "memory");
-    };
     auto issue_step = [&](int t, int kc, int buf) {
         const int c0 = kc * BK;
         const unsigned stage = lds_wave + (unsigned)buf * (unsigned)((A_FLOATS + B_FLOATS) * 4);
         if (c0 < a.C1) {
 #pragma unroll
-            for (int j = 0; j < ACH; ++j) dma16(w1, eoff[j] + (unsigned)(c0 * 4), stage + (unsigned)(j * NW * 1024));
+            for (int j = 0; j < ACH; ++j) lds_dma16(w1, eoff[j] + (unsigned)(c0 * 4), stage + (unsigned)(j * NW * 1024));
         } else {
 #pragma unroll
-            for (int j = 0; j < ACH; ++j) dma16(w2, eoff2[j] + (unsigned)((c0 - a.C1) * 4), stage + (unsigned)(j * NW * 1024));
+            for (int j = 0; j < ACH; ++j) lds_dma16(w2, eoff2[j] + (unsigned)((c0 - a.C1) * 4), stage + (unsigned)(j * NW * 1024));
         }
         const unsigned wbase = (unsigned)((t * a.Cout * Cin + c0) * 4);
 #pragma unroll
-        for (int j = 0; j < BCH; ++j) dma16(ww, boff[j] + wbase, stage + (unsigned)(A_FLOATS * 4 + j * NW * 1024));
+        for (int j = 0; j < BCH; ++j) lds_dma16(ww, boff[j] + wbase, stage + (unsigned)(A_FLOATS * 4 + j * NW * 1024));
     };
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -291,7 +278,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     };
     prep_tap(t);
     issue_step(t, kc, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_dma_wait();
     __syncthreads();
     FORGE_STAMP(1);
     // One K-step = 4 MFMA groups of 8 k-values. (A/B in round 1: issuing the next tile's global loads after group 0 and its LDS
@@ -329,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) mfma_group(sa, sb, g);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part of step s + 1 is in LDS ...
+        lds_dma_wait();                                           // this wave's part of step s + 1 is in LDS ...
         __syncthreads();                                          // ... and so is everybody else's
     }
 

@@ -7,7 +7,7 @@
 // wants from LDS without any transpose: lane l supplies A[i = l&31][k = l>>5], so a half-wave reads 32 CONSECUTIVE floats
 // of one LDS row (conflict-free ds_read_b32). Workgroup = 4 waves (2 x 2, wave tile 64 x 64 with even/odd channel interleave: one 8-byte LDS read feeds two MFMAs), tile 128(co) x 128(ci) for one
 // tap over one M-chunk, K-step = 16 voxels (32 KiB of LDS, 112 VGPRs: 4 workgroups per CU; with 32-voxel steps and 2 workgroups per
-// CU the same kernel ran 7-16 % slower), register-staged buffer loads (out-of-range rows / taps -> 0), double-buffered LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
+// CU the same kernel ran 7-16 % slower), LDS-DMA staged operands (`buffer_load ... lds`, out-of-range rows / taps -> 0; common.h), double-buffered LDS, partial sums added to dW with hardware fp32 atomics (split-K over M-chunks so that the chip is filled:
 // taps x tiles alone is only ~100 workgroups). dW must be zero-filled by the caller.
 //
 // Replaces torch's conv3d weight-gradient (cuDNN/MIOpen) for the ConvGRU / fusion_conv / conv1 convolutions
@@ -68,10 +68,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int co0 = co_t * WT, ci0 = ci_t * CIW;
 
     const long long pb = a.tpp > 0 ? t / a.tpp : 0;                  // batched problems: this tap's operands
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + pb * a.pty), 0, (int)a.spany, 0x00020000);
+    const forge_v4i32 ry = make_rsrc_words(a.dy + pb * a.pty, a.spany);
     const bool second = ci0 >= a.C1;                                 // this ci tile lives in x2
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(second ? a.x2 + pb * a.pt2 : a.x1 + pb * a.pt1), 0,
-                                                                        (int)(second ? a.span2 : a.span1), 0x00020000);
+    const forge_v4i32 rx = make_rsrc_words(second ? a.x2 + pb * a.pt2 : a.x1 + pb * a.pt1, second ? a.span2 : a.span1);
     const int ldx = second ? a.ld2 : a.ld1, cx0 = second ? ci0 - a.C1 : ci0, Cx = second ? a.C2 : a.C1;
     const long long bsx = second ? a.bs2r : a.bs1r;
     const int dz = a.tap[t][0], dy_ = a.tap[t][1], dx = a.tap[t][2];
@@ -79,7 +78,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = (tid >> 5) + 8 j, chunk = tid & 31)
     const int sc4 = (tid & 31) << 2;
     const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = sc4 < CIW && cx0 + sc4 < Cx;
-    float4 ra[WJ], rb[WJ];
     // voxel coordinates of the staged rows, advanced by WK rows per K-step (no per-step divisions)
     int rx_[WJ], ry_[WJ], rz_[WJ], rn_[WJ];
 #pragma unroll
@@ -96,31 +94,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const unsigned ycol_off = (unsigned)(co0 + sc4), xcol_off = (unsigned)(cx0 + sc4);
     const int is_ = a.is, Wg = a.W, Hg = a.H, Dg = a.D, Wi_ = a.Wi, Hi_ = a.Hi, Di_ = a.Di;
     const int trow = tid >> 5;
-    auto load_step = [&](int s) {
+    // LDS-DMA staging (common.h: lds_dma16): chunk j of this thread is LDS bytes 16 tid + 4096 j of the A / B image = per wave a lane-linear
+    // 1 KB block; rows / taps / channels out of range read offset OOBW and land as zeros.
+    const unsigned lds_wave = lds_addr(smem) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto issue_step = [&](int s, int buf) {
+        const unsigned stage = lds_wave + (unsigned)buf * (unsigned)(2 * WK * WT * 4);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             // 32-bit offsets: every operand span is < 2 GiB (checked on the host side)
             const unsigned m = mbeg_u + (unsigned)(s * WK + trow + 8 * j);
             const bool mok = m < mend_u;
-            ra[j] = buf_load16w(ry, (mok && ycol_ok) ? (m * ldy_u + ycol_off) * 4u : OOBW);
+            lds_dma16(ry, (mok && ycol_ok) ? (m * ldy_u + ycol_off) * 4u : OOBW, stage + (unsigned)(j * 4096));
             const int x = rx_[j] * is_ + dx, y = ry_[j] * is_ + dy_, z = rz_[j] * is_ + dz;
             const bool ok = mok && xcol_ok && (unsigned)z < (unsigned)Di_ && (unsigned)y < (unsigned)Hi_ && (unsigned)x < (unsigned)Wi_;
             const unsigned e = (unsigned)rn_[j] * bsx_u + (unsigned)((z * Hi_ + y) * Wi_ + x);
-            rb[j] = buf_load16w(rx, ok ? (e * ldx_u + xcol_off) * 4u : OOBW);
+            lds_dma16(rx, ok ? (e * ldx_u + xcol_off) * 4u : OOBW, stage + (unsigned)(WK * WT * 4 + j * 4096));
             rx_[j] += WK;                                         // advance to the row of the next K-step
             while (rx_[j] >= Wg) {
                 rx_[j] -= Wg;
                 if (++ry_[j] == Hg) { ry_[j] = 0; if (++rz_[j] == Dg) { rz_[j] = 0; ++rn_[j]; } }
             }
-        }
-    };
-    auto store_step = [&](int buf) {
-        float* sa = smem + buf * (2 * WK * WT);
-        float* sb = sa + WK * WT;
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) {
-            *reinterpret_cast<float4*>(sa + ((tid >> 5) + 8 * j) * WT + sc4) = ra[j];
-            *reinterpret_cast<float4*>(sb + ((tid >> 5) + 8 * j) * WT + sc4) = rb[j];
         }
     };
 
@@ -134,15 +127,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
 
-    if (nsteps > 0) {
-        load_step(0);
-        store_step(0);
-    }
+    if (nsteps > 0) issue_step(0, 0);
+    lds_dma_wait();
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) load_step(s + 1);
+        if (s + 1 < nsteps) issue_step(s + 1, buf ^ 1);           // the other stage was last read in step s - 1; in flight under this step's MFMAs
         const float* sa = smem + buf * (2 * WK * WT) + (P == 2 ? wm * 64 + 2 * l31 : wm * 32 + l31);
         const float* sb = smem + buf * (2 * WK * WT) + WK * WT + (Q == 2 ? wn * 64 + 2 * l31 : l31);
 #pragma unroll
@@ -158,7 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int q = 0; q < Q; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[p], fb[q], acc[p][q], 0, 0, 0);
         }
-        if (more) store_step(buf ^ 1);
+        lds_dma_wait();
         __syncthreads();
     }
 

@@ -74,7 +74,9 @@ typedef int forge_v4i32 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ forge_v4i32 make_rsrc_words(const void* base, long long bytes) {     // raw dword buffer, stride 0
     const unsigned long long p = (unsigned long long)base;
     forge_v4i32 r;
-    r.x = (int)(p & 0xffffffffull); r.y = (int)((p >> 32) & 0xffffull); r.z = (int)bytes; r.w = 0x00020000;
+    // readfirstlane: the words must live in SGPRs (an "s" operand of the inline assembly) even where the compiler cannot prove the base uniform
+    r.x = __builtin_amdgcn_readfirstlane((int)(p & 0xffffffffull)); r.y = __builtin_amdgcn_readfirstlane((int)((p >> 32) & 0xffffull));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes); r.w = 0x00020000;
     return r;
 }
 

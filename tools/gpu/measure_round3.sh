@@ -23,4 +23,6 @@ r=d["roofline"]; print({k:r[k] for k in ("frac","executed_frac","floor_ms","step
 for e in d["extra_configs"]: print(e["name"], round(e.get("ms_per_step",0),2), round(e.get("views_per_s",0),1), e.get("pipelined"), e.get("error"))
 print(json.dumps(d["cpu_baseline"])[:700])
 PY
+for d in 2 3 4 6; do PIPE_DEPTH=$d PIPE_STEPS=120 python tools/pipeline_probe.py 2>&1 | grep "in flight"; done > gpurun_out/r03_pipeline_depth.txt; cat gpurun_out/r03_pipeline_depth.txt
+for s in 1 4; do TRAIN_SCENES=$s bash tools/gpu/run_trainprof.sh > gpurun_out/r03_train_step_kernel_stats_b$s.txt 2>&1; head -3 gpurun_out/r03_train_step_kernel_stats_b$s.txt | tail -1; done
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

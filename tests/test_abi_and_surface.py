@@ -173,6 +173,8 @@ def test_conv_plan_is_host_arithmetic_and_sane():
         for N in (17, 32, 64, 96, 2048):
             t, k = co.conv_plan(M, N, 64, 1, co.EPI_BIAS, N)
             assert t in "ABCDE" and k == 1                                               # 2 K-steps: never split
+    # forge_wino_gemm_tile (host arithmetic too): the 16-problem Winograd launches take the 64x128 tile, the 2-D trunk's tiny ones 64x64
+    assert co.wino_gemm_tile(8192, 256, 256) == "B" and co.wino_gemm_tile(40960, 128, 64) == "B" and co.wino_gemm_tile(320, 256, 256) == "D"
 
 
 def test_loss_functions_match_reference_golden():

@@ -25,6 +25,10 @@ SIGNATURES = {
     "forge_rotate_fwd_slots": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_rotate_xf_from_poses": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_pose_chain_fwd": [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "forge_adam_small": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P],
+    "forge_rotate_bwd_slots": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "forge_pose_chain_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
     "forge_pack_cameras": [_P, _LL, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _LL, _P, _P, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],

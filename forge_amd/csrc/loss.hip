@@ -76,9 +76,37 @@ static int fill_args(SseArgs& a, const char* fn, const float* pred, const float*
     return 0;
 }
 
+// torch.optim.Adam (no weight decay, no amsgrad) on ONE small tensor: p -= lr / (1 - b1^k) * m / (sqrt(v) / sqrt(1 - b2^k) + eps) after
+// m = lerp(m, g, 1 - b1), v = b2 v + (1 - b2) g^2, with the step count k kept on the device (the captured refinement iteration advances
+// it itself). One workgroup: the refinement loop optimises b (t-1) x 7 numbers, for which the capturable torch optimiser issues ~30 launches.
+__global__ __launch_bounds__(256) void adam_small_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ step, int n, float lr, float b1, float b2, float eps) {
+    const float k = step[0] + 1.f;
+    __syncthreads();
+    if (threadIdx.x == 0) step[0] = k;
+    const float bc1 = 1.f - powf(b1, k), bc2 = 1.f - powf(b2, k);
+    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);          // Tensor.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;          // mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
+
+extern "C" int forge_adam_small(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int n, float lr, float beta1, float beta2,
+                                float eps, forge_stream_t stream) {
+    FORGE_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && n > 0, FORGE_EINVAL, "forge_adam_small: null pointer argument or n <= 0");
+    FORGE_REQUIRE(n <= (1 << 20), FORGE_ESHAPE, "forge_adam_small: n=%d - a one-workgroup kernel for small parameter sets", n);
+    hipLaunchKernelGGL(adam_small_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, step, n, lr, beta1, beta2, eps);
+    FORGE_LAUNCH_CHECK("forge_adam_small");
+    return 0;
+}
 
 extern "C" int forge_sse_groups_blocks(void) { return 1024; }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
 // kernel below; its first version scatter-added 8 x C fp32 atomics per voxel from here.)
 __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
                                                          const float* __restrict__ xf, const int* __restrict__ mode,
-                                                         float* __restrict__ dxf,
+                                                         const int* __restrict__ src_slot, float* __restrict__ dxf,
                                                          int C4, int D, int H, int W, long long per_vol,
                                                          unsigned blocks_per_vol) {
     __shared__ float red[12][4];   // per-wave partials of d xf
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __
         const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
         TriTaps t;
         taps_ac_false(sx, sy, sz, W, H, D, t);
-        const float4 g = dout[(long long)n * per_vol + e];
+        const float4 g = dout[(long long)(src_slot ? src_slot[n] : n) * per_vol + e];     // forge_rotate_fwd_slots stored view n at volume slot[n]
         const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
         float gsx = 0.f, gsy = 0.f, gsz = 0.f;   // d loss / d pixel coordinate
 #pragma unroll
@@ -213,14 +213,14 @@ __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __
 // the exact transpose of rotate_fwd_kernel; it is deterministic (fixed summation order) and dvox is written, not accumulated.
 template <int NQ>
 __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __restrict__ dout, const float* __restrict__ xf,
-                                                                const int* __restrict__ mode, float4* __restrict__ dvox,
+                                                                const int* __restrict__ mode, const int* __restrict__ src_slot, float4* __restrict__ dvox,
                                                                 int C4, int D, int H, int W, unsigned per_vol, unsigned blocks_per_vol) {
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const unsigned n = bid / blocks_per_vol;
     const unsigned CQ = (unsigned)C4 / NQ;                           // threads per voxel, NQ channel groups each (as in rotate_fwd_kernel)
     const unsigned tq = (bid % blocks_per_vol) * 256u + threadIdx.x;
     if (tq >= per_vol / NQ) return;
-    const float4* g = dout + (size_t)n * per_vol;
+    const float4* g = dout + (size_t)(src_slot ? (unsigned)src_slot[n] : n) * per_vol;
     float4* dv = dvox + (size_t)n * per_vol;
     const unsigned c4 = tq % CQ;
     int qx, qy, qz;
@@ -348,6 +348,151 @@ __global__ void pose_xf_kernel(const float* __restrict__ poses, float* __restric
     }
 }
 
+// ---- pose chain of the refinement loop (kubric_eval.py:412-530, demo.py:115-188) -----------------------------------------------------------
+// From the optimised 7-D relative poses (raw quaternion, translation) of the non-reference views to BOTH kernel operands - the warp's affine
+// xf = [R_T | t_T / e] with T = P_0 P_i^-1 (models/rotate.py:64-89,132-135) and the ray-marcher's packed cameras [R | T | fx fy cx cy] from the
+// extrinsics P_i^-1 (models/volume_render.py:40-51) - in ONE launch, with the Jacobian of the 24 pose-dependent outputs w.r.t. the 7 inputs by
+// forward-mode differentiation (dual numbers), so that the backward is one tiny matrix-vector kernel. The torch algebra it replaces
+// (F.normalize, quat2mat, canonical @ rel, inverse_affine twice, P_0 @ inverse, cat / stack / slicing and all their autograd nodes) was ~250
+// launches of 3-8 us per iteration inside the captured graph. Same formulas in the same order as forge_amd/geo_utils.py.
+struct Dual7 {
+    float v, d[7];
+};
+__device__ __forceinline__ Dual7 dconst(float c) { Dual7 r; r.v = c; for (int i = 0; i < 7; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ Dual7 dvar(float x, int k) { Dual7 r = dconst(x); r.d[k] = 1.f; return r; }
+__device__ __forceinline__ Dual7 operator+(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v + b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator-(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v - b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator-(const Dual7& a) { Dual7 r; r.v = -a.v; for (int i = 0; i < 7; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator*(const Dual7& a, const Dual7& b) { Dual7 r; r.v = a.v * b.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator*(float c, const Dual7& a) { Dual7 r; r.v = c * a.v; for (int i = 0; i < 7; ++i) r.d[i] = c * a.d[i]; return r; }
+__device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) {
+    Dual7 r; r.v = a.v / b.v;
+    const float ib = 1.f / b.v;
+    for (int i = 0; i < 7; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib;
+    return r;
+}
+__device__ __forceinline__ Dual7 dsqrt(const Dual7& a) { Dual7 r; r.v = sqrtf(a.v); const float h = 0.5f / r.v; for (int i = 0; i < 7; ++i) r.d[i] = a.d[i] * h; return r; }
+
+// translation row i of can_p @ [R | tr]: the one expression both the pose output and the view ranking use
+__device__ __forceinline__ float pose_translation(const float* __restrict__ can_p, const float* __restrict__ tr, int i) {
+    return fmaf(can_p[i * 4], tr[0], fmaf(can_p[i * 4 + 1], tr[1], fmaf(can_p[i * 4 + 2], tr[2], can_p[i * 4 + 3])));
+}
+
+// One thread per view (b t of them). rot [b (t-1)][4], trans [b (t-1)][3]; can_p / can_e: pose and extrinsics of the reference view (row-major 4x4);
+// K [b t][9] full-resolution intrinsics. Outputs: xf [b t][12], mode [b t], cam [b t][16], poses [b t][16], origin [b t][2] (nullable),
+// jac [b (t-1)][24][7] (nullable): d (xf[0..11], cam[0..11]) / d (quaternion, translation).
+__global__ void pose_chain_fwd_kernel(const float* __restrict__ rot, const float* __restrict__ trans, const float* __restrict__ can_p,
+                                      const float* __restrict__ can_e, const float* __restrict__ K, float e, int b, int t, float* __restrict__ xf,
+                                      int* __restrict__ mode, int* __restrict__ slot, float* __restrict__ cam, float* __restrict__ poses,
+                                      float* __restrict__ origin, float* __restrict__ jac) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= b * t) return;
+    const int v = idx % t;
+    if (slot) {
+        // view order of models/model.py:152-158 (stable sort by squared distance of the camera position to view 0's): slot = scene's first volume +
+        // rank of this view. The camera position of view j is the translation of its pose, can_p_A trans_j + can_p_t - no quaternion involved -,
+        // evaluated here for every view of the scene with the SAME fmaf chain that produces this kernel's `poses` output, and ranked on
+        // ((dx^2 + dy^2) + dz^2) without fused multiply-adds like sequence_from_distance's reduction.
+        auto cam_pos = [&](int j, float* o) {
+            if (j == 0) { o[0] = can_p[3]; o[1] = can_p[7]; o[2] = can_p[11]; return; }
+            const float* tj = trans + ((long long)(idx / t) * (t - 1) + j - 1) * 3;
+            for (int i = 0; i < 3; ++i) o[i] = pose_translation(can_p, tj, i);
+        };
+        auto dist = [&](int j) {
+            float p0[3], pj[3];
+            cam_pos(0, p0); cam_pos(j, pj);
+            const float dx = pj[0] - p0[0], dy = pj[1] - p0[1], dz = pj[2] - p0[2];
+            return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        };
+        const float di = dist(v);
+        int rank = 0;
+        for (int j = 0; j < t; ++j) {
+            const float dj = dist(j);
+            rank += (dj < di || (dj == di && j < v)) ? 1 : 0;
+        }
+        slot[idx] = (idx - v) + rank;
+    }
+    const float* Kv = K + (long long)idx * 9;
+    const float fx = Kv[0] / 2.f, fy = Kv[4] / 2.f, cx = Kv[2] / 2.f, cy = Kv[5] / 2.f;     // models/volume_render.py:50-51
+    float* xo = xf + (long long)idx * 12;
+    float* co = cam + (long long)idx * 16;
+    float* po = poses + (long long)idx * 16;
+    mode[idx] = v == 0 ? 0 : 1;
+    co[12] = fx; co[13] = fy; co[14] = cx; co[15] = cy;
+    if (v == 0) {                                                    // the reference view: identity warp, canonical camera
+        for (int k = 0; k < 12; ++k) xo[k] = 0.f;
+        for (int k = 0; k < 16; ++k) po[k] = can_p[k];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) co[r * 3 + c] = can_e[r * 4 + c];
+            co[9 + r] = can_e[r * 4 + 3];
+        }
+        if (origin) { origin[idx * 2] = fx * co[9] / co[11] + cx; origin[idx * 2 + 1] = fy * co[10] / co[11] + cy; }
+        return;
+    }
+    const int k = (idx / t) * (t - 1) + v - 1;
+    Dual7 q[4], tr[3];
+    for (int i = 0; i < 4; ++i) q[i] = dvar(rot[k * 4 + i], i);
+    for (int i = 0; i < 3; ++i) tr[i] = dvar(trans[k * 3 + i], 4 + i);
+    // F.normalize(rot) (refine.py), then quat2mat_transform's own q / |q| (geo_utils.py:54)
+    Dual7 n1 = dsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (n1.v < 1e-12f) n1 = dconst(1e-12f);
+    for (int i = 0; i < 4; ++i) q[i] = q[i] / n1;
+    const Dual7 n2 = dsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const Dual7 w = q[0] / n2, x = q[1] / n2, y = q[2] / n2, z = q[3] / n2;
+    Dual7 R[3][3];
+    R[0][0] = w * w + x * x - y * y - z * z; R[0][1] = 2.f * x * y - 2.f * w * z;     R[0][2] = 2.f * w * y + 2.f * x * z;
+    R[1][0] = 2.f * w * z + 2.f * x * y;     R[1][1] = w * w - x * x + y * y - z * z; R[1][2] = 2.f * y * z - 2.f * w * x;
+    R[2][0] = 2.f * x * z - 2.f * w * y;     R[2][1] = 2.f * w * x + 2.f * y * z;     R[2][2] = w * w - x * x - y * y + z * z;
+    // pose = can_p @ [R | tr]
+    Dual7 A[3][3], tp[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) A[i][j] = can_p[i * 4] * R[0][j] + can_p[i * 4 + 1] * R[1][j] + can_p[i * 4 + 2] * R[2][j];
+        tp[i] = can_p[i * 4] * tr[0] + can_p[i * 4 + 1] * tr[1] + can_p[i * 4 + 2] * tr[2] + dconst(can_p[i * 4 + 3]);
+        tp[i].v = pose_translation(can_p, trans + k * 3, i);       // the value with the pinned fmaf chain (the derivatives do not depend on it)
+    }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) po[i * 4 + j] = A[i][j].v; po[i * 4 + 3] = tp[i].v; }
+    po[12] = 0.f; po[13] = 0.f; po[14] = 0.f; po[15] = 1.f;
+    // extrinsics = inverse_affine(pose): A^-1 = [b x c, c x a, a x b] / det, t' = -A^-1 t (geo_utils.py:108-122)
+    auto cross = [](const Dual7* u, const Dual7* w2, Dual7* o) {
+        o[0] = u[1] * w2[2] - u[2] * w2[1]; o[1] = u[2] * w2[0] - u[0] * w2[2]; o[2] = u[0] * w2[1] - u[1] * w2[0];
+    };
+    Dual7 bc[3], ca[3], ab[3];
+    cross(A[1], A[2], bc); cross(A[2], A[0], ca); cross(A[0], A[1], ab);
+    const Dual7 det = A[0][0] * bc[0] + A[0][1] * bc[1] + A[0][2] * bc[2];
+    Dual7 Ai[3][3], ti[3];
+    for (int i = 0; i < 3; ++i) { Ai[i][0] = bc[i] / det; Ai[i][1] = ca[i] / det; Ai[i][2] = ab[i] / det; }
+    for (int i = 0; i < 3; ++i) ti[i] = -(Ai[i][0] * tp[0] + Ai[i][1] * tp[1] + Ai[i][2] * tp[2]);
+    // T = P_0 @ extrinsics with P_0 = can_p; xf = [T_A | T_t / e]
+    Dual7 out[24];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out[i * 4 + j] = can_p[i * 4] * Ai[0][j] + can_p[i * 4 + 1] * Ai[1][j] + can_p[i * 4 + 2] * Ai[2][j];
+        out[i * 4 + 3] = (1.f / e) * (can_p[i * 4] * ti[0] + can_p[i * 4 + 1] * ti[1] + can_p[i * 4 + 2] * ti[2] + dconst(can_p[i * 4 + 3]));
+    }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out[12 + i * 3 + j] = Ai[i][j]; out[21 + i] = ti[i]; }
+    for (int o = 0; o < 12; ++o) { xo[o] = out[o].v; co[o] = out[12 + o].v; }
+    if (origin) { origin[idx * 2] = fx * ti[0].v / ti[2].v + cx; origin[idx * 2 + 1] = fy * ti[1].v / ti[2].v + cy; }
+    if (jac) {
+        float* jo = jac + (long long)k * 24 * 7;
+        for (int o = 0; o < 24; ++o)
+            for (int i = 0; i < 7; ++i) jo[o * 7 + i] = out[o].d[i];
+    }
+}
+
+// drot [n][4], dtrans [n][3] = J^T (dxf row | dcam row[0..11]) per non-reference view; one thread per (view, input).
+__global__ void pose_chain_bwd_kernel(const float* __restrict__ jac, const float* __restrict__ dxf, const float* __restrict__ dcam, float* __restrict__ drot,
+                                      float* __restrict__ dtrans, int b, int t) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = b * (t - 1);
+    if (idx >= n * 7) return;
+    const int k = idx / 7, i = idx - k * 7;
+    const int row = (k / (t - 1)) * t + (k % (t - 1)) + 1;
+    const float* jo = jac + (long long)k * 24 * 7;
+    float acc = 0.f;
+    for (int o = 0; o < 12; ++o) acc = fmaf(dxf ? dxf[(long long)row * 12 + o] : 0.f, jo[o * 7 + i], acc);
+    for (int o = 0; o < 12; ++o) acc = fmaf(dcam ? dcam[(long long)row * 16 + o] : 0.f, jo[(12 + o) * 7 + i], acc);
+    if (i < 4) drot[k * 4 + i] = acc; else dtrans[k * 3 + (i - 4)] = acc;
+}
+
 // cameras_from_opencv_projection's inputs -> the ray-marcher's packed cameras (models/volume_render.py:40-51: K / 2 with K[2][2] = 1 on a
 // copy) and, optionally, the projected world origin (models/volume_render.py:77-79). One thread per camera; inputs may be strided views.
 __global__ void pack_cameras_kernel(const float* __restrict__ R, long long r0, long long r1, long long r2, const float* __restrict__ T, long long t0,
@@ -430,10 +575,29 @@ extern "C" int forge_pack_cameras(const float* R, long long r0, long long r1, lo
     return 0;
 }
 
-extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const int* mode,
-                                float* dvox, float* dxf, int n, int C, int D, int H, int W,
-                                forge_stream_t stream) {
-    if (int rc = check_rotate_args(dout, xf, mode, dvox, n, C, D, H, W)) return rc;
+extern "C" int forge_pose_chain_fwd(const float* rot, const float* trans, const float* can_pose, const float* can_extr, const float* K, float half_extent,
+                                    int b, int t, float* xf, int* mode, int* slot, float* cam16, float* poses, float* origin, float* jac, forge_stream_t stream) {
+    FORGE_REQUIRE(can_pose && can_extr && K && xf && mode && cam16 && poses, FORGE_EINVAL, "forge_pose_chain_fwd: null pointer argument");
+    FORGE_REQUIRE(b > 0 && t > 0 && half_extent > 0.f && (t == 1 || (rot && trans)), FORGE_EINVAL, "forge_pose_chain_fwd: bad b=%d t=%d e=%g", b, t, half_extent);
+    const int n = b * t;
+    hipLaunchKernelGGL(pose_chain_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, rot, trans, can_pose, can_extr, K, half_extent, b, t, xf,
+                       mode, slot, cam16, poses, origin, jac);
+    FORGE_LAUNCH_CHECK("forge_pose_chain_fwd");
+    return 0;
+}
+
+extern "C" int forge_pose_chain_bwd(const float* jac, const float* dxf, const float* dcam, float* drot, float* dtrans, int b, int t, forge_stream_t stream) {
+    FORGE_REQUIRE(jac && drot && dtrans && (dxf || dcam), FORGE_EINVAL, "forge_pose_chain_bwd: null pointer argument");
+    FORGE_REQUIRE(b > 0 && t > 1, FORGE_EINVAL, "forge_pose_chain_bwd: bad b=%d t=%d (t > 1)", b, t);
+    const int n = b * (t - 1) * 7;
+    hipLaunchKernelGGL(pose_chain_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, jac, dxf, dcam, drot, dtrans, b, t);
+    FORGE_LAUNCH_CHECK("forge_pose_chain_bwd");
+    return 0;
+}
+
+static int rotate_bwd_launch(const float* dout, const float* vox, const float* xf, const int* mode, const int* src_slot,
+                             float* dvox, float* dxf, int n, int C, int D, int H, int W, forge_stream_t stream) {
+    if (int rc = check_rotate_args(dout, xf, mode, dvox ? (const void*)dvox : (const void*)dxf, n, C, D, H, W)) return rc;     // at least one of dvox / dxf
     FORGE_REQUIRE(!dxf || vox, FORGE_EINVAL, "forge_rotate_bwd: dxf requested but vox is NULL");
     const int C4 = C / 4;
     const long long per_vol = (long long)D * H * W * C4;
@@ -444,14 +608,27 @@ extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float
     const unsigned bpg = (unsigned)((per_vol / nq + 255) / 256);
 #define FORGE_LAUNCH_GATHER(NQv)                                                                                            \
     hipLaunchKernelGGL(rotate_bwd_gather_kernel<NQv>, dim3(bpg * (unsigned)n), dim3(256), 0, (hipStream_t)stream,           \
-                       (const float4*)dout, xf, mode, (float4*)dvox, C4, D, H, W, (unsigned)per_vol, bpg)
-    if (nq == 4) FORGE_LAUNCH_GATHER(4);
+                       (const float4*)dout, xf, mode, src_slot, (float4*)dvox, C4, D, H, W, (unsigned)per_vol, bpg)
+    if (!dvox) { }                                                   // frozen features (pose refinement): only the affine gradient is wanted
+    else if (nq == 4) FORGE_LAUNCH_GATHER(4);
     else if (nq == 2) FORGE_LAUNCH_GATHER(2);
     else FORGE_LAUNCH_GATHER(1);
 #undef FORGE_LAUNCH_GATHER
     if (dxf)
         hipLaunchKernelGGL(rotate_bwd_affine_kernel, dim3(bpv * (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                           (const float4*)dout, (const float4*)vox, xf, mode, dxf, C4, D, H, W, per_vol, bpv);
+                           (const float4*)dout, (const float4*)vox, xf, mode, src_slot, dxf, C4, D, H, W, per_vol, bpv);
     FORGE_LAUNCH_CHECK("forge_rotate_bwd");
     return 0;
+}
+
+extern "C" int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const int* mode,
+                                float* dvox, float* dxf, int n, int C, int D, int H, int W,
+                                forge_stream_t stream) {
+    return rotate_bwd_launch(dout, vox, xf, mode, nullptr, dvox, dxf, n, C, D, H, W, stream);
+}
+
+extern "C" int forge_rotate_bwd_slots(const float* dout, const float* vox, const float* xf, const int* mode, const int* src_slot,
+                                      float* dvox, float* dxf, int n, int C, int D, int H, int W, forge_stream_t stream) {
+    FORGE_REQUIRE(src_slot, FORGE_EINVAL, "forge_rotate_bwd_slots: null slot array");
+    return rotate_bwd_launch(dout, vox, xf, mode, src_slot, dvox, dxf, n, C, D, H, W, stream);
 }

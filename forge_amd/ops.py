@@ -36,38 +36,96 @@ def _zeros_like_cl(x_cl):
 
 
 class _RotateWarp(torch.autograd.Function):
-    """forge_rotate_fwd / forge_rotate_bwd (models/rotate.py:127-141)."""
+    """forge_rotate_fwd / forge_rotate_bwd (models/rotate.py:127-141). slot (optional, int32 [n]): the warp stores view i at volume slot[i]
+    (the view order of models/model.py:127-128 fused into the store, forge_rotate_fwd_slots) and the backward reads its gradient there."""
 
     @staticmethod
     @_lib.on_tensor_device
-    def forward(ctx, vox, xf, mode):
+    def forward(ctx, vox, xf, mode, slot=None):
         _require_cuda(vox, xf, mode)
         vox_cl = to_channels_last_3d(vox)
         n, C, D, H, W = vox_cl.shape
         xf_c = xf.detach().to(torch.float32).contiguous()
         out = _empty_like_cl(vox_cl)
-        _lib.check(_lib.lib().forge_rotate_fwd(_lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode), _lib.ptr(out),
-                                               n, C, D, H, W, _lib.current_stream()), "forge_rotate_fwd")
-        ctx.save_for_backward(vox_cl, xf_c, mode)
+        if slot is None:
+            _lib.check(_lib.lib().forge_rotate_fwd(_lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode), _lib.ptr(out),
+                                                   n, C, D, H, W, _lib.current_stream()), "forge_rotate_fwd")
+        else:
+            _lib.check(_lib.lib().forge_rotate_fwd_slots(_lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode), _lib.ptr(slot), _lib.ptr(out),
+                                                         n, C, D, H, W, _lib.current_stream()), "forge_rotate_fwd_slots")
+        ctx.save_for_backward(vox_cl, xf_c, mode, slot)
         return out
 
     @staticmethod
     @_lib.on_tensor_device
     def backward(ctx, g):
-        vox_cl, xf_c, mode = ctx.saved_tensors
+        vox_cl, xf_c, mode, slot = ctx.saved_tensors
         n, C, D, H, W = vox_cl.shape
-        g_cl = to_channels_last_3d(g)
-        dvox = _empty_like_cl(vox_cl)                      # written by the gather kernel
+        dvox = _empty_like_cl(vox_cl) if ctx.needs_input_grad[0] else None     # written by the gather kernel; frozen volumes (refinement): skipped
         dxf = torch.zeros_like(xf_c) if ctx.needs_input_grad[1] else None
-        _lib.check(_lib.lib().forge_rotate_bwd(_lib.ptr(g_cl), _lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode),
-                                               _lib.ptr(dvox), _lib.ptr(dxf), n, C, D, H, W, _lib.current_stream()),
-                   "forge_rotate_bwd")
-        return (dvox if ctx.needs_input_grad[0] else None), dxf, None
+        if dvox is None and dxf is None:
+            return None, None, None, None
+        g_cl = to_channels_last_3d(g)
+        if slot is None:
+            _lib.check(_lib.lib().forge_rotate_bwd(_lib.ptr(g_cl), _lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode),
+                                                   _lib.ptr(dvox), _lib.ptr(dxf), n, C, D, H, W, _lib.current_stream()), "forge_rotate_bwd")
+        else:
+            _lib.check(_lib.lib().forge_rotate_bwd_slots(_lib.ptr(g_cl), _lib.ptr(vox_cl), _lib.ptr(xf_c), _lib.ptr(mode), _lib.ptr(slot),
+                                                         _lib.ptr(dvox), _lib.ptr(dxf), n, C, D, H, W, _lib.current_stream()), "forge_rotate_bwd_slots")
+        return dvox, dxf, None, None
 
 
-def rotate_warp(vox, xf, mode):
-    """vox [n,C,D,H,W]; xf [n,12] 3x4 affine in normalised grid coords; mode [n] int32 (0 copy, 1 warp)."""
-    return _RotateWarp.apply(vox, xf, mode)
+class _PoseChain(torch.autograd.Function):
+    """forge_pose_chain_fwd / _bwd: the refinement loop's pose algebra (normalise, quaternion -> matrix, canonical @ rel, inverse, P_0 @ inverse,
+    camera packing) as one launch forward (values + Jacobian by forward-mode differentiation) and one launch backward."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, rot, trans, can_p, can_e, K, half_extent, b, t):
+        _require_cuda(rot, trans, can_p, can_e, K)
+        dev = rot.device
+        f32 = lambda x: x.detach().to(torch.float32).contiguous()
+        rot_c, trans_c, Kc = f32(rot), f32(trans), f32(K).reshape(b * t, 9)
+        if rot_c.shape != (b * (t - 1), 4) or trans_c.shape != (b * (t - 1), 3):
+            raise ValueError("pose_chain: rot %s / trans %s do not match b=%d, t=%d" % (tuple(rot.shape), tuple(trans.shape), b, t))
+        new = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        xf, cam, poses, origin, jac = new(b * t, 12), new(b * t, 16), new(b, t, 4, 4), new(b * t, 2), new(b * (t - 1), 24, 7)
+        mode, slot = torch.empty(b * t, dtype=torch.int32, device=dev), torch.empty(b * t, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().forge_pose_chain_fwd(_lib.ptr(rot_c), _lib.ptr(trans_c), _lib.ptr(f32(can_p)), _lib.ptr(f32(can_e)), _lib.ptr(Kc), float(half_extent),
+                                                   b, t, _lib.ptr(xf), _lib.ptr(mode), _lib.ptr(slot), _lib.ptr(cam), _lib.ptr(poses), _lib.ptr(origin),
+                                                   _lib.ptr(jac), _lib.current_stream()), "forge_pose_chain_fwd")
+        ctx.save_for_backward(jac)
+        ctx.bt = (b, t)
+        ctx.mark_non_differentiable(mode, slot, poses, origin)
+        return xf, cam, mode, slot, poses, origin
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dxf, dcam, _dmode, _dslot, _dposes, _dorigin):
+        (jac,) = ctx.saved_tensors
+        b, t = ctx.bt
+        if dxf is None and dcam is None:
+            return (None,) * 8
+        c = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        dxf, dcam = c(dxf), c(dcam)
+        drot = torch.empty(b * (t - 1), 4, dtype=torch.float32, device=jac.device)
+        dtrans = torch.empty(b * (t - 1), 3, dtype=torch.float32, device=jac.device)
+        _lib.check(_lib.lib().forge_pose_chain_bwd(_lib.ptr(jac), _lib.ptr(dxf), _lib.ptr(dcam), _lib.ptr(drot), _lib.ptr(dtrans), b, t, _lib.current_stream()),
+                   "forge_pose_chain_bwd")
+        return drot, dtrans, None, None, None, None, None, None
+
+
+def pose_chain(rot, trans, can_p, can_e, K, half_extent, b, t):
+    """rot [b(t-1),4] raw quaternions, trans [b(t-1),3], can_p / can_e [4,4], K [b,t,3,3] -> (xf [b t,12], cam [b t,16], mode [b t] int32,
+    slot [b t] int32 (view i goes to volume slot[i]: the order of models/model.py:152-158), poses [b,t,4,4], origin [b t,2]); gradients reach
+    rot / trans through xf (the warp) and cam (the ray-marcher)."""
+    return _PoseChain.apply(rot, trans, can_p, can_e, K, half_extent, b, t)
+
+
+def rotate_warp(vox, xf, mode, slot=None):
+    """vox [n,C,D,H,W]; xf [n,12] 3x4 affine in normalised grid coords; mode [n] int32 (0 copy, 1 warp); slot [n] int32 (optional): view i is
+    stored at volume slot[i]."""
+    return _RotateWarp.apply(vox, xf, mode, slot)
 
 
 class _RenderRays(torch.autograd.Function):

@@ -39,13 +39,52 @@ def _render_views(model, config, dataset, features, pose7, K, device, canonical=
     return imgs, masks, depths, origin, poses
 
 
+class _SmallAdam:
+    """torch.optim.Adam's update (defaults: betas (0.9, 0.999), eps 1e-8, no weight decay) for a few tiny tensors: ONE launch per tensor
+    (forge_adam_small, step count on the device) instead of the ~30 of the capturable torch optimiser. groups = [(tensor, lr), ...]."""
+
+    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8):
+        self.groups, self.betas, self.eps = [(p, float(lr)) for p, lr in groups], betas, eps
+        self.state = [(torch.zeros_like(p), torch.zeros_like(p), torch.zeros(1, dtype=torch.float32, device=p.device)) for p, _ in self.groups]
+
+    def zero_grad(self, set_to_none=True):
+        for p, _ in self.groups:
+            p.grad = None
+
+    def step(self):
+        from . import _lib
+        for (p, lr), (m, v, k) in zip(self.groups, self.state):
+            if p.grad is None:
+                continue
+            with torch.cuda.device(p.device):
+                _lib.check(_lib.lib().forge_adam_small(_lib.ptr(p.data), _lib.ptr(p.grad.contiguous()), _lib.ptr(m), _lib.ptr(v), _lib.ptr(k), p.numel(), lr,
+                                                       self.betas[0], self.betas[1], self.eps, _lib.current_stream()), "forge_adam_small")
+
+
+def _render_views_fused(model, config, dataset, features, rot, trans, K, device, canonical):
+    """_render_views with the pose algebra on ONE HIP launch (ops.pose_chain: raw quaternion / translation -> warp affine + packed cameras, Jacobian
+    by forward-mode differentiation) instead of ~250 torch launches per iteration; what the refinement loop runs. Same outputs."""
+    from . import ops
+    b, t = features.shape[:2]
+    C, D = features.shape[2], features.shape[3]
+    can_p, can_e = canonical
+    xf, cam, mode, slot, poses, origin = ops.pose_chain(rot, trans, can_p, can_e, K, model.rotate.half_extent(D), b, t)
+    ft = ops.rotate_warp(features.reshape(b * t, C, D, D, D), xf, mode, slot).reshape(b, t, C, D, D, D)       # stored in sequence_from_distance's order
+    fused = model.encoder_3d.fuse(ft)
+    feat, dens = model.encoder_3d.heads(fused)
+    v2v = torch.arange(b, device=device, dtype=torch.int32).repeat_interleave(t)
+    imgs, masks, depths, origin = model.render({"packed": cam, "origin": origin}, feat, dens, return_origin_proj=True, render_depth=True, view2vol=v2v)
+    return imgs, masks, depths, origin, poses
+
+
 class PoseRefiner:
     """One instance of the refinement problem (kubric_eval.py:412-530): features [b,t,C,D,H,W] (detached encoder output), initial poses
     [b(t-1),7] (quat, trans), targets, intrinsics. `iteration()` = forward, loss, backward through every HIP kernel, Adam step; `capture()`
     records it into a hipGraph on `stream` (fixed shapes, no host synchronisation: closed-form pose inverses, device-side view ordering,
     capturable Adam), `step()` replays it (or runs it eagerly). The model's weights must be frozen by the caller (refine_poses does)."""
 
-    def __init__(self, model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=True, stream=None):
+    def __init__(self, model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=True, stream=None, fused=True):
+        self.fused_pose_chain = bool(fused)   # False: torch pose algebra + torch.optim.Adam (the yardstick of tests/test_gpu_parity.py)
         self.model, self.config, self.dataset, self.device = model, config, dataset, device
         self.features = features.detach().to(device)
         self.target_imgs, self.target_masks, self.K = target_imgs.to(device), target_masks.to(device), K.to(device)
@@ -53,14 +92,21 @@ class PoseRefiner:
         self.rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
         self.trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
         lr = 0.001
-        self.opt = torch.optim.Adam([{"params": self.rot, "lr": lr}, {"params": self.trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
+        if self.fused_pose_chain and self.features.is_cuda:
+            self.opt = _SmallAdam([(self.rot, lr), (self.trans, lr / 2.0)])
+        else:
+            self.opt = torch.optim.Adam([{"params": self.rot, "lr": lr}, {"params": self.trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
         self.w_rgb, self.w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
         self.use_graph, self.graph, self.static_loss = bool(use_graph), None, None
         self.stream = stream
 
     def iteration(self):
-        pose7 = torch.cat([F.normalize(self.rot), self.trans], dim=1)
-        imgs, masks, _, _, _ = _render_views(self.model, self.config, self.dataset, self.features, pose7, self.K, self.device, self.canonical)
+        if self.fused_pose_chain and self.features.is_cuda:
+            imgs, masks, _, _, _ = _render_views_fused(self.model, self.config, self.dataset, self.features, self.rot, self.trans, self.K, self.device,
+                                                       self.canonical)
+        else:
+            pose7 = torch.cat([F.normalize(self.rot), self.trans], dim=1)
+            imgs, masks, _, _, _ = _render_views(self.model, self.config, self.dataset, self.features, pose7, self.K, self.device, self.canonical)
         loss = self.w_rgb * F.mse_loss(imgs, self.target_imgs) + self.w_mask * F.mse_loss(masks, self.target_masks)
         loss.backward()
         self.opt.step()

@@ -133,7 +133,13 @@ class VolRender(co.PackedModule):
         nvol, C, D, H, W = feature_3d.shape
         device = feature_3d.device
         origin = None
-        if hip_inference(self, feature_3d) and not any(camera_params[k].requires_grad for k in ("R", "T", "K")):
+        if "packed" in camera_params:
+            # extension (forge_amd/refine.py): cameras already packed as the ray-marcher wants them ([V,16]: R, T, fx fy cx cy at half
+            # resolution, ops.pose_chain) together with the origin projection - no per-call camera algebra
+            cam, origin = camera_params["packed"], camera_params.get("origin")
+            if return_origin_proj and origin is None:
+                raise ValueError("VolRender: packed cameras need their 'origin' projection for return_origin_proj")
+        elif hip_inference(self, feature_3d) and not any(camera_params[k].requires_grad for k in ("R", "T", "K")):
             cam, origin = self._pack_cameras_hip(camera_params, device, return_origin_proj)
         else:
             cam, T, K = self._pack_cameras(camera_params, device)

@@ -74,16 +74,35 @@ int forge_rotate_fwd_slots(const float* vox, const float* xf, const int* mode, c
 int forge_rotate_xf_from_poses(const float* poses, float* xf, int* mode, int* slot, const float* dist, int B, int t, float half_extent,
                                forge_stream_t stream);
 
+/* Pose chain of the refinement loop (kubric_eval.py:412-530 `do_refinement`, demo.py:115-188): from the optimised relative poses of the
+ * non-reference views - rot [b (t-1)][4] raw quaternions (w, x, y, z; normalised here as F.normalize + utils/geo_utils.py:122-137 do),
+ * trans [b (t-1)][3] - to both kernel operands in one launch:
+ *   poses [b t][16]  canonical_pose @ [R(q) | trans] (view 0: canonical_pose itself)            utils/geo_utils.py:268-287
+ *   xf [b t][12], mode [b t]   the warp's affine [R_T | t_T / half_extent], T = P_0 P_i^-1       models/rotate.py:64-89,132-135
+ *   slot [b t]       (nullable) the view order of models/model.py:152-158 as forge_rotate_fwd_slots' dst_slot (see forge_rotate_xf_from_poses)
+ *   cam16 [b t][16]  the ray-marcher's cameras [R | T | fx fy cx cy] from the extrinsics P_i^-1 and K / 2   models/volume_render.py:40-51
+ *   origin [b t][2]  (nullable) projection of the world origin (models/volume_render.py:77-79)
+ *   jac [b (t-1)][24][7] (nullable) d(xf[0..11], cam16[0..11]) / d(quaternion, translation), by forward-mode differentiation in the kernel
+ * can_pose / can_extr: row-major 4x4 pose / extrinsics of the reference view; K [b t][9] full-resolution intrinsics.
+ * forge_pose_chain_bwd: drot [b (t-1)][4], dtrans [b (t-1)][3] = jac^T (dxf row | dcam row[0..11]) (dxf [b t][12] from forge_rotate_bwd,
+ * dcam [b t][16] from forge_render_bwd; either nullable). Replaces ~250 torch launches of 3-8 us per refinement iteration. */
+int forge_pose_chain_fwd(const float* rot, const float* trans, const float* can_pose, const float* can_extr, const float* K, float half_extent,
+                         int b, int t, float* xf, int* mode, int* slot, float* cam16, float* poses, float* origin, float* jac, forge_stream_t stream);
+int forge_pose_chain_bwd(const float* jac, const float* dxf, const float* dcam, float* drot, float* dtrans, int b, int t, forge_stream_t stream);
+
 /* Backward of forge_rotate_fwd w.r.t. the volumes (and optionally the affine).
  *   dout [n][D][H][W][C]   upstream gradient
- *   dvox [n][D][H][W][C]   written (not accumulated): the exact transpose of the warp, computed as a gather per source voxel
- *                          (deterministic, no atomics); mode 0 volumes: plain copy of dout
+ *   dvox [n][D][H][W][C]   nullable (frozen volumes: pose refinement wants dxf only); written (not accumulated): the exact transpose of
+ *                          the warp, computed as a gather per source voxel (deterministic, no atomics); mode 0 volumes: plain copy of dout
  *   dxf  [n][12]           nullable; MUST be zero-filled; d loss / d xf (pose refinement,
  *                          kubric_eval.py:469-503). Needs vox (nullable when dxf is NULL).
  */
 int forge_rotate_bwd(const float* dout, const float* vox, const float* xf, const int* mode,
                      float* dvox, float* dxf, int n, int C, int D, int H, int W,
                      forge_stream_t stream);
+/* The same for a forward that stored view i at volume slot[i] (forge_rotate_fwd_slots): view i's upstream gradient is read at dout[slot[i]]. */
+int forge_rotate_bwd_slots(const float* dout, const float* vox, const float* xf, const int* mode, const int* src_slot,
+                           float* dvox, float* dxf, int n, int C, int D, int H, int W, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a6  fused ray sampler + volume sampler + emission-absorption ray-marcher — replaces
@@ -353,6 +372,12 @@ int forge_sse_groups_fwd(const float* pred, long long sn, long long sc, long lon
                          float* partial, int B, int Vp, int Vt, int gsize, int C, int H, int W, forge_stream_t stream);
 int forge_sse_groups_bwd(const float* pred, long long sn, long long sc, long long sh, long long sw, const float* target,
                          const float* coef, float* dpred, int B, int Vp, int Vt, int gsize, int C, int H, int W, forge_stream_t stream);
+
+/* f2  torch.optim.Adam (betas, eps; no weight decay / amsgrad) on one SMALL tensor in one launch, the step count `step` [1] (float) kept and
+ * advanced on the device: the pose-refinement loop (kubric_eval.py:440-449) optimises b (t-1) x 7 numbers, for which the capturable torch
+ * optimiser issues ~30 launches inside the captured iteration. param / exp_avg / exp_avg_sq [n] updated in place. */
+int forge_adam_small(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step, int n, float lr, float beta1, float beta2,
+                     float eps, forge_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * layout helpers: NCDHW <-> channels-last for callers that hold plain-contiguous volumes.

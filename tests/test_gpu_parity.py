@@ -1152,6 +1152,114 @@ def test_refinement_pose_gradient_vs_oracle_autograd(dev):
     assert err < 2e-2 * po.grad.abs().max().item(), (err, po.grad.abs().max().item())
 
 
+def test_pose_chain_kernel_vs_torch_algebra(dev):
+    """forge_pose_chain_fwd / _bwd (the refinement loop's pose algebra in one launch, Jacobian by forward-mode duals) against the torch algebra it
+    replaces - F.normalize, geo_utils.quat2mat, canonical @ rel, inverse_affine, Rotate_world.get_transformation, VolRender._pack_cameras - in
+    float64 on the CPU: values to 2e-6, the vector-Jacobian product for random upstream gradients to 1e-5 of its scale; un-normalised
+    quaternions (the optimiser's raw parameter) and two scenes."""
+    from forge_amd import geo_utils, ops
+    ds = syn.SyntheticDataset(1.5)
+    g = torch.Generator().manual_seed(9)
+    b, t, e = 2, 4, 0.484375
+    sample = syn.make_sample(b, t, 256, 1.5, seed=77)
+    p7 = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][:, 1:].reshape(b * (t - 1), 4, 4))
+    rot = (p7[:, :4] * (0.5 + torch.rand(b * (t - 1), 1, generator=g)) + 0.05 * torch.randn(b * (t - 1), 4, generator=g))     # NOT unit length
+    trans = p7[:, 4:] + 0.02 * torch.randn(b * (t - 1), 3, generator=g)
+    K = sample["K_cv2"]
+    can_p, can_e = ds.get_canonical_pose_cv2(device="cpu"), ds.get_canonical_extrinsics_cv2(device="cpu")
+    gxf, gcam = torch.randn(b * t, 12, generator=g), torch.randn(b * t, 16, generator=g)
+    # float64 torch algebra
+    r64, t64 = rot.double().requires_grad_(True), trans.double().requires_grad_(True)
+    rel = geo_utils.quat2mat(torch.cat([torch.nn.functional.normalize(r64), t64], dim=1))
+    poses = (can_p.double().unsqueeze(0) @ rel)
+    extr = geo_utils.inverse_affine(poses).reshape(b, t - 1, 4, 4)
+    poses_all = torch.cat([can_p.double().reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), poses.reshape(b, t - 1, 4, 4)], dim=1)
+    extr_all = torch.cat([can_e.double().reshape(1, 1, 4, 4).repeat(b, 1, 1, 1), extr], dim=1).reshape(b * t, 4, 4)
+    T = poses_all[:, 0:1].repeat(1, t - 1, 1, 1).reshape(-1, 4, 4) @ geo_utils.inverse_affine(poses_all[:, 1:].reshape(-1, 4, 4))
+    xf_ref = torch.cat([torch.zeros(b, 1, 12, dtype=torch.float64), torch.cat([T[:, :3, :3], T[:, :3, 3:4] / e], dim=-1).reshape(b, t - 1, 12)], dim=1).reshape(b * t, 12)
+    Kh = K.double().reshape(b * t, 3, 3) / 2.0
+    cam_ref = torch.cat([extr_all[:, :3, :3].reshape(b * t, 9), extr_all[:, :3, 3], Kh[:, 0, 0:1], Kh[:, 1, 1:2], Kh[:, 0, 2:3], Kh[:, 1, 2:3]], dim=1)
+    ((xf_ref * gxf.double()).sum() + (cam_ref * gcam.double()).sum()).backward()
+    # HIP
+    rh, th = rot.to(dev).requires_grad_(True), trans.to(dev).requires_grad_(True)
+    xf, cam, mode, slot, poses_h, origin = ops.pose_chain(rh, th, can_p.to(dev), can_e.to(dev), K.to(dev), e, b, t)
+    ((xf * gxf.to(dev)).sum() + (cam * gcam.to(dev)).sum()).backward()
+    assert (xf.detach().cpu().double() - xf_ref.detach()).abs().max().item() < 2e-6 * max(1.0, xf_ref.abs().max().item())
+    assert (cam.detach().cpu().double() - cam_ref.detach()).abs().max().item() < 2e-6 * cam_ref.abs().max().item()
+    assert (poses_h.cpu().double() - poses_all.detach()).abs().max().item() < 2e-6 * poses_all.abs().max().item()
+    assert mode.cpu().tolist() == ([0] + [1] * (t - 1)) * b
+    from forge_amd.model import sequence_from_distance
+    order = sequence_from_distance(poses_h[:, :, :3, 3])                                      # out[:, j] = view order[:, j]  <=>  slot[view] = its rank
+    want = torch.argsort(order, dim=1) + torch.arange(b, device=dev)[:, None] * t
+    assert slot.cpu().tolist() == want.reshape(-1).cpu().tolist()
+    org_ref = torch.stack([Kh[:, 0, 0] * extr_all[:, 0, 3] / extr_all[:, 2, 3] + Kh[:, 0, 2], Kh[:, 1, 1] * extr_all[:, 1, 3] / extr_all[:, 2, 3] + Kh[:, 1, 2]], dim=-1)
+    assert (origin.cpu().double() - org_ref.detach()).abs().max().item() < 1e-4
+    for got, ref in ((rh.grad, r64.grad), (th.grad, t64.grad)):
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item(), (got, ref)
+
+
+def test_adam_small_kernel_follows_torch_adam(dev):
+    """forge_adam_small (one launch per tensor, step count on the device) against torch.optim.Adam with the refinement loop's settings
+    (kubric_eval.py:440-449: lr 1e-3 / 5e-4, default betas / eps) over 25 steps of random gradients: parameters to 1e-6."""
+    from forge_amd import refine
+    g = torch.Generator().manual_seed(1)
+    p0, q0 = torch.randn(4, 4, generator=g), torch.randn(4, 3, generator=g)
+    a, b = p0.clone().to(dev).requires_grad_(True), q0.clone().to(dev).requires_grad_(True)
+    c, d = p0.clone().to(dev).requires_grad_(True), q0.clone().to(dev).requires_grad_(True)
+    mine = refine._SmallAdam([(a, 1e-3), (b, 5e-4)])
+    ref = torch.optim.Adam([{"params": c, "lr": 1e-3}, {"params": d, "lr": 5e-4}], lr=1e-3)
+    for _ in range(25):
+        ga, gb = torch.randn(4, 4, generator=g).to(dev), (torch.randn(4, 3, generator=g) * 10.0 ** float(torch.randint(-4, 3, (1,), generator=g))).to(dev)
+        a.grad, b.grad, c.grad, d.grad = ga.clone(), gb.clone(), ga.clone(), gb.clone()
+        mine.step()
+        ref.step()
+    assert (a - c).abs().max().item() < 1e-6 and (b - d).abs().max().item() < 1e-6
+    assert float(mine.state[0][2]) == 25.0
+
+
+def test_refinement_iteration_fused_pose_chain_equals_torch_pose_algebra(dev):
+    """f2: the iteration PoseRefiner runs (ops.pose_chain -> warp affine + packed cameras) against the same iteration with the torch pose algebra
+    (refine._render_views): rendered images / masks to 3e-4 of their scale (the two pose algebras differ by fp32 rounding, ~1e-7, which the warp's
+    trilinear weights and five GRU steps amplify to ~6e-5), loss to 1e-5, pose gradients to 5e-3 of their max (the ray-march and rotate
+    backward use fp32 atomics: two runs of ONE path differ by ~1e-4)."""
+    from forge_amd import geo_utils, refine
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+    refine._frozen(model)
+    ds = syn.SyntheticDataset(1.5)
+    t = 4
+    sample = syn.make_sample(1, t, 256, 1.5, seed=33)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        feats = model.encoder_3d.get_feat3D(sample["images"][0].to(dev)).reshape(1, t, 128, 32, 32, 32)
+        gt7 = geo_utils.mat2quat(sample["cam_poses_rel_cv2"][0, 1:]).to(dev)
+        tgt_i, tgt_m, _, _, _ = refine._render_views(model, cfg, ds, feats, gt7, sample["K_cv2"].to(dev), dev)
+    init = gt7.clone()
+    init[:, :4] = init[:, :4] * 1.3 + 0.03 * torch.randn(t - 1, 4, generator=g).to(dev)
+    init[:, 4:] += 0.02 * torch.randn(t - 1, 3, generator=g).to(dev)
+    res = {}
+    for fused in (True, False):
+        r = refine.PoseRefiner(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, use_graph=False, fused=fused)
+        can = r.canonical
+        if fused:
+            imgs, masks, _, origin, poses = refine._render_views_fused(model, cfg, ds, r.features, r.rot, r.trans, r.K, dev, can)
+        else:
+            pose7 = torch.cat([torch.nn.functional.normalize(r.rot), r.trans], dim=1)
+            imgs, masks, _, origin, poses = refine._render_views(model, cfg, ds, r.features, pose7, r.K, dev, can)
+        loss = r.w_rgb * torch.nn.functional.mse_loss(imgs, tgt_i) + r.w_mask * torch.nn.functional.mse_loss(masks, tgt_m)
+        loss.backward()
+        res[fused] = (imgs.detach(), masks.detach(), origin.detach(), poses.detach(), float(loss.detach()), r.rot.grad.clone(), r.trans.grad.clone())
+    a, c = res[True], res[False]
+    for i in range(4):
+        assert (a[i] - c[i]).abs().max().item() < (3e-4 if i < 2 else 2e-6) * max(1.0, c[i].abs().max().item()), i
+    assert abs(a[4] - c[4]) < 1e-5 * max(1.0, abs(c[4]))
+    for i in (5, 6):
+        assert (a[i] - c[i]).abs().max().item() < 5e-3 * c[i].abs().max().item(), (i, a[i], c[i])
+
+
 def test_pose_refinement_graph_replay_matches_eager(dev):
     """f2: the refinement iteration captured into a hipGraph (forward, loss, backward through rotate / fuse / heads / ray-march, Adam)
     follows the same trajectory as the eager loop (atomics in the backward make the two runs differ in the last bits only)."""

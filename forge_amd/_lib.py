@@ -26,6 +26,7 @@ SIGNATURES = {
     "forge_rotate_xf_from_poses": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "forge_rotate_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_pose_chain_fwd": [_P, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "forge_colsum": [_P, _I, _P, _P, _LL, _I, _P],
     "forge_adam_small": [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P],
     "forge_rotate_bwd_slots": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_pose_chain_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],

@@ -479,6 +479,22 @@ def _batch_stride_rows(x):
     return 0 if (n == 1 or x.stride(0) == D * H * W * C) else x.stride(0) // C
 
 
+@_lib.on_tensor_device
+def colsum(x):
+    """Sum over the rows of a channels-last tensor [..., C] -> [C] - the bias gradient of a convolution - on forge_colsum (float64 partial sums in a
+    fixed order: deterministic, and more accurate than a fp32 tree). Channel counts that are not multiples of 4 (the 1- and 3-channel direct
+    convolutions) keep torch's reduction."""
+    C = x.shape[-1]
+    rows = x.reshape(-1, C)
+    if C % 4 or not (rows.is_cuda and rows.dtype == torch.float32):
+        return rows.sum(dim=0)
+    rows = rows if (rows.stride(1) == 1 and rows.stride(0) >= C and rows.stride(0) % 4 == 0) else rows.contiguous()
+    out = torch.empty(C, dtype=torch.float32, device=rows.device)
+    ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=rows.device)
+    _lib.check(_lib.lib().forge_colsum(_lib.ptr(rows), rows.stride(0), _lib.ptr(out), _lib.ptr(ws), rows.shape[0], C, _lib.current_stream()), "forge_colsum")
+    return out
+
+
 class _ConvTapsRows(torch.autograd.Function):
     """y[m] = bias + sum_t wp[t] @ cat(x1, x2)[voxel(m) * istride + taps[t]] on channels-last rows — the one autograd node behind
     every convolution of the training path. `wp` [T][Cout][Cin] is the differentiable weight: callers build it from the module
@@ -564,7 +580,7 @@ class _ConvTapsRows(torch.autograd.Function):
                 conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
                            bs2=0 if x2 is None else _batch_stride_rows(x2))
         if has_bias and ctx.needs_input_grad[3]:
-            db = dy.reshape(-1, Cout).sum(dim=0)
+            db = colsum(dy.reshape(-1, Cout))
         return dx1, dx2, dwp, db, None, None, None
 
 
@@ -631,7 +647,7 @@ class _ConvDirectRows(torch.autograd.Function):
             _lib.check(_lib.lib().forge_conv_direct_wgrad(_lib.ptr(dy), Cout, _lib.ptr(x), Cin, _lib.ptr(dwp), n, D, H, W, Cin, Cout,
                                                           _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.reshape(-1, Cout).sum(dim=0)
+            db = colsum(dy.reshape(-1, Cout))
         return dx, dwp, db, None
 
 
@@ -710,7 +726,7 @@ class _ConvTS2Rows(torch.autograd.Function):
             conv_wgrad(x, dy, Cout, None, 0, dwp, (n, D, H, W), (Do, 2 * H, 2 * W), Cin, taps, istride=2)
             dw = dwp.permute(1, 2, 0).reshape(weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.reshape(-1, Cout).sum(dim=0)
+            db = colsum(dy.reshape(-1, Cout))
         return dx, dw, db, None, None
 
 

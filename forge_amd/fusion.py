@@ -221,7 +221,7 @@ class _GRUCellRows(torch.autograd.Function):
             dwo = torch.zeros_like(wo)
             co.conv3_wgrad(dc, x, C, hr, C, dwo, grid, C, bs1=bsx)
         if ctx.has_bias[1] and ctx.needs_input_grad[5]:
-            dbo = dc.reshape(M, C).sum(dim=0)
+            dbo = co.colsum(dc.reshape(M, C))
         # gates: g = conv([x | h], wg); z = sigmoid(g[:C]), r = sigmoid(g[C:]), hr = h r
         dg = new(2 * C)
         _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
@@ -231,7 +231,7 @@ class _GRUCellRows(torch.autograd.Function):
             dwg = torch.zeros_like(wg)
             co.conv3_wgrad(dg, x, C, h, C, dwg, grid, 2 * C, bs1=bsx)
         if ctx.has_bias[0] and ctx.needs_input_grad[3]:
-            dbg = dg.reshape(M, 2 * C).sum(dim=0)
+            dbg = co.colsum(dg.reshape(M, 2 * C))
         dx = (dxh[..., :C] + dxh2[..., :C]) if ctx.needs_input_grad[0] else None
         dh_total = (dh + dxh2[..., C:]) if ctx.needs_input_grad[1] else None
         return dx, dh_total, dwg, dbg, dwo, dbo
@@ -288,7 +288,7 @@ class _GRUCellPreRows(torch.autograd.Function):
             dwo = torch.zeros_like(wo)
             co.conv3_wgrad(dc, hr, C, None, 0, dwo, grid, C)
         if ctx.has_bias[1] and ctx.needs_input_grad[6]:
-            dbo = dc.reshape(M, C).sum(dim=0)
+            dbo = co.colsum(dc.reshape(M, C))
         dg = new(2 * C)
         _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
         dh_total = new(C)                                          # dh (state + reset paths) + conv^T(dg, Wg_h), added in the GEMM epilogue
@@ -297,7 +297,7 @@ class _GRUCellPreRows(torch.autograd.Function):
             dwg = torch.zeros_like(wg)
             co.conv3_wgrad(dg, h, C, None, 0, dwg, grid, 2 * C)
         if ctx.has_bias[0] and ctx.needs_input_grad[4]:
-            dbg = dg.reshape(M, 2 * C).sum(dim=0)
+            dbg = co.colsum(dg.reshape(M, 2 * C))
         return (dg if ctx.needs_input_grad[0] else None), (dc if ctx.needs_input_grad[1] else None), dh_total, dwg, dbg, dwo, dbo
 
 

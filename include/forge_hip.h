@@ -311,6 +311,9 @@ int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const flo
  * x / y / dy / dx rows [M][ld] fp32, C % 4 == 0; gamma / beta nullable (1 / 0); slope 1 = no activation, 0 = ReLU; ws = forge_bn_ws_doubles(C)
  * doubles of scratch (one float64 partial per reduction block, summed by a second kernel in a fixed order: deterministic, no atomics). */
 int forge_bn_ws_doubles(int C);
+/* Column sums out[c] = sum_m x[m][c] of a row-major [M][C] matrix with row stride ldx (floats): the bias gradient of a convolution (torch:
+ * dy.sum over every dimension but the channels). float64 partial sums in a fixed order (deterministic); ws = forge_bn_ws_doubles(C) doubles. */
+int forge_colsum(const float* x, int ldx, float* out, double* ws, long long M, int C, forge_stream_t stream);
 int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                        float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
                        long long M, int C, forge_stream_t stream);

@@ -55,3 +55,21 @@ def test_bn_eval_keeps_the_torch_module_and_single_process_syncbn_runs_hip():
     plain, sync = nn.BatchNorm3d(32).to(dev).train(), nn.SyncBatchNorm(32).to(dev).train()
     assert torch.equal(bn_act_rows(sync, x, 0.01), bn_act_rows(plain, x, 0.01))
     assert torch.equal(sync.running_var, plain.running_var)
+
+
+@pytest.mark.parametrize("M,C,ld", [(32768, 128, 128), (5120, 2048, 2048), (1000, 32, 64), (7, 8, 8), (262144, 16, 16)])
+def test_colsum_kernel_vs_float64(M, C, ld):
+    """forge_colsum (the bias gradients of the training path; float64 partial sums, fixed order) against a float64 torch sum: 2e-7 of the
+    column's absolute sum; a strided view (ld > C) and a deterministic repeat."""
+    from forge_amd import convops as co
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M + C)
+    buf = (torch.randn(M, ld, generator=g) * 3.0 + 0.5).to(dev)
+    x = buf[:, :C]
+    got = co.colsum(x)
+    ref = x.double().sum(dim=0)
+    scale = x.double().abs().sum(dim=0)
+    assert ((got.double() - ref).abs() <= 2e-7 * scale + 1e-30).all()
+    assert torch.equal(got, co.colsum(x))
+    x3 = buf.reshape(1, M, ld)[..., :C]                                   # [..., C] input shapes
+    assert torch.equal(co.colsum(x3), got)

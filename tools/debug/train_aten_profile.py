@@ -34,7 +34,7 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(os.environ.get("ATEN_STACKS"))) as prof:
     step()
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages() if e.self_device_time_total > 0 and (e.key.startswith("aten::") or e.key.startswith("Optimizer") or "Memcpy" in e.key or "Memset" in e.key)]
@@ -43,3 +43,15 @@ tot = sum(e.self_device_time_total for e in rows)
 print("aten / memcpy device time of one step: %.2f ms in %d launches" % (tot / 1e3, sum(e.count for e in rows)))
 for e in rows[:40]:
     print("%-50s %5d calls %9.1f us  avg %6.1f us" % (e.key[:50], e.count, e.self_device_time_total, e.self_device_time_total / e.count))
+
+if os.environ.get("ATEN_STACKS"):      # where the small ops come from: python frames under forge_amd / torch.optim / torch.nn.utils per op
+    import collections
+    want = set(os.environ["ATEN_STACKS"].split(","))
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for e in prof.events():
+        if e.name in want and e.device_time_total > 0:
+            frames = [f for f in (e.stack or []) if ("forge_amd" in f or "optim" in f or "clip_grad" in f or "tools/" in f)]
+            agg[(e.name, frames[0] if frames else "(autograd engine / no python frame)")][0] += 1
+            agg[(e.name, frames[0] if frames else "(autograd engine / no python frame)")][1] += e.device_time_total
+    for (name, fr), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+        print("%-14s %4d calls %8.1f us  %s" % (name, n, us, fr[-110:]))

@@ -649,6 +649,140 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
 }
 
 
+// Narrow-N kernel for stride-1 convolutions whose taps form complete x-LINES: taps [(dz, dy)] x [dx = -R .. R] (the 3x3x3 second convolutions of the
+// heads, R = 1; conv_rgb's 5x5, R = 2). conv_igemm_n16_kernel stages the 256 tile rows once per TAP: at 16 output columns a K-step is 8 MFMAs per wave
+// against a 16 KB global -> LDS round trip, so every one of its 54 (heads) / 50 (conv_rgb) K-steps is load-latency bound. The dx taps of one
+// (dz, dy) line read the SAME rows shifted by dx voxels = dx rows of the channels-last tensor, so here a K-step stages the slab of 256 + 2R rows ONCE
+// (LDS-DMA, common.h) and runs all 2R + 1 taps on shifted views of it: (2R + 1) x fewer global loads, barriers and K-steps, (2R + 1) x the MFMA
+// work per barrier. A shifted row that crosses the end of its x-line is another line's voxel: masked per (row, dx) at use. Rows whose (z + dz, y + dy)
+// leave the grid are staged as zeros. Same sums as conv_igemm_n16_kernel in a different order (taps of a line innermost).
+template <int R>
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_lines_kernel(const ConvArgs a) {
+    constexpr int NT = 2 * R + 1, SR = BM16 + 2 * R;               // taps per line, slab rows
+    constexpr int A_FLOATS = ((SR * BK16 + 255) / 256) * 256, B_FLOATS = NT * 16 * BK16;     // A padded to whole 1 KB wave blocks
+    constexpr int APASS = (SR * 4 + NTHREADS - 1) / NTHREADS;      // 16-byte chunks of the slab per thread (3)
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_FLOATS + B_FLOATS)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long M = (long long)a.n * a.D * a.H * a.W;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long long m0 = (long long)bid * BM16;
+    const int Cin = a.C1 + a.C2;
+    const int kchunks = Cin / BK16;
+    const int nlines = a.ntaps / NT;
+    const int nsteps = nlines * kchunks;
+    const forge_v4i32 w1 = make_rsrc_words(a.in1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 : a.in1, a.in2 ? a.span2 : 0),
+                      ww = make_rsrc_words(a.wp, (long long)a.ntaps * a.Cout * Cin * 4);
+    const unsigned lds_wave = lds_addr(smem) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+
+    // slab chunk q = tid + 512 j: slab row q >> 2 = the voxel m0 - R + (q >> 2), physical 16-byte chunk q & 3 (LDS byte 16 q: lane-linear)
+    const int cp = tid & 3;
+    int sz[APASS], sy[APASS], sn[APASS], sx[APASS], asrc[APASS];
+    bool sval[APASS];
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+        const int srow = (tid + NTHREADS * j) >> 2;
+        const long long vl = m0 - R + srow;
+        sval[j] = srow < SR && vl >= 0 && vl < M;
+        unsigned v = sval[j] ? (unsigned)vl : 0u;
+        unsigned q = v / (unsigned)a.W;
+        sx[j] = (int)(v - q * (unsigned)a.W); v = q;
+        q = v / (unsigned)a.H;
+        sy[j] = (int)(v - q * (unsigned)a.H); v = q;
+        q = v / (unsigned)a.D;
+        sz[j] = (int)(v - q * (unsigned)a.D);
+        sn[j] = (int)q;
+        asrc[j] = (cp ^ ((4 - ((srow >> 2) & 3)) & 3)) << 2;
+    }
+    // weights of a line: NT x 16 rows (tap-in-line, cout) x 4 chunks, staged by the first NT waves; LDS byte 16 tid of the B image
+    const int brow = tid >> 2;
+    const unsigned boff = (wave < NT && (brow & 15) < a.Cout)
+                              ? (unsigned)((((brow >> 4) * a.Cout + (brow & 15)) * Cin + ((cp ^ ((4 - ((brow >> 2) & 3)) & 3)) << 2)) * 4) : OOB;
+    int line = 0, kc = 0;
+    auto issue_step = [&](int buf) {
+        const int dz = a.tap[line * NT][0], dy = a.tap[line * NT][1];
+        const int c0 = kc * BK16;
+        const unsigned stage = lds_wave + (unsigned)buf * (unsigned)((A_FLOATS + B_FLOATS) * 4);
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+            if ((tid + NTHREADS * j) < A_FLOATS / 4) {                 // whole waves in or out except in the last pass (exec-masked lanes do not write)
+                const int zi = sz[j] + dz, yi = sy[j] + dy;
+                const bool ok = sval[j] && (unsigned)zi < (unsigned)a.D && (unsigned)yi < (unsigned)a.H;
+                const int sp = (zi * a.H + yi) * a.W + sx[j];
+                unsigned off = OOB;
+                if (c0 < a.C1) { if (ok) off = (unsigned)(((sn[j] * (int)a.bs1r + sp) * a.ld1 + c0 + asrc[j]) * 4); lds_dma16(w1, off, stage + (unsigned)(j * 8 * 1024)); }
+                else { if (ok) off = (unsigned)(((sn[j] * (int)a.bs2r + sp) * a.ld2 + (c0 - a.C1) + asrc[j]) * 4); lds_dma16(w2, off, stage + (unsigned)(j * 8 * 1024)); }
+            }
+        }
+        if (wave < NT) lds_dma16(ww, boff == OOB ? OOB : boff + (unsigned)((line * NT * a.Cout * Cin + c0) * 4), stage + (unsigned)(A_FLOATS * 4));
+    };
+    auto advance = [&]() { if (++kc == kchunks) { kc = 0; ++line; } };
+
+    f32x4 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    const int kq = lane >> 4, l15 = lane & 15;
+    int xr[2];                                                     // x coordinate of this lane's two MFMA rows: shifted reads beyond the line end are masked
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + wave * 32 + i * 16 + l15;
+        xr[i] = (int)((unsigned)(m < M ? m : 0) % (unsigned)a.W);
+    }
+    issue_step(0);
+    lds_dma_wait();
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) { advance(); issue_step(buf ^ 1); }
+        const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+        const float* sb = sa + A_FLOATS;
+#pragma unroll
+        for (int d = 0; d < NT; ++d) {
+            const float4 fb = *reinterpret_cast<const float4*>(sb + lds_off16(d * 16 + l15, kq));
+            float4 fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const float4*>(sa + lds_off16(wave * 32 + i * 16 + l15 + d, kq));     // slab row = tile row + R + dx, d = dx + R
+                if ((unsigned)(xr[i] + d - R) >= (unsigned)a.W) fa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
+        }
+        lds_dma_wait();
+        __syncthreads();
+    }
+    // ---- epilogue (bias / folded-BN + LeakyReLU + residual): identity row mapping (stride 1, same grid). 16x16 C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+    const int col = l15;
+    if (col < a.Cout) {
+        const float bias = a.bias ? a.bias[col] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if (a.epi == EPI_AFFINE_ACT) { sc = a.scale[col]; sh = a.shift[col]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long orow = m0 + wave * 32 + i * 16 + kq * 4 + r;
+                if (orow < M) {
+                    float v = acc[i][r] + bias;
+                    if (a.epi == EPI_AFFINE_ACT) {
+                        v = fmaf(v, sc, sh);
+                        if (a.residual) v += a.residual[orow * a.ldr + col];
+                        v = v > 0.f ? v : v * a.slope;
+                    }
+                    a.out[orow * a.ldo + col] = v;
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Launch plan: tile shape and split-K factor from a makespan model of the 256-CU chip (times in us).
 //   tiles      A 128x128 / 8 waves   B 64x128 / 8   C 128x64 / 8   D 64x64 / 4   E 128x32 / 4 (Cout <= 32)
@@ -792,7 +926,20 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
         FORGE_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT, FORGE_EINVAL, "forge_conv_igemm: GRU epilogues need Cout > 16");
         const long long grid = (M + BM16 - 1) / BM16 * a.nphase;
         FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_igemm: grid too large");
-        hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+        // stride-1 convolution on its own grid whose taps are complete x-lines [(dz, dy)] x [dx = -R .. R], dx fastest (R = 1, 2): the lines kernel
+        int lines_r = 0;
+        if (a.nphase == 1 && is == 1 && os == 1 && lift == 0 && Do == D && Ho == H && Wo == W && Di == D && Hi == H && Wi == W && pz == 0 && py == 0 && px == 0) {
+            for (int r = 1; r <= 2 && !lines_r; ++r) {
+                const int nt = 2 * r + 1;
+                bool ok = ntaps % nt == 0 && W > r;
+                for (int t = 0; ok && t < ntaps; ++t)
+                    ok = taps[t * 3 + 2] == (t % nt) - r && taps[t * 3] == taps[(t - t % nt) * 3] && taps[t * 3 + 1] == taps[(t - t % nt) * 3 + 1];
+                if (ok) lines_r = r;
+            }
+        }
+        if (lines_r == 1) hipLaunchKernelGGL(conv_igemm_n16_lines_kernel<1>, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+        else if (lines_r == 2) hipLaunchKernelGGL(conv_igemm_n16_lines_kernel<2>, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+        else hipLaunchKernelGGL(conv_igemm_n16_kernel, dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
     } else {
         const bool can_split = a.nphase == 1 && splitk_ws && (epilogue == EPI_BIAS || epilogue == EPI_AFFINE_ACT) && Cout % 4 == 0 && ldo % 4 == 0;
         ConvPlan pl;

@@ -744,6 +744,38 @@ def test_conv_igemm_narrow_n(dev, Cin, Cout):
     assert out[..., Cout:].abs().max().item() == 0.0 if Cout < 16 else True
 
 
+@pytest.mark.parametrize("dims,k2d", [((4, 6, 70), False), ((3, 5, 2), False), ((1, 9, 300), True), ((1, 7, 3), True)])
+def test_conv_igemm_narrow_lines_kernel_vs_generic_and_torch(dev, dims, k2d):
+    """Cout <= 16 with complete x-lines of taps (3x3x3, dx fastest; 5x5) runs conv_igemm_n16_lines_kernel - the slab of a (dz, dy) line staged once,
+    its dx taps as shifted views, x-line ends masked; the SAME taps in a shuffled order run the generic narrow kernel. Both against torch (3e-5) and
+    against each other (summation order only), with two concatenated inputs, a residual, rows that are not a multiple of the 256-row tile, x-lines
+    shorter than the tile / than the tap radius, and batch boundaries inside a tile."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(sum(dims) + k2d)
+    D, H, W = dims
+    n, C1, C2, Cout = 3, 16, 16, 12
+    kd, k = (1, 5) if k2d else (3, 3)
+    x1, x2 = torch.randn(n, C1, D, H, W, generator=g), torch.randn(n, C2, D, H, W, generator=g)
+    w = torch.randn(Cout, C1 + C2, kd, k, k, generator=g) / (kd * k * k * (C1 + C2)) ** 0.5
+    b, sc, sh = torch.randn(Cout, generator=g), torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    res = torch.randn(n, Cout, D, H, W, generator=g)
+    bc = lambda v: v[None, :, None, None, None]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(torch.cat([x1, x2], 1), w, b, padding=(kd // 2, k // 2, k // 2)) * bc(sc) + bc(sh) + res, 0.01)
+    taps = [(dz, dy, dx) for dz in range(-(kd // 2), kd // 2 + 1) for dy in range(-(k // 2), k // 2 + 1) for dx in range(-(k // 2), k // 2 + 1)]
+    wp = w.permute(2, 3, 4, 0, 1).reshape(len(taps), Cout, C1 + C2).contiguous()
+    perm = torch.randperm(len(taps), generator=g).tolist()
+    outs = []
+    for order in (list(range(len(taps))), perm):                         # complete lines -> lines kernel; shuffled -> generic kernel
+        out = torch.full((n, D, H, W, 16), float("nan"), device=dev)
+        res16 = torch.nn.functional.pad(_rows(res), (0, 16 - Cout)).to(dev)           # the residual shares the output's row stride (16)
+        co.conv_igemm(_rows(x1).to(dev), C1, C1, _rows(x2).to(dev), C2, C2, wp[order].contiguous().to(dev), b.to(dev), sc.to(dev), sh.to(dev), 0.01,
+                      res16, None, None, out, None, (n, D, H, W), (D, H, W), Cout, 16, [taps[i] for i in order], epilogue=co.EPI_AFFINE_ACT)
+        got = out[..., :Cout].permute(0, 4, 1, 2, 3).cpu()
+        assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+        outs.append(got)
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_igemm_2d_5x5_and_transpose2d(dev):
     """the conv_rgb shapes: 25-tap 5x5 conv and ConvTranspose2d(k6,s2,p2) as 4 phase GEMMs of 9 taps."""
     from forge_amd import convops as co

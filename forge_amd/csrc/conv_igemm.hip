@@ -18,10 +18,10 @@
 // (32 MT) x (BN / WN) made of 32x32 MFMA tiles; the tile and a split-K factor are chosen per launch
 // by plan_conv(). Both operands are staged as [row][32 k] images in LDS (128-byte rows, 16-byte
 // chunks XOR-swizzled with (row>>1)&7 so that the 16-lane groups of ds_read_b128 hit 16 distinct
-// slots), filled through registers (raw buffer_load_dwordx4 whose out-of-range offset returns 0 —
-// zero padding of out-of-grid taps / ragged tiles costs neither a branch nor a select — then
-// ds_write_b128), double-buffered with one barrier per K-step and the next K-step's loads in
-// flight under the current MFMAs. The K order inside a 32-chunk is permuted identically for A
+// slots), filled by LDS-DMA (buffer_load_dwordx4 ... lds: global memory straight into LDS, an
+// out-of-range offset lands as zeros — the zero padding of out-of-grid taps / ragged tiles costs
+// neither a branch nor a select; round 3, see the kernel's comment and common.h), double-buffered
+// with one barrier per K-step and the next K-step's loads in flight under the current MFMAs. The K order inside a 32-chunk is permuted identically for A
 // and B: a lane's 16-byte read supplies operand k = 4c+j (lanes 0-31) / 4c+4+j (lanes 32-63) of
 // MFMA j.
 //

@@ -177,6 +177,28 @@ def test_conv_plan_is_host_arithmetic_and_sane():
     assert co.wino_gemm_tile(8192, 256, 256) == "B" and co.wino_gemm_tile(40960, 128, 64) == "B" and co.wino_gemm_tile(320, 256, 256) == "D"
 
 
+def test_plan_model_replica_of_the_fitting_tool_matches_the_library():
+    """tools/fit_plan_model.py re-fits plan_conv's constants on sweep data with a Python replica of the model; the replica (and the constants it
+    starts from) must stay the library's: same (tile, split-K) on a grid of 405 shapes."""
+    from forge_amd import convops as co
+    ns = {"__name__": "replica"}
+    try:
+        exec(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fit_plan_model.py")).read(), ns)
+    except SystemExit:
+        pass
+    avail = {"%s%d" % (t, k) for t in "ABCDE" for k in ns["SPLITS"]}
+    n = 0
+    for M in (1280, 5120, 20480, 32768, 131072, 786432):
+        for N in (32, 64, 128, 256, 512, 2048):
+            for C in (32, 64, 256, 1024):
+                for T in (1, 9, 27):
+                    if M * max(N, C) * 4 >= 1 << 31:
+                        continue
+                    n += 1
+                    assert ns["choose"](ns["TILES"], (M, N, C, T), avail) == "%s%d" % co.conv_plan(M, N, C, T, co.EPI_AFFINE_ACT, N), (M, N, C, T)
+    assert n == 405
+
+
 def test_loss_functions_match_reference_golden():
     """f1: forge_amd.train's four loss functions against the values the REFERENCE's scripts/kubric_compute_loss.py produced on the same
     tensors through a stub model (tests/golden/loss_terms.npz, generated by oracle/make_golden.py)."""

@@ -724,7 +724,7 @@ class ConvGRU_3D(co.PackedModule):
         gx_all = co.conv3x3x3_rows(flat, None, Wg[:, :C], None).reshape(t, b, D, H, W, 2 * C).unbind(0)
         cx_all = co.conv3x3x3_rows(flat, None, Wo[:, :C], None).reshape(t, b, D, H, W, C).unbind(0)
         xviews = xt.unbind(0)
-        wgh, woh = co._pack3d(Wg[:, C:]), co._pack3d(Wo[:, C:])
+        wgh, woh = co._pack3d(Wg[:, C:]).contiguous(), co._pack3d(Wo[:, C:]).contiguous()      # dense once: every GRU step of every group reads them
         lrelu = 0.01
         outs = []
         for grp in groups:

@@ -95,7 +95,7 @@ def stage_timers(model):
         if tuple(kw.get("phase", (0, 0, 0))) == (-1, -1, -1):       # merged transposed-conv phases: 8 (3-D) or 4 (2-D, D not doubled)
             nphase = 8 if kw["out_grid"][0] == 2 * grid[1] else 4
         tile, ksplit = co.conv_plan(M, Cout, C1 + C2, len(taps), kw.get("epilogue", co.EPI_BIAS), a[12], nphase)
-        key = "conv_igemm_n16_kernel" if tile == "N" else "conv_igemm_kernel<%s>" % co.TILE_NAMES[tile]
+        key = "conv_igemm_n16_kernel + conv_igemm_n16_lines_kernel<R> (Cout <= 16)" if tile == "N" else "conv_igemm_kernel<%s>" % co.TILE_NAMES[tile]
         rec.setdefault(key, []).append((e0, e1, 2.0 * M * Cout * len(taps) * (C1 + C2), (M, Cout, len(taps), C1 + C2)))
         return out
     co.conv_igemm = conv_timed

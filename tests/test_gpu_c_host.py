@@ -24,3 +24,18 @@ def test_c_host_program_builds_and_runs(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK" in run.stdout
+
+
+def test_lds_dma_hardware_assumptions_probe(tmp_path):
+    """The K loops of conv_igemm / conv_wgrad stage their operands with `buffer_load_dwordx4 ... offen lds` from inline assembly (csrc/common.h:
+    lds_dma16). What they rely on - lane L of a wave lands at LDS byte M0 + 16 L, lanes whose offset is beyond the buffer write zeros, M0 beyond
+    the first KB works - is checked by a stand-alone HIP program (tools/experiments/dma_probe) compiled here with hipcc for gfx950 and run."""
+    hipcc = shutil.which("hipcc") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "dma_probe")
+    build = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tools", "experiments", "dma_probe", "dma_probe.hip"), "-o", exe],
+                           capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stdout + build.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "dma_probe: OK" in run.stdout, run.stdout + run.stderr

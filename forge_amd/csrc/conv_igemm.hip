@@ -82,17 +82,9 @@ extern "C" int forge_debug_conv_stamps(long long* host, int n) {
 #define FORGE_STAMP(k) do { } while (0)
 #endif
 
-typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-constexpr unsigned OOB = 0x80000000u;      // byte offset beyond any buffer (< 2 GiB spans enforced on the host side)
-
-// Raw buffer load: out-of-range offsets return 0 — the zero padding of out-of-grid taps and of
-// rows/cols beyond M / Cout costs neither a branch nor a select.
-__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    float4 f;
-    __builtin_memcpy(&f, &v, 16);
-    return f;
-}
+constexpr unsigned OOB = 0x80000000u;      // byte offset beyond any buffer (< 2 GiB spans enforced on the host side): such a lane of an LDS-DMA load
+                                           // lands as zeros - the zero padding of out-of-grid taps and of rows / columns beyond M / Cout costs neither
+                                           // a branch nor a select
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset of a 16-byte chunk
     return row * BK + ((chunk ^ ((row >> 1) & 7)) << 2);
@@ -510,9 +502,10 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
     const int kchunks = Cin / BK16;
     const int nsteps = a.tpp * kchunks;
 
-    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.in1, 0, (int)a.span1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in2 ? a.in2 : a.in1), 0, a.in2 ? (int)a.span2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((long long)a.ntaps * a.Cout * Cin * 4), 0x00020000);
+    const forge_v4i32 w1 = make_rsrc_words(a.in1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 : a.in1, a.in2 ? a.span2 : 0),
+                      ww = make_rsrc_words(a.wp, (long long)a.ntaps * a.Cout * Cin * 4);
+    // LDS-DMA staging (common.h): A chunk j of this thread is LDS bytes 16 tid + 8192 j of the stage, the weight chunk (wave 0) bytes 16 tid of the B image
+    const unsigned lds_wave = lds_addr(smem) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
 
     const int cp = tid & 3;                                      // physical chunk in the 64-byte LDS row
     int ar[2], az[2], ay[2], ax[2], an[2], asrc[2];
@@ -547,23 +540,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
             erow2[j] = ok ? an[j] * (int)a.bs2r + sp : -1;
         }
     };
-    float4 ra[2], rb;
-    auto load_step = [&](int t, int kc) {
+    auto issue_step = [&](int t, int kc, int buf) {
         const int c0 = kc * BK16;
+        const unsigned stage = lds_wave + (unsigned)buf * (unsigned)((A_FLOATS + B_FLOATS) * 4);
         if (c0 < a.C1) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ra[j] = buf_load16(r1, erow[j] < 0 ? OOB : (unsigned)((erow[j] * a.ld1 + c0 + asrc[j]) * 4));
+            for (int j = 0; j < 2; ++j) lds_dma16(w1, erow[j] < 0 ? OOB : (unsigned)((erow[j] * a.ld1 + c0 + asrc[j]) * 4), stage + (unsigned)(j * 8192));
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) ra[j] = buf_load16(r2, erow2[j] < 0 ? OOB : (unsigned)((erow2[j] * a.ld2 + (c0 - a.C1) + asrc[j]) * 4));
+            for (int j = 0; j < 2; ++j) lds_dma16(w2, erow2[j] < 0 ? OOB : (unsigned)((erow2[j] * a.ld2 + (c0 - a.C1) + asrc[j]) * 4), stage + (unsigned)(j * 8192));
         }
-        rb = buf_load16(rw, boff == OOB ? OOB : boff + (unsigned)((t * a.Cout * Cin + c0) * 4));
-    };
-    auto store_step = [&](int buf) {
-        float* sa = smem + buf * (A_FLOATS + B_FLOATS);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(sa + ar[j] * BK16 + (cp << 2)) = ra[j];
-        if (tid < 64) *reinterpret_cast<float4*>(sa + A_FLOATS + brow * BK16 + (cp << 2)) = rb;
+        if (wave == 0) lds_dma16(ww, boff == OOB ? OOB : boff + (unsigned)((t * a.Cout * Cin + c0) * 4), stage + (unsigned)(A_FLOATS * 4));
     };
 
     f32x4 acc[2];
@@ -575,15 +562,14 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
     const int kq = lane >> 4, l15 = lane & 15;
     int t = t_lo, kc = 0;
     prep_tap(t);
-    load_step(t, 0);
-    store_step(0);
+    issue_step(t, 0, 0);
+    lds_dma_wait();
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        const bool more = s + 1 < nsteps;
-        if (more) {
+        if (s + 1 < nsteps) {
             if (++kc == kchunks) { kc = 0; ++t; prep_tap(t); }
-            load_step(t, kc);
+            issue_step(t, kc, buf ^ 1);                            // in flight under this step's MFMAs
         }
         const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
         const float* sb = sa + A_FLOATS;
@@ -599,7 +585,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_n16_kernel(const ConvArgs
         for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
-        if (more) store_step(buf ^ 1);
+        lds_dma_wait();
         __syncthreads();
     }
 

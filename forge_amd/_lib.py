@@ -32,7 +32,8 @@ SIGNATURES = {
     "forge_pose_chain_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
     "forge_pack_cameras": [_P, _LL, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _LL, _P, _P, _I, _P],
     "forge_render_fwd": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
-    "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P],
+    "forge_render_bwd_ws_bytes": [_I] * 6,
+    "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P, _LL, _P],
     "forge_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "forge_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 12 + [_P, _LL, _P],
@@ -71,6 +72,9 @@ SIGNATURES = {
 }
 
 
+_LL_RESULTS = ("forge_render_bwd_ws_bytes",)       # byte counts: long long results
+
+
 def lib():
     """Load (once) and return the ctypes handle. Raises if the library has not been built."""
     global _lib
@@ -83,7 +87,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(h, name)
             fn.argtypes = args
-            fn.restype = ctypes.c_char_p if name == "forge_last_error" else _I
+            fn.restype = ctypes.c_char_p if name == "forge_last_error" else (_LL if name in _LL_RESULTS else _I)
         _lib = h
     return _lib
 

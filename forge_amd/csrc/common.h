@@ -68,7 +68,8 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomic
 // buffer byte offset voff[lane] and the hardware writes them to LDS byte address lds + 16 lane (lds must be wave-uniform); lanes whose
 // offset lies outside the buffer's num_records write zeros (the halo / ragged-edge padding of every GEMM here). It is inline assembly
 // on purpose: the compiler's waitcnt insertion does not see these loads, so the K loops place their own `s_waitcnt vmcnt(0)` directly
-// in front of the barrier that publishes the stage, AFTER the step's MFMAs (the builtin form is drained before them).
+// in front of the barrier that publishes the stage, AFTER the step's MFMAs (the builtin form is drained before them). M0 is declared
+// clobbered: the compiler must not keep a live M0 value (LDS / movrel / readlane uses) across the statement.
 typedef int forge_v4i32 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ forge_v4i32 make_rsrc_words(const void* base, long long bytes) {     // raw dword buffer, stride 0
@@ -80,9 +81,12 @@ __device__ __forceinline__ forge_v4i32 make_rsrc_words(const void* base, long lo
     return r;
 }
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"       // "clobber list contains reserved registers: m0" - the clobber is the point (see above)
 __device__ __forceinline__ void lds_dma16(const forge_v4i32& rsrc, unsigned voff, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

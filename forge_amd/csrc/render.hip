@@ -203,41 +203,38 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(const float4* __restric
     }
 }
 
-// Backward. Pass 1 re-marches the densities and parks (d_s, T_s) of every sample in LDS
-// ([s][ray] so a wave's lanes hit consecutive banks); pass 2 walks the ray backwards with
-//     dL/dd_s = T_s (a_s - Q_s),  Q_{s-1} = a_s d_s + (1 - d_s) Q_s,  Q_{S-1} = -g_opacity,
-//     a_s = sum_c g_c f_sc + g_depth z_s          (no division by (1 - d_s): densities may be 1)
-// and scatter-adds the volume gradients through the same 8 taps.
+// Backward = two deterministic launches (no atomics: bit-identical gradients run to run).
 //
-// The scatter is the cost: 8 taps x (C + 1) floats per sample per ray = 143 M fp32 atomics per 128^2 x 64 view when every lane
-// adds its own taps to HBM, although the 64 rays of a workgroup's 8x8 pixel tile land on the same ~5x5x2 voxels at every sample
-// (adjacent pixels are ~0.5 voxel apart on a 64^3 grid). LDS float atomics do not help: ds_add_f32 serialises to ~3 clocks per
-// lane under these same-address collisions (measured: 5 ms of 5.8 for 10 views). So each sample step is turned from a scatter
-// into a GATHER inside the workgroup:
-//   phase A (ray-parallel, lane = ray x 4 channels): re-sample, a_s, dL/dd_s, Q update; park the sample's pixel-space position,
-//           dL/dd_s and the vector T_s d_s g_c in LDS (double-buffered, one barrier per step);
-//   phase B (voxel-parallel, lane = voxel x 4 channels): the voxels of the step's bounding box (block-uniform, from the four
-//           corner rays of the tile: positions are affine in the pixel coordinates) each sum w(q, p_r) * parked vector over the
-//           rays - w(q, p) = prod_a (1 - |p_a - q_a|)+ IS the trilinear tap weight, evaluated with the forward pass's expressions -
-//           in registers, and issue ONE fp32 atomic per non-zero (voxel, channel).
-// HBM atomics drop ~10x (one per touched voxel-channel per step), no LDS atomics, no camera-dependent fallback path.
+//   dL/dd_s = T_s (a_s - Q_s),  Q_{s-1} = a_s d_s + (1 - d_s) Q_s,  Q_{S-1} = -g_opacity,
+//   a_s = sum_c g_c f_sc + g_depth z_s          (no division by (1 - d_s): densities may be 1)
+//   dL/df_sc = T_s d_s g_c
+//
+// (1) render_bwd_rays_kernel (ray-parallel, the forward's decomposition: C/4 lanes per ray, 4x4 pixel quads per wave): re-march, park
+//     (d_s, a_s) of every sample in LDS, run the Q recurrence backwards and the transmittance forwards over the parked values, and
+//     write the two per-sample SCALARS every volume gradient is made of - (dL/dd_s, T_s d_s) - to the workspace G [V][S][Hr][Wr][2]
+//     (8.4 MB per 128^2 x 64 view). With CAM the same pass re-samples the taps for d loss / d (ray origin, direction) and leaves one
+//     16-float partial per workgroup; render_bwd_cam_reduce_kernel sums them in a fixed order.
+// (2) render_bwd_voxels_kernel (voxel-parallel GATHER): one lane per voxel of every volume. For each view of its volume it finds the
+//     depth planes s whose samples can lie inside the voxel's (-1, 1)^3 neighbourhood (|z_s - z_voxel| < sum_a |R_2a| voxel_a) and,
+//     per plane, the small pixel rectangle whose samples can (positions are affine in the pixel index: a 2x2 solve on the best-
+//     conditioned pair of axes, as the forward's taps see them), re-evaluates those rays' sample positions with the FORWARD's
+//     expressions, and sums w(q, p) (dL/dd_s | T_s d_s g_c) with w(q, p) = prod_a (1 - |p_a - q_a|)+ = the forward's trilinear tap
+//     weight of voxel q. Every voxel-channel is WRITTEN once (no zero-fill, no atomics): the scatter of 143 M tap contributions per
+//     view becomes ~20 gathered samples per voxel and view (0.55 voxel / pixel, 1.5 voxels / sample at 64^3).
+// Round 3's in-workgroup gather + one atomic per touched voxel-channel and step took 0.16 ms / view and was order-dependent in the
+// last bits (the noise floor of every training-gradient tolerance); this form costs the forward's march once more plus ~0.02 ms / view.
 template <int C4, bool CAM>
-__global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
-                                                         const float* __restrict__ cams, const int* __restrict__ view2vol,
-                                                         const float* __restrict__ g_feat, const float* __restrict__ g_opac,
-                                                         const float* __restrict__ g_depth, float* __restrict__ dfeat,
-                                                         float* __restrict__ ddens, float* __restrict__ dcam,
-                                                         int D, int H, int W, int Hr, int Wr,
-                                                         int S, float zmin, float zmax, float hx, float hy, float hz) {
+__global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __restrict__ feat, const float* __restrict__ dens,
+                                                              const float* __restrict__ cams, const int* __restrict__ view2vol,
+                                                              const float* __restrict__ g_feat, const float* __restrict__ g_opac,
+                                                              const float* __restrict__ g_depth, float2* __restrict__ G,
+                                                              float* __restrict__ cam_part, int D, int H, int W, int Hr, int Wr,
+                                                              int S, float zmin, float zmax, float hx, float hy, float hz) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][S][RPB] (d, T)  +  2 x { [RPB] float4 (p, dL/dd), [RPB][C4] float4 T d g }
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][RPB][S + 1]: (d_s, a_s) -> (T_s d_s, dL/dd_s); row pad: a wave's rays hit distinct banks
+    const int SP = S + 1;
     float* lds_d = lds;
-    float* lds_T = lds + (size_t)S * RPB;
-    float4* stage = reinterpret_cast<float4*>(lds + (size_t)2 * S * RPB);
-    constexpr int STAGE4 = RPB * (1 + C4);                         // float4 per staging buffer
-    __shared__ int s_range[2];                                     // block-wide [min s0, max s_last] of the marched samples
-    if (threadIdx.x == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
-    __syncthreads();
+    float* lds_a = lds + (size_t)RPB * SP;
     const int v = blockIdx.z;
     const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
     int lx, ly;
@@ -255,31 +252,6 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
     int s0 = 0, s1 = -1;
     if (inside) ray_interval(ray, hx, hy, hz, W, H, D, S, zmin, step, s0, s1);
     const float scx = (float)(W - 1), scy = (float)(H - 1), scz = (float)(D - 1);
-
-    // pass 1: densities + transmittance (every lane of the ray computes the same values; lane cg==0 stores)
-    float T = 1.f;
-    int s_last = s0 - 1;          // last sample marched in the forward pass
-    for (int s = s0; s <= s1; ++s) {
-        const float z = sample_depth(s, S, zmin, zmax, step);
-        const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
-        const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
-        const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
-        Taps t;
-        taps_ac_true(px, py, pz, W, H, D, t);
-        float d = 0.f;
-        if (t.any) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) d = fmaf(t.w[k], Dn[tap_off(t, k)], d);
-        }
-        if (cg == 0) { lds_d[s * RPB + r] = d; lds_T[s * RPB + r] = T; }
-        T *= (1.f - d);
-        s_last = s;
-        if (T == 0.f) break;
-    }
-    if (cg == 0 && s_last >= s0) { atomicMin(&s_range[0], s0); atomicMax(&s_range[1], s_last); }
-    __syncthreads();
-    const int s_lo = s_range[0], s_hi = s_range[1];
-
     const long long plane = (long long)Hr * Wr, pix = (long long)min(h, Hr - 1) * Wr + min(w, Wr - 1);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     float gop = 0.f, gdep = 0.f;
@@ -288,201 +260,103 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
         gop = g_opac[(long long)v * plane + pix];
         if (g_depth) gdep = g_depth[(long long)v * plane + pix];
     }
-    // Samples after an exact T == 0 break have weight 0 and T_s = 0: dL/dd_s = 0, and Q only matters
-    // multiplied by T_s = 0 further down... except through (1-d) factors of *earlier* samples, for
-    // which the forward value of later samples is irrelevant once T hit 0 exactly only if the zero
-    // came from the last marched sample (d = 1): Q_{s_last} would need later terms. They are all
-    // multiplied by T_j = 0 in the true gradient, so starting the recurrence at s_last with
-    // Q = -g_op * prod_{i > s_last}(1 - d_i) is required; that product is not known without marching
-    // on. Keep it exact: when the forward pass broke early, finish marching densities here.
+    float* row_d = lds_d + r * SP;
+    float* row_a = lds_a + r * SP;
+    for (int s = cg; s < S; s += C4) { row_d[s] = 0.f; row_a[s] = 0.f; }     // samples outside the ray's interval: exact zeros in G
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // pass A (forward march over the ray's sample interval): d_s and a_s. All C4 lanes of a ray run the same trip count, so the
+    // xor-shuffles are executed by whole ray groups. No early break at T == 0: the tail's (d, a) still enter Q.
+#pragma unroll 2
+    for (int s = s0; s <= s1; ++s) {
+        const float z = sample_depth(s, S, zmin, zmax, step);
+        const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
+        const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
+        const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
+        Taps t;
+        taps_ac_true(px, py, pz, W, H, D, t);
+        float d = 0.f;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t.any) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long long o = tap_off(t, k);
+                d = fmaf(t.w[k], Dn[o], d);
+                f = f4_fma(t.w[k], F[o * C4], f);
+            }
+        }
+        float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
+#pragma unroll
+        for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
+        a = fmaf(gdep, z, a);
+        if (cg == 0) { row_d[s] = d; row_a[s] = a; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // each ray's rows are written and read by its own C4 lanes (same wave for C4 <= 64)
+    __builtin_amdgcn_wave_barrier();
+    // pass B (reverse, LDS only): X_s = a_s - Q_s parked over a_s
     float Q = -gop;
-    if (inside && s_last < s1) {
-        // rare path (T == 0 exactly): fold the tail's (1 - d) factors and a_j d_j terms into Q
-        for (int s = s1; s > s_last; --s) {
+    for (int s = s1; s >= s0; --s) {
+        const float d = row_d[s], a = row_a[s];
+        __builtin_amdgcn_wave_barrier();                          // all lanes of the ray have read a_s before lane 0 overwrites it
+        if (cg == 0) row_a[s] = a - Q;
+        Q = fmaf(a, d, (1.f - d) * Q);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // pass C (forward): T_s in the forward's multiplication order; (dL/dd_s, T_s d_s) parked, camera gradients accumulated
+    float Go[3] = {0.f, 0.f, 0.f}, Gd[3] = {0.f, 0.f, 0.f};     // d loss / d (ray origin, ray direction), this lane's share
+    float T = 1.f;
+    for (int s = s0; s <= s1; ++s) {
+        const float d = row_d[s], X = row_a[s];
+        const float dLdd = T * X, wgt = d * T;
+        __builtin_amdgcn_wave_barrier();
+        if (cg == 0) { row_d[s] = wgt; row_a[s] = dLdd; }
+        T *= (1.f - d);
+        if (CAM && (wgt != 0.f || dLdd != 0.f)) {
+            // d loss / d pixel coordinate of this sample, this lane's share (its 4 channels; lane cg==0 adds the density term).
+            // Everything downstream is linear, so lanes and rays are summed once at the end.
             const float z = sample_depth(s, S, zmin, zmax, step);
             const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
             const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
             const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
             Taps t;
             taps_ac_true(px, py, pz, W, H, D, t);
-            float d = 0.f;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t.any) {
+                float gpx = 0.f, gpy = 0.f, gpz = 0.f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
+                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
                     const long long o = tap_off(t, k);
-                    d = fmaf(t.w[k], Dn[o], d);
-                    f = f4_fma(t.w[k], F[o * C4], f);
+                    const float4 fv = F[o * C4];
+                    float q = wgt * (fv.x * g.x + fv.y * g.y + fv.z * g.z + fv.w * g.w);
+                    if (cg == 0) q = fmaf(Dn[o], dLdd, q);
+                    gpx = fmaf(t.bx[dx] * t.ay[dy] * t.az[dz], q, gpx);
+                    gpy = fmaf(t.ax[dx] * t.by[dy] * t.az[dz], q, gpy);
+                    gpz = fmaf(t.ax[dx] * t.ay[dy] * t.bz[dz], q, gpz);
                 }
+                const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;
+                Go[0] = fmaf(kx, gpx, Go[0]); Go[1] = fmaf(ky, gpy, Go[1]); Go[2] = fmaf(kz, gpz, Go[2]);
+                Gd[0] = fmaf(kx * z, gpx, Gd[0]); Gd[1] = fmaf(ky * z, gpy, Gd[1]); Gd[2] = fmaf(kz * z, gpz, Gd[2]);
             }
-            float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
-#pragma unroll
-            for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
-            a = fmaf(gdep, z, a);
-            Q = fmaf(a, d, (1.f - d) * Q);
         }
     }
-    float Go[3] = {0.f, 0.f, 0.f}, Gd[3] = {0.f, 0.f, 0.f};   // d loss / d (ray origin, ray direction), this lane's share
-    // pass 2: reverse march, block-uniform over s (rays outside their own [s0, s_last] idle in phase A).
-    // NOTE: all C4 lanes of a ray have identical (s0, s_last), so the xor-shuffles below are
-    // executed by all lanes of each ray group together.
-    // the four corner rays of the tile (identical in every thread): their sample positions bound those of all rays of the tile
-    float cdir[4][3];
+    __syncthreads();
+    // write-out, plane-major G [V][S][Hr][Wr] (what the voxel gather wants: the lanes of a wave - neighbouring voxels - read neighbouring
+    // pixels of one depth plane): per (s, tile row) 8 pixels = 64 contiguous bytes; samples outside a ray's interval are exact zeros
     {
-        const int x0 = min((int)blockIdx.x * 8, Wr - 1), x1 = min((int)blockIdx.x * 8 + 7, Wr - 1);
-        const int y0 = min((int)blockIdx.y * TH, Hr - 1), y1 = min((int)blockIdx.y * TH + TH - 1, Hr - 1);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const RayCam c = make_ray(cam, (q & 1) ? x1 : x0, (q & 2) ? y1 : y0);
-            cdir[q][0] = c.dx; cdir[q][1] = c.dy; cdir[q][2] = c.dz;
-        }
-    }
-    float d00[3], dU[3], dV[3];                                    // direction of the tile's pixel (0, 0) and its per-pixel increments
-    {
-        const RayCam c = make_ray(cam, (int)blockIdx.x * 8, (int)blockIdx.y * TH);
-        d00[0] = c.dx; d00[1] = c.dy; d00[2] = c.dz;
-        dU[0] = cam[0] / cam[12]; dU[1] = cam[1] / cam[12]; dU[2] = cam[2] / cam[12];
-        dV[0] = cam[3] / cam[13]; dV[1] = cam[4] / cam[13]; dV[2] = cam[5] / cam[13];
-    }
-    const int vslot = threadIdx.x / C4;                            // phase B: voxel slot of this lane (RPB slots x C4 channel groups)
-    int buf = 0;
-    for (int s = s_hi; s >= s_lo; --s, buf ^= 1) {
-        const float z = sample_depth(s, S, zmin, zmax, step);
-        float4* st_p = stage + buf * STAGE4;                       // [RPB] (px, py, pz, dL/dd)
-        float4* st_g = st_p + RPB;                                 // [RPB][C4] T d g
-        // ---- phase A
-        int step_active = 0;
-        {
-            float4 park_p = make_float4(-1e30f, -1e30f, -1e30f, 0.f), park_g = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s <= s_last && s >= s0) {
-                float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
-                float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
-                float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
-                Taps t;
-                taps_ac_true(px, py, pz, W, H, D, t);
-                const float d = lds_d[s * RPB + r], Ts = lds_T[s * RPB + r];
-                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t.any) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) f = f4_fma(t.w[k], F[tap_off(t, k) * C4], f);
-                }
-                float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
-#pragma unroll
-                for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
-                a = fmaf(gdep, z, a);
-                const float dLdd = Ts * (a - Q);
-                Q = fmaf(a, d, (1.f - d) * Q);
-                const float wgt = d * Ts;
-                if (CAM && t.any) {
-                    // d loss / d pixel coordinate of this sample, this lane's share (its 4 channels; lane cg==0 adds the density
-                    // term). Everything downstream is linear, so lanes and rays are summed once at the end.
-                    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                        const long long o = tap_off(t, k);
-                        const float4 fv = F[o * C4];
-                        float q = wgt * (fv.x * g.x + fv.y * g.y + fv.z * g.z + fv.w * g.w);
-                        if (cg == 0) q = fmaf(Dn[o], dLdd, q);
-                        gpx = fmaf(t.bx[dx] * t.ay[dy] * t.az[dz], q, gpx);
-                        gpy = fmaf(t.ax[dx] * t.by[dy] * t.az[dz], q, gpy);
-                        gpz = fmaf(t.ax[dx] * t.ay[dy] * t.bz[dz], q, gpz);
-                    }
-                    const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;
-                    Go[0] = fmaf(kx, gpx, Go[0]); Go[1] = fmaf(ky, gpy, Go[1]); Go[2] = fmaf(kz, gpz, Go[2]);
-                    Gd[0] = fmaf(kx * z, gpx, Gd[0]); Gd[1] = fmaf(ky * z, gpy, Gd[1]); Gd[2] = fmaf(kz * z, gpz, Gd[2]);
-                }
-                if (t.any && (wgt != 0.f || dLdd != 0.f)) {       // else: this sample's volume gradients are exactly 0
-                    // the position the taps were built from (taps_ac_true clamps it to [-2, N + 1])
-                    park_p = make_float4(fminf(fmaxf(px, -2.f), (float)W + 1.f), fminf(fmaxf(py, -2.f), (float)H + 1.f),
-                                         fminf(fmaxf(pz, -2.f), (float)D + 1.f), dLdd);
-                    park_g = make_float4(wgt * g.x, wgt * g.y, wgt * g.z, wgt * g.w);
-                }
-            }
-            if (cg == 0) st_p[r] = park_p;
-            st_g[r * C4 + cg] = park_g;
-            step_active = park_p.x > -1e29f;
-        }
-        if (!__syncthreads_or(step_active)) continue;              // no ray of the tile scatters at this sample (empty space)
-        // ---- phase B: bounding box of the step's taps from the corner rays (+- a guard against rounding), clamped to the grid
-        float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
-        {
-            const float o3[3] = {ray.ox, ray.oy, ray.oz}, h3[3] = {hx, hy, hz}, sc3[3] = {scx, scy, scz};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    const float pc = (((o3[ax] + cdir[q][ax] * z) / h3[ax] + 1.f) / 2.f) * sc3[ax];
-                    lo[ax] = fminf(lo[ax], pc); hi[ax] = fmaxf(hi[ax], pc);
-                }
-        }
-        const int bx0 = max((int)floorf(fmaxf(lo[0], -4.f) - 0.01f), 0), bx1 = min((int)floorf(fminf(hi[0], (float)W + 4.f) + 0.01f) + 1, W - 1);
-        const int by0 = max((int)floorf(fmaxf(lo[1], -4.f) - 0.01f), 0), by1 = min((int)floorf(fminf(hi[1], (float)H + 4.f) + 0.01f) + 1, H - 1);
-        const int bz0 = max((int)floorf(fmaxf(lo[2], -4.f) - 0.01f), 0), bz1 = min((int)floorf(fminf(hi[2], (float)D + 4.f) + 0.01f) + 1, D - 1);
-        const int ex = bx1 - bx0 + 1, ey = by1 - by0 + 1, ez = bz1 - bz0 + 1;
-        const int nbox = (ex > 0 && ey > 0 && ez > 0) ? ex * ey * ez : 0;
-        // rays that can touch a voxel: positions are affine in the tile-local pixel index, p(lx, ly) = P00 + lx U + ly V, so
-        // |p_a - q_a| < 1 on the two axes (a, b) with the best-conditioned 2x2 system confines (lx, ly) to a small rectangle
-        // around M^-1 (q - P00)_ab with block-uniform half extents (~2 pixels at 0.55 voxel / pixel instead of the whole 8 x 8 tile)
-        float P00[3], U[3], V[3];
-        {
-            const float o3[3] = {ray.ox, ray.oy, ray.oz}, h3[3] = {hx, hy, hz}, sc3[3] = {scx, scy, scz};
-#pragma unroll
-            for (int ax = 0; ax < 3; ++ax) {
-                P00[ax] = (((o3[ax] + d00[ax] * z) / h3[ax] + 1.f) / 2.f) * sc3[ax];
-                U[ax] = z * dU[ax] * (0.5f * sc3[ax] / h3[ax]);
-                V[ax] = z * dV[ax] * (0.5f * sc3[ax] / h3[ax]);
-            }
-        }
-        const float det01 = U[0] * V[1] - U[1] * V[0], det02 = U[0] * V[2] - U[2] * V[0], det12 = U[1] * V[2] - U[2] * V[1];
-        int aa = 0, ab = 1;
-        float det = det01;
-        if (fabsf(det02) > fabsf(det)) { aa = 0; ab = 2; det = det02; }
-        if (fabsf(det12) > fabsf(det)) { aa = 1; ab = 2; det = det12; }
-        const bool solvable = fabsf(det) > 1e-12f;
-        const float idet = solvable ? 1.f / det : 0.f;
-        const float Ua = aa == 0 ? U[0] : U[1], Va = aa == 0 ? V[0] : V[1], Pa = aa == 0 ? P00[0] : P00[1];
-        const float Ub = ab == 1 ? U[1] : U[2], Vb = ab == 1 ? V[1] : V[2], Pb = ab == 1 ? P00[1] : P00[2];
-        const float ext_x = (fabsf(Vb) + fabsf(Va)) * fabsf(idet) + 0.05f, ext_y = (fabsf(Ub) + fabsf(Ua)) * fabsf(idet) + 0.05f;
-        for (int idx = vslot; idx < nbox; idx += RPB) {
-            const int qx = bx0 + idx % ex, qy = by0 + (idx / ex) % ey, qz = bz0 + idx / (ex * ey);
-            const float fqx = (float)qx, fqy = (float)qy, fqz = (float)qz;
-            int lx0 = 0, lx1 = 7, ly0 = 0, ly1 = TH - 1;
-            if (solvable) {
-                const float ra = (aa == 0 ? fqx : fqy) - Pa, rb = (ab == 1 ? fqy : fqz) - Pb;
-                const float cxp = (Vb * ra - Va * rb) * idet, cyp = (Ua * rb - Ub * ra) * idet;
-                lx0 = max((int)ceilf(cxp - ext_x), 0); lx1 = min((int)floorf(cxp + ext_x), 7);
-                ly0 = max((int)ceilf(cyp - ext_y), 0); ly1 = min((int)floorf(cyp + ext_y), TH - 1);
-            }
-            float4 accf = make_float4(0.f, 0.f, 0.f, 0.f);
-            float accd = 0.f;
-            for (int yy = ly0; yy <= ly1; ++yy)
-                for (int xx = lx0; xx <= lx1; ++xx) {
-                    const int rr = (xx & 3) | ((yy & 3) << 2) | ((xx >> 2) << 4) | ((yy >> 2) << 5);   // inverse of tile_pixel
-                    const float4 pp = st_p[rr];
-                    const float ddx = pp.x - fqx, ddy = pp.y - fqy, ddz = pp.z - fqz;
-                    if (fabsf(ddx) < 1.f && fabsf(ddy) < 1.f && fabsf(ddz) < 1.f) {
-                        // the forward pass's weight expressions: lower tap (q = floor p) (q + 1) - p, upper tap (q = floor p + 1) p - (q - 1)
-                        const float wx = ddx >= 0.f ? (fqx + 1.f) - pp.x : pp.x - (fqx - 1.f);
-                        const float wy = ddy >= 0.f ? (fqy + 1.f) - pp.y : pp.y - (fqy - 1.f);
-                        const float wz = ddz >= 0.f ? (fqz + 1.f) - pp.z : pp.z - (fqz - 1.f);
-                        const float wq = wx * wy * wz;
-                        accf = f4_fma(wq, st_g[rr * C4 + cg], accf);
-                        accd = fmaf(wq, pp.w, accd);
-                    }
-                }
-            const long long o = ((long long)qz * H + qy) * W + qx;
-            float* df = dfeat + ((vbase + o) * C4 + cg) * 4;
-            if (accf.x != 0.f) atomic_add_f32(df + 0, accf.x);
-            if (accf.y != 0.f) atomic_add_f32(df + 1, accf.y);
-            if (accf.z != 0.f) atomic_add_f32(df + 2, accf.z);
-            if (accf.w != 0.f) atomic_add_f32(df + 3, accf.w);
-            if (cg == 0 && accd != 0.f) atomic_add_f32(ddens + vbase + o, accd);
+        const int x0 = blockIdx.x * 8, y0 = blockIdx.y * TH;
+        for (int idx = threadIdx.x; idx < RPB * S; idx += 256) {
+            const int s = idx / RPB, pp = idx - s * RPB;            // pp = py * 8 + px inside the 8 x TH tile
+            const int px_ = pp & 7, py_ = pp >> 3;
+            const int ww = x0 + px_, hh = y0 + py_;
+            if (ww >= Wr || hh >= Hr) continue;
+            const int rr = (px_ & 3) | ((py_ & 3) << 2) | ((px_ >> 2) << 4) | ((py_ >> 2) << 5);   // inverse of tile_pixel
+            G[(((long long)v * S + s) * Hr + hh) * Wr + ww] = make_float2(lds_a[rr * SP + s], lds_d[rr * SP + s]);
         }
     }
     if (CAM) {
         // chain to the packed camera (R[9], T[3], fx, fy, cx, cy): o = -R^T T, dir = R^T (dxc, dyc, 1),
-        // dxc = (w + .5 - cx)/fx, dyc = (h + .5 - cy)/fy; then one block reduction and 16 atomics per workgroup.
+        // dxc = (w + .5 - cx)/fx, dyc = (h + .5 - cy)/fy; then one block reduction in a fixed order -> this workgroup's partial
         float dc[16];
         const float dxc = ((float)min(w, Wr - 1) + 0.5f - cam[14]) / cam[12], dyc = ((float)min(h, Hr - 1) + 0.5f - cam[15]) / cam[13];
         const float dcv[3] = {dxc, dyc, 1.f};
@@ -507,7 +381,137 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(const float4* __restric
             if (lane == 0) red[i][wv] = sacc;
         }
         __syncthreads();
-        if (threadIdx.x < 16) atomic_add_f32(dcam + v * 16 + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        const long long blk = ((long long)v * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (threadIdx.x < 16) cam_part[blk * 16 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+// dcam [V][16] = the per-workgroup partials of one view summed in workgroup order (deterministic)
+__global__ __launch_bounds__(64) void render_bwd_cam_reduce_kernel(const float* __restrict__ cam_part, float* __restrict__ dcam, int V, int nblk) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= V * 16) return;
+    const int v = i / 16, k = i % 16;
+    const float* p = cam_part + (long long)v * nblk * 16 + k;
+    float acc = 0.f;
+    for (int b = 0; b < nblk; ++b) acc += p[(long long)b * 16];
+    dcam[i] = acc;
+}
+
+template <int C4>
+__global__ __launch_bounds__(256) void render_bwd_voxels_kernel(const float* __restrict__ cams, const int* __restrict__ view2vol,
+                                                                const float* __restrict__ g_feat, const float2* __restrict__ G,
+                                                                float* __restrict__ dfeat, float* __restrict__ ddens,
+                                                                int V, int D, int H, int W, int Hr, int Wr, int S, float zmin,
+                                                                float zmax, float hx, float hy, float hz) {
+    const long long nvox = (long long)D * H * W;
+    const int n = blockIdx.y;
+    const long long o = (long long)blockIdx.x * 256 + threadIdx.x;       // voxel of volume n
+    const bool live = o < nvox;
+    const long long oc = live ? o : nvox - 1;
+    const int qx = (int)(oc % W), qy = (int)((oc / W) % H), qz = (int)(oc / ((long long)W * H));
+    const float fqx = (float)qx, fqy = (float)qy, fqz = (float)qz;
+    const float scx = (float)(W - 1), scy = (float)(H - 1), scz = (float)(D - 1);
+    const float step = (zmax - zmin) / (float)(S - 1);
+    // world position of the voxel centre (the inverse of the forward's pix = ((x / h + 1) / 2) (N - 1)) and the voxel pitch
+    const float xw = (2.f * fqx / scx - 1.f) * hx, yw = (2.f * fqy / scy - 1.f) * hy, zw = (2.f * fqz / scz - 1.f) * hz;
+    const float vsx = 2.f * hx / scx, vsy = 2.f * hy / scy, vsz = 2.f * hz / scz;
+    const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;     // voxel coordinates per world unit
+    float4 acc[C4];
+#pragma unroll
+    for (int c = 0; c < C4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accd = 0.f;
+    __shared__ int vlist[64];                                            // views of volume n, 64 at a time
+    __shared__ int vcount, vnext;
+    int vscan = 0;
+    while (vscan < V) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int c = 0, v = vscan;
+            for (; v < V && c < 64; ++v)
+                if (view2vol[v] == n) vlist[c++] = v;
+            vcount = c; vnext = v;
+        }
+        __syncthreads();
+        const int nviews = vcount;
+        vscan = vnext;
+        for (int j = 0; j < nviews; ++j) {
+            const int v = vlist[j];
+            const float* cam = cams + v * 16;
+            // camera-z of the voxel centre and the half extent in camera-z of its (-1, 1)^3-voxel neighbourhood: samples of depth plane s
+            // all have camera-z = z_s exactly, so only planes with |z_s - zq| < dzq can hold a sample with a tap on this voxel
+            const float zq = fmaf(cam[6], xw, fmaf(cam[7], yw, fmaf(cam[8], zw, cam[11])));
+            const float dzq = (fabsf(cam[6]) * vsx + fabsf(cam[7]) * vsy + fabsf(cam[8]) * vsz) * 1.001f + 1e-6f;
+            const float fs_lo = (zq - dzq - zmin) / step, fs_hi = (zq + dzq - zmin) / step;
+            if (!(fs_hi >= -0.02f) || !(fs_lo <= (float)(S - 1) + 0.02f)) continue;
+            const int s_lo = max(0, (int)ceilf(fs_lo - 0.02f)), s_hi = min(S - 1, (int)floorf(fs_hi + 0.02f));
+            const RayCam c00 = make_ray(cam, 0, 0);
+            const float dUx = cam[0] / cam[12], dUy = cam[1] / cam[12], dUz = cam[2] / cam[12];     // d direction / d pixel column
+            const float dVx = cam[3] / cam[13], dVy = cam[4] / cam[13], dVz = cam[5] / cam[13];     // d direction / d pixel row
+            const float2* Gv = G + (long long)v * S * Hr * Wr;
+            const float4* gv = reinterpret_cast<const float4*>(g_feat) + (long long)v * Hr * Wr * C4;
+            for (int s = s_lo; s <= s_hi; ++s) {
+                const float z = sample_depth(s, S, zmin, zmax, step);
+                // sample positions of plane s in voxel coordinates are affine in the pixel index: p(x, y) = P0 + x U + y V (rounding aside);
+                // relative to the voxel: e(x, y) = p - q
+                const float E0x = fmaf(fmaf(c00.dx, z, c00.ox), kx, 0.5f * scx) - fqx, E0y = fmaf(fmaf(c00.dy, z, c00.oy), ky, 0.5f * scy) - fqy,
+                            E0z = fmaf(fmaf(c00.dz, z, c00.oz), kz, 0.5f * scz) - fqz;
+                const float Ux = z * dUx * kx, Uy = z * dUy * ky, Uz = z * dUz * kz;
+                const float Vx = z * dVx * kx, Vy = z * dVy * ky, Vz = z * dVz * kz;
+                // |e_a| < 1 on the two axes (a, b) with the best-conditioned 2x2 system confines (x, y) to a small rectangle
+                const float det01 = Ux * Vy - Uy * Vx, det02 = Ux * Vz - Uz * Vx, det12 = Uy * Vz - Uz * Vy;
+                float Ua = Ux, Va = Vx, ra = -E0x, Ub = Uy, Vb = Vy, rb = -E0y, det = det01;
+                if (fabsf(det02) > fabsf(det)) { Ub = Uz; Vb = Vz; rb = -E0z; det = det02; }
+                if (fabsf(det12) > fabsf(det)) { Ua = Uy; Va = Vy; ra = -E0y; Ub = Uz; Vb = Vz; rb = -E0z; det = det12; }
+                int x0 = 0, x1 = Wr - 1, y0 = 0, y1 = Hr - 1;
+                if (fabsf(det) > 1e-12f) {
+                    const float idet = 1.f / det;
+                    const float cxp = (Vb * ra - Va * rb) * idet, cyp = (Ua * rb - Ub * ra) * idet;
+                    const float ext_x = (fabsf(Vb) + fabsf(Va)) * fabsf(idet) + 0.05f, ext_y = (fabsf(Ub) + fabsf(Ua)) * fabsf(idet) + 0.05f;
+                    if (!(cxp + ext_x >= 0.f) || !(cyp + ext_y >= 0.f)) continue;                 // left / above the image (also catches NaN)
+                    // clamp in float first: a far-away voxel's centre may not fit an int
+                    x0 = (int)fmaxf(ceilf(cxp - ext_x), 0.f); x1 = (int)fminf(floorf(cxp + ext_x), (float)(Wr - 1));
+                    y0 = (int)fmaxf(ceilf(cyp - ext_y), 0.f); y1 = (int)fminf(floorf(cyp + ext_y), (float)(Hr - 1));
+                }
+                for (int yy = y0; yy <= y1; ++yy) {
+                    const float rx = fmaf((float)yy, Vx, E0x), ry = fmaf((float)yy, Vy, E0y), rz = fmaf((float)yy, Vz, E0z);
+                    for (int xx = x0; xx <= x1; ++xx) {
+                        // cheap reject on the affine form (its rounding is ~1e-5 voxel: a 1e-3 guard band), then the forward's own expressions
+                        const float ax_ = fmaf((float)xx, Ux, rx), ay_ = fmaf((float)xx, Uy, ry), az_ = fmaf((float)xx, Uz, rz);
+                        if (!(fabsf(ax_) < 1.001f && fabsf(ay_) < 1.001f && fabsf(az_) < 1.001f)) continue;
+                        const float2 gs = Gv[((long long)s * Hr + yy) * Wr + xx];            // (dL/dd_s, T_s d_s)
+                        if (gs.x == 0.f && gs.y == 0.f) continue;
+                        const RayCam rc = make_ray(cam, xx, yy);
+                        float px = (((rc.ox + rc.dx * z) / hx + 1.f) / 2.f) * scx;
+                        float py = (((rc.oy + rc.dy * z) / hy + 1.f) / 2.f) * scy;
+                        float pz = (((rc.oz + rc.dz * z) / hz + 1.f) / 2.f) * scz;
+                        px = fminf(fmaxf(px, -2.f), (float)W + 1.f);                        // taps_ac_true's clamp
+                        py = fminf(fmaxf(py, -2.f), (float)H + 1.f);
+                        pz = fminf(fmaxf(pz, -2.f), (float)D + 1.f);
+                        const float ddx = px - fqx, ddy = py - fqy, ddz = pz - fqz;
+                        if (fabsf(ddx) < 1.f && fabsf(ddy) < 1.f && fabsf(ddz) < 1.f) {
+                            // the forward's weight expressions: lower tap (q = floor p) (q + 1) - p, upper tap (q = floor p + 1) p - (q - 1)
+                            const float wx = ddx >= 0.f ? (fqx + 1.f) - px : px - (fqx - 1.f);
+                            const float wy = ddy >= 0.f ? (fqy + 1.f) - py : py - (fqy - 1.f);
+                            const float wz = ddz >= 0.f ? (fqz + 1.f) - pz : pz - (fqz - 1.f);
+                            const float wq = wx * wy * wz;
+                            accd = fmaf(wq, gs.x, accd);
+                            if (gs.y != 0.f) {
+                                const float wg = wq * gs.y;
+                                const float4* gp = gv + ((long long)yy * Wr + xx) * C4;
+#pragma unroll
+                                for (int c = 0; c < C4; ++c) acc[c] = f4_fma(wg, gp[c], acc[c]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        float4* df = reinterpret_cast<float4*>(dfeat) + ((long long)n * nvox + o) * C4;
+#pragma unroll
+        for (int c = 0; c < C4; ++c) df[c] = acc[c];
+        ddens[(long long)n * nvox + o] = accd;
     }
 }
 
@@ -538,15 +542,19 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const float* _
 }
 
 // adjoint as a gather per INPUT pixel (deterministic, no atomics): the output rows / columns that can reference input index i lie in
-// [ (i - 1) / scale - 1, (i + 1) / scale + 1 ]; each candidate's taps / weights are re-evaluated with the forward's own expressions.
+// ( (i - 0.5) / scale - 0.5, (i + 1.5) / scale - 0.5 ) for any scale; each candidate's taps / weights are re-evaluated with the forward's
+// own expressions.
 __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* __restrict__ g, float* __restrict__ din, int P, int Hi, int Wi, int Ho, int Wo,
                                                                   float sh, float sw) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)P * Hi * Wi) return;
     const int x = (int)(idx % Wi), y = (int)((idx / Wi) % Hi);
     const long long p = idx / ((long long)Wi * Hi);
-    const int Y0 = max(0, (int)floorf((float)(y - 1) / sh) - 1), Y1 = min(Ho - 1, (int)ceilf((float)(y + 1) / sh) + 1);
-    const int X0 = max(0, (int)floorf((float)(x - 1) / sw) - 1), X1 = min(Wo - 1, (int)ceilf((float)(x + 1) / sw) + 1);
+    // src(Y) = sh (Y + 0.5) - 0.5 taps rows floor(src) and floor(src) + 1: row y is referenced iff y - 1 < src(Y) < y + 1, i.e.
+    // (y - 0.5) / sh - 0.5 < Y < (y + 1.5) / sh - 0.5 (+- 1 against rounding; the clamp of src at 0 only adds outputs below that range
+    // for y = 0, which the max(0, .) covers)
+    const int Y0 = max(0, (int)ceilf(((float)y - 0.5f) / sh - 0.5f) - 1), Y1 = min(Ho - 1, (int)floorf(((float)y + 1.5f) / sh - 0.5f) + 1);
+    const int X0 = max(0, (int)ceilf(((float)x - 0.5f) / sw - 0.5f) - 1), X1 = min(Wo - 1, (int)floorf(((float)x + 1.5f) / sw - 0.5f) + 1);
     const float* gp = g + p * Ho * Wo;
     float acc = 0.f;
     for (int Y = Y0; Y <= Y1; ++Y) {
@@ -604,27 +612,55 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
     return 0;
 }
 
+// bytes of workspace forge_render_bwd needs: G [V][Hr][Wr][S] float2 (+ per-workgroup camera partials when dcam is requested)
+static size_t render_bwd_ws_layout(int V, int C, int Hr, int Wr, int S, int want_cam, size_t* cam_off) {
+    const int C4 = C / 4, RPB = 256 / C4, TH = RPB / 8;
+    const size_t g_bytes = (size_t)V * Hr * Wr * S * sizeof(float2);
+    const size_t nblk = (size_t)((Wr + 7) / 8) * ((Hr + TH - 1) / TH);
+    if (cam_off) *cam_off = g_bytes;
+    return g_bytes + (want_cam ? (size_t)V * nblk * 16 * sizeof(float) : 0);
+}
+
+extern "C" long long forge_render_bwd_ws_bytes(int V, int C, int Hr, int Wr, int S, int want_cam) {
+    if (V <= 0 || Hr <= 0 || Wr <= 0 || S <= 1 || !(C == 4 || C == 8 || C == 16 || C == 32)) return -1;
+    return (long long)render_bwd_ws_layout(V, C, Hr, Wr, S, want_cam, nullptr);
+}
+
 extern "C" int forge_render_bwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
                                 const float* g_feat, const float* g_opac, const float* g_depth,
                                 float* dfeat, float* ddens, float* dcam,
                                 int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
-                                float zmin, float zmax, float hx, float hy, float hz, forge_stream_t stream) {
+                                float zmin, float zmax, float hx, float hy, float hz, void* ws, long long ws_bytes, forge_stream_t stream) {
     if (int rc = check_render_args("forge_render_bwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
     FORGE_REQUIRE(g_feat && g_opac && dfeat && ddens, FORGE_EINVAL, "forge_render_bwd: null gradient pointer");
-    const size_t lds_bytes = ((size_t)2 * S * (256 / (C / 4)) + (size_t)2 * (256 / (C / 4)) * (4 + C)) * sizeof(float);
+    FORGE_REQUIRE(nvol <= 65535, FORGE_ESHAPE, "forge_render_bwd: nvol=%d exceeds gridDim.y", nvol);
+    size_t cam_off = 0;
+    const size_t need = render_bwd_ws_layout(V, C, Hr, Wr, S, dcam != nullptr, &cam_off);
+    FORGE_REQUIRE(ws && ws_bytes >= (long long)need, FORGE_EINVAL, "forge_render_bwd: workspace of %lld B given, %zu B needed (forge_render_bwd_ws_bytes)",
+                  ws_bytes, need);
+    FORGE_REQUIRE(((size_t)ws & 15) == 0, FORGE_EINVAL, "forge_render_bwd: workspace must be 16-byte aligned");
+    const size_t lds_bytes = (size_t)2 * (256 / (C / 4)) * (S + 1) * sizeof(float);
     FORGE_REQUIRE(lds_bytes <= 160 * 1024 - 2048, FORGE_ESHAPE, "forge_render_bwd: S=%d needs %zu B of LDS (> 160 KiB)", S, lds_bytes);
+    float2* G = (float2*)ws;
+    float* cam_part = (float*)((char*)ws + cam_off);
+    const long long nvox = (long long)D * H * W;
+    FORGE_REQUIRE((nvox + 255) / 256 < (1ll << 31), FORGE_ESHAPE, "forge_render_bwd: grid too large");
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
         dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
         if (dcam) {
-            FORGE_SET_MAX_LDS_ONCE((render_bwd_kernel<C4, true>), 160 * 1024 - 2048);
-            hipLaunchKernelGGL((render_bwd_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+            FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, true>), 160 * 1024 - 2048);
+            hipLaunchKernelGGL((render_bwd_rays_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+            hipLaunchKernelGGL(render_bwd_cam_reduce_kernel, dim3((V * 16 + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)cam_part, dcam, V,
+                               (int)(grid.x * grid.y));
         } else {
-            FORGE_SET_MAX_LDS_ONCE((render_bwd_kernel<C4, false>), 160 * 1024 - 2048);
-            hipLaunchKernelGGL((render_bwd_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, dfeat, ddens, dcam, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+            FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, false>), 160 * 1024 - 2048);
+            hipLaunchKernelGGL((render_bwd_rays_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
         }
+        hipLaunchKernelGGL(render_bwd_voxels_kernel<C4>, dim3((unsigned)((nvox + 255) / 256), nvol), dim3(256), 0, (hipStream_t)stream, cam, view2vol,
+                           g_feat, (const float2*)G, dfeat, ddens, V, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
     });
     FORGE_LAUNCH_CHECK("forge_render_bwd");
     return 0;

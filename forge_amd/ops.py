@@ -166,13 +166,19 @@ class _RenderRays(torch.autograd.Function):
         g_feat = g_feat.contiguous(memory_format=torch.channels_last)      # [V,Hr,Wr,C] in memory
         g_opac = g_opac.contiguous()
         g_depth = g_depth.contiguous() if (want_depth and g_depth is not None) else None
-        dfeat = _zeros_like_cl(feat_cl)
-        ddens = torch.zeros_like(dens_c)
-        dcam = torch.zeros_like(cam_c) if ctx.needs_input_grad[2] else None        # pose refinement / joint training
-        _lib.check(_lib.lib().forge_render_bwd(
+        # every element of dfeat / ddens / dcam is WRITTEN by the voxel-parallel gather (deterministic, no atomics): no zero-fills
+        dfeat = _empty_like_cl(feat_cl)
+        ddens = torch.empty_like(dens_c)
+        dcam = torch.empty_like(cam_c) if ctx.needs_input_grad[2] else None        # pose refinement / joint training
+        L = _lib.lib()
+        ws_bytes = L.forge_render_bwd_ws_bytes(V, C, Hr, Wr, S, 0 if dcam is None else 1)
+        if ws_bytes < 0:
+            raise RuntimeError("forge_amd: forge_render_bwd_ws_bytes rejected V=%d C=%d Hr=%d Wr=%d S=%d" % (V, C, Hr, Wr, S))
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=feat_cl.device)   # per-sample (dL/dd_s, T_s d_s) of every ray: 8 V Hr Wr S bytes
+        _lib.check(L.forge_render_bwd(
             _lib.ptr(feat_cl), _lib.ptr(dens_c), _lib.ptr(cam_c), _lib.ptr(view2vol),
             _lib.ptr(g_feat), _lib.ptr(g_opac), _lib.ptr(g_depth), _lib.ptr(dfeat), _lib.ptr(ddens), _lib.ptr(dcam),
-            V, nvol, C, D, H, W, Hr, Wr, S, zmin, zmax, half[0], half[1], half[2], _lib.current_stream()),
+            V, nvol, C, D, H, W, Hr, Wr, S, zmin, zmax, half[0], half[1], half[2], _lib.ptr(ws), ws_bytes, _lib.current_stream()),
             "forge_render_bwd")
         return (dfeat, ddens, dcam) + (None,) * 8
 

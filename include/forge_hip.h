@@ -136,17 +136,22 @@ int forge_render_fwd(const float* feat, const float* dens, const float* cam, con
 int forge_pack_cameras(const float* R, long long r0, long long r1, long long r2, const float* T, long long t0, long long t1,
                        const float* K, long long k0, long long k1, long long k2, float* cam16, float* origin, int V, forge_stream_t stream);
 
-/* Backward of forge_render_fwd w.r.t. volumes (and optionally cameras).
+/* Backward of forge_render_fwd w.r.t. volumes (and optionally cameras) - what autograd through PyTorch3D's VolumeSampler /
+ * EmissionAbsorptionRaymarcher computes for models/volume_render.py:63. Deterministic (no atomics): a ray-parallel pass leaves the two
+ * per-sample scalars (dL/dd_s, T_s d_s) in the workspace, a voxel-parallel gather sums every voxel's tap contributions in a fixed order.
  *   g_feat [V][Hr][Wr][C], g_opac [V][Hr][Wr], g_depth [V][Hr][Wr] (nullable)
- *   dfeat  [nvol][D][H][W][C], ddens [nvol][D][H][W]   MUST be zero-filled; scatter-added
- *   dcam   [V][16] nullable, MUST be zero-filled: d loss / d (R, T, fx, fy, cx, cy)
+ *   dfeat  [nvol][D][H][W][C], ddens [nvol][D][H][W]   WRITTEN (every element; no zero-fill needed, nothing accumulated)
+ *   dcam   [V][16] nullable, WRITTEN: d loss / d (R, T, fx, fy, cx, cy)
+ *   ws     caller-owned scratch of at least forge_render_bwd_ws_bytes(V, C, Hr, Wr, S, dcam != NULL) bytes, 16-byte aligned
+ *          (8 V Hr Wr S bytes + 64 bytes per 8 x (64 / (C/4)) pixel tile and view when dcam is requested); no allocation inside.
  */
+long long forge_render_bwd_ws_bytes(int V, int C, int Hr, int Wr, int S, int want_cam);     /* < 0: unsupported arguments */
 int forge_render_bwd(const float* feat, const float* dens, const float* cam, const int* view2vol,
                      const float* g_feat, const float* g_opac, const float* g_depth,
                      float* dfeat, float* ddens, float* dcam,
                      int V, int nvol, int C, int D, int H, int W, int Hr, int Wr, int S,
                      float zmin, float zmax, float hx, float hy, float hz,
-                     forge_stream_t stream);
+                     void* ws, long long ws_bytes, forge_stream_t stream);
 
 /* a7  mask / depth up-sampling (models/volume_render.py:69,74: F.upsample(size=img_size, mode='bilinear') = align_corners False): P planes
  * [Hi][Wi] -> [Ho][Wo] with ATen's source-index / weight arithmetic; _bwd is the adjoint (a deterministic gather per input pixel, written). */

@@ -1,0 +1,15 @@
+# render backward: parity / property tests + the probe timings
+python -m pytest tests/test_gpu_properties.py tests/test_gpu_parity.py -x -q -k "render or resize or refine or pose" 2>&1 | grep -E "assert|Error|passed|failed" | head
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_rb -o rb --output-format csv -- python $GRAFT_REPO_ROOT/tools/render_bwd_probe.py > $GRAFT_REPO_ROOT/gpurun_out/render_bwd_probe.log 2>&1
+cd $GRAFT_REPO_ROOT
+grep backward gpurun_out/render_bwd_probe.log
+python - <<'PY'
+import csv, glob
+tr = sorted(csv.DictReader(open(glob.glob("gpurun_out/prof_rb/**/rb_kernel_trace.csv", recursive=True)[0])), key=lambda r: int(r["Start_Timestamp"]))
+for r in tr:
+    n = r["Kernel_Name"]
+    if "render_bwd" in n:
+        print("%8.1f us  grid %s x %s x %s  %s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], n[:70]))
+PY
+rm -rf gpurun_out/prof_rb

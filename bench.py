@@ -249,7 +249,7 @@ def kernel_rooflines(dev, B, D=32):
         flops = 2.0 * M * Cout * 27 * (Cc + C2)
         out["conv_igemm " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9,
                                                   "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF,
-                                                  "used_by": "the direct form of the same convolution (FORGE_WINOGRAD=0, odd grids, operands beyond the buffer range); "
+                                                  "used_by": "the direct form of the same convolution (`convops.winograd(False)`, odd grids, operands beyond the buffer range); "
                                                              "inference, refinement and training run the Winograd launches below"}
     # the same kernel as the fusion's inference path launches it: 16 Winograd point GEMMs per launch, 3 depth taps, K = 3 Cin
     R = B * D * (D // 2) * (D // 2)
@@ -524,7 +524,7 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "views_counted": units, "ms_per_step": dt / args.steps * 1e3,
-                          "scaling": "weak", "ranks_ok": int(ranks_ok), "train": bool(args.train), "replicas_identical": same, "error": err,
+                          "scaling": "weak", "ranks_ok": int(ranks_ok), "process_group": fdist.group_info(), "train": bool(args.train), "replicas_identical": same, "error": err,
                           "config": {"workload": "dry run: no HIP work, launch + rendezvous + reductions only"}}), flush=True)
     fdist.barrier()
     fdist.shutdown()
@@ -547,29 +547,40 @@ def _timed(fn, steps, warm=2):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-def timed_region(fn, steps, warmup):
-    """W untimed + EXACTLY K timed steps between (barrier, synchronize) pairs; a rank that fails keeps the barrier count."""
-    good, msg, out, dt = 1.0, None, None, 0.0
+def timed_region(fn, steps, warmup, repeats=1):
+    """W untimed steps, then `repeats` regions of EXACTLY K timed steps, each between (barrier, synchronize) pairs; a rank that fails keeps
+    the barrier count. Returns (ok, error, last output, [seconds per region])."""
+    good, msg, out, dts = 1.0, None, None, []
     try:
         for _ in range(warmup):
             out = fn()
         torch.cuda.synchronize()
     except Exception as e:
         good, msg = 0.0, repr(e)[:400]
-    fdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    try:
-        if good:
-            for _ in range(steps):
-                out = fn()
-            torch.cuda.synchronize()
-    except Exception as e:
-        good, msg = 0.0, repr(e)[:400]
-    fdist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return good, msg, out, dt
+    for _ in range(max(1, repeats)):
+        fdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        try:
+            if good:
+                for _ in range(steps):
+                    out = fn()
+                torch.cuda.synchronize()
+        except Exception as e:
+            good, msg = 0.0, repr(e)[:400]
+        fdist.barrier()
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    return good, msg, out, dts
+
+
+def region_stats(dts_max, steps, units_per_step):
+    """dts_max = every region's duration (max over ranks): `value` = units / MEDIAN region; the spread of the same run beside it."""
+    import statistics
+    med = statistics.median(dts_max)
+    per = lambda d: units_per_step * steps / d if d > 0 else None
+    return med, {"regions": len(dts_max), "steps_per_region": steps, "value_median": per(med), "value_min": per(max(dts_max)), "value_max": per(min(dts_max)),
+                 "ms_per_step_median": med / steps * 1e3, "ms_per_step_min": min(dts_max) / steps * 1e3, "ms_per_step_max": max(dts_max) / steps * 1e3}
 
 
 def extra_configs(dev, steps=5):
@@ -725,10 +736,36 @@ def extra_configs(dev, steps=5):
             torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
             opt.step()
         entry("train_step_4_scenes", "the same training step at configs[3]'s per-GPU batch: 4 scenes x 5 views -> 40 rendered views per step; eager launch",
-              40, train_step4, train_step4, n=min(steps, 3))
+              40, train_step4, train_step4, n=steps)
         del s4
     except Exception as e:
         out.append({"name": "train_step_4_scenes", "error": repr(e)[:300]})
+    # BASELINE configs[3] at its REAL per-GPU shape: 4 scenes x 128^3-voxel render grid = 64^3 feature grid (models/rotate.py:115-117; the encoder cannot
+    # produce 64^3 features from 256^2 images, models/encoder.py:49, so synthetic [4,5,128,64^3] feature volumes enter at rotate): rotate(D=64), three
+    # fusions at M = 4 x 262144, heads to 128^3, 40 ray-marched views, loss, backward (data + weight gradients), clip, Adam
+    try:
+        s4 = {k: v.to(dev) for k, v in syn.make_sample(4, T_IN, 256, 1.5, seed=1001).items()}
+        gen4 = torch.Generator(device=dev).manual_seed(78)
+        f4 = torch.randn(4, T_IN, 128, 64, 64, 64, device=dev, generator=gen4).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+        c4 = geo_utils.camera_dict(s4["cam_extrinsics_cv2_canonicalized"][:, :T_IN].repeat(1, 2, 1, 1), s4["K_cv2"][:, :T_IN].repeat(1, 2, 1, 1))
+        p4 = s4["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
+
+        def train_step4g():
+            imgs, masks = m3.reconstruct(f4, p4, c4)[:2]
+            mi = grouped_mse(imgs.reshape(4, 10, 3, 256, 256), s4["images"][:, :T_IN], T_IN)
+            mm = grouped_mse(masks.reshape(4, 10, 1, 256, 256), s4["fg_probabilities"][:, :T_IN], T_IN)
+            loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+            opt.step()
+        entry("train_step_4_scenes_grid64", "BASELINE configs[3] per-GPU shape: GT-pose training step, 4 scenes x 5 synthetic [128,64^3] feature volumes "
+              "(128^3-voxel render grid) -> rotate(D=64) -> 3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
+              40, train_step4g, train_step4g, n=steps)
+        del s4, f4
+    except Exception as e:
+        out.append({"name": "train_step_4_scenes_grid64", "error": repr(e)[:300]})
+    torch.cuda.empty_cache()
     # the same step captured into ONE hipGraph (forge_amd.graph.GraphedStep: forward, loss, backward, clip, capturable Adam) - single-process
     # training is host-bound at one scene (~1000 launches per step); reported beside the eager number, which is what a DDP wrapper runs
     try:
@@ -785,13 +822,17 @@ def train_bench(args, rank, world, dev, affinity):
         ok, err = 0.0, repr(e)[:400]
         import traceback
         traceback.print_exc()
+    R = max(1, min(args.repeats, 3))                                # bounded: a training region is steps x ~0.2 s
+    dts = [0.0] * R
     if ok:
-        ok, err, lt, dt = timed_region(step, args.steps, args.warmup)
+        ok, err, lt, dts = timed_region(step, args.steps, args.warmup, R)
         loss = float(lt) if ok else float("nan")
     else:
-        fdist.barrier()
-        fdist.barrier()
-    dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
+        for _ in range(2 * R):
+            fdist.barrier()
+    pg = fdist.group_info()
+    dts = fdist.all_reduce_scalars(dts, dev, "max")
+    dt = sorted(dts)[len(dts) // 2]
     views, ranks_ok, loss_sum = fdist.all_reduce_scalars([B * 10.0 * ok, ok, loss if ok else 0.0], dev, "sum")
     errs = fdist.gather_strings(err)
     if rank == 0:
@@ -800,6 +841,7 @@ def train_bench(args, rank, world, dev, affinity):
             "metric": "rendered views/sec incl. backward (GT-pose training step, 10 views/scene, 64^3 voxel)", "value": views * args.steps / dt if dt > 0 else None,
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_ok": int(ranks_ok), "errors": [e for e in errs if e],
+            "process_group": pg, "repeats": region_stats(dts, args.steps, views)[1] if dt > 0 else None,
             "mean_loss_all_ranks": loss_sum / max(ranks_ok, 1.0),
             "config": {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered "
                                    "views/scene, reference-native 32^3 / 64^3 grids, SyncBatchNorm + DDP" % B, "scenes_per_gpu": B,
@@ -819,6 +861,9 @@ def main():
                     help="feature grid: 32 = the metric's configuration (64^3 render volume); 64 = BASELINE configs[3]/[4] 128^3-voxel "
                          "scenes: synthetic [b,5,128,64^3] feature volumes through rotate -> fuse -> heads -> ray-march (the encoder cannot produce them)")
     ap.add_argument("--train", action="store_true", help="time the data-parallel training step (SyncBatchNorm + DDP) instead of inference")
+    ap.add_argument("--repeats", type=int, default=10,
+                    help="timed regions of EXACTLY --steps steps each in the same run (each between barrier + synchronize pairs); value = units / the MEDIAN "
+                         "region, min / max reported beside it")
     ap.add_argument("--no-graph", action="store_true", help="launch the step eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--pipeline-depth", type=int, default=4,
                     help="steps in flight: that many hipGraphs of the step replayed round-robin on as many HIP streams (forge_amd.graph.PipelinedForward); "
@@ -912,13 +957,16 @@ def main():
     fdist.init()                                                    # RCCL (backend "nccl") over xGMI when world > 1
     fdist.barrier()
 
+    R = max(1, args.repeats)
     if ok:
-        ok, err, out, dt = timed_region(step, args.steps, args.warmup)
+        ok, err, out, dts = timed_region(step, args.steps, args.warmup, R)
     else:
-        fdist.barrier()
-        fdist.barrier()
-        out, dt = None, 0.0
-    dt = fdist.all_reduce_scalars([dt], dev, "max")[0]
+        for _ in range(2 * R):
+            fdist.barrier()
+        out, dts = None, [0.0] * R
+    pg = fdist.group_info()                                          # which backend actually carried the collectives of this run
+    dts = fdist.all_reduce_scalars(dts, dev, "max")                  # every region: the slowest rank's clock
+    dt = sorted(dts)[len(dts) // 2] if len(dts) % 2 else 0.5 * (sorted(dts)[len(dts) // 2 - 1] + sorted(dts)[len(dts) // 2])   # median region
     # the one exchange of the inference path: (SSE to the target views, pixel count, views rendered) summed over ranks
     # (RCCL all-reduce of a few doubles) -> whole-job PSNR / view count; ranks_ok rides along
     if ok:
@@ -934,7 +982,8 @@ def main():
     if B_strong:                                                     # bounded: <= 5 steps
         n_s = min(5, args.steps)
         if strong is not None and ok:
-            ok_s, err_s, _, dt_s = timed_region(strong, n_s, 1)
+            ok_s, err_s, _, dts_s = timed_region(strong, n_s, 1)
+            dt_s = dts_s[0]
         else:
             fdist.barrier()
             fdist.barrier()
@@ -953,7 +1002,7 @@ def main():
         return None
     if not ok:
         print(json.dumps({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ranks_ok": int(ranks_ok), "errors": errors, "error": err}), flush=True)
+                          "warmup": args.warmup, "ranks_ok": int(ranks_ok), "process_group": pg, "errors": errors, "error": err}), flush=True)
         return None
 
     # ---- the same steps with the sample handed over as (pinned) HOST buffers, as a DataLoader would: PCIe-inclusive rate (never `value`)
@@ -1056,7 +1105,8 @@ def main():
         "metric": metric, "value": views / dt, "unit": "views/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "ranks_ok": int(ranks_ok), "errors": errors,
+        "ranks_ok": int(ranks_ok), "errors": errors, "process_group": pg,
+        "repeats": region_stats(dts, args.steps, float(views_per_step))[1],
         "config": {"workload": workload, "scenes_per_gpu": B, "views_in": T_IN, "views_out": V_OUT, "feature_grid": args.grid,
                    "render_grid": 2 * args.grid, "rank0_affinity": affinity,
                    "steps_in_flight": graphed.depth if graphed is not None else 1,
@@ -1092,7 +1142,7 @@ def main():
     if world == 1 and not args.no_extra and args.grid == 32:
         del graphed, step
         torch.cuda.empty_cache()
-        result["extra_configs"] = extra_configs(dev, steps=min(5, max(2, args.steps)))
+        result["extra_configs"] = extra_configs(dev, steps=10)
     print(json.dumps(result), flush=True)
     return result
 

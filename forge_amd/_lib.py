@@ -55,12 +55,12 @@ SIGNATURES = {
     "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P],
     "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P],
     "forge_bn_ws_doubles": [_I],
-    "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P],
-    "forge_bn_train_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _LL, _I, _P],
+    "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P, _I, _P, _P],
+    "forge_bn_train_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _LL, _I, _P, _I, _P, _I, _P],
     "forge_bn_sync_stats": [_P, _I, _P, _LL, _I, _P],
-    "forge_bn_sync_fwd_apply": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _LL, _I, _P],
-    "forge_bn_sync_bwd_reduce": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _LL, _I, _P],
-    "forge_bn_sync_bwd_apply": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _LL, _LL, _I, _P],
+    "forge_bn_sync_fwd_apply": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _LL, _I, _P, _I, _P, _P],
+    "forge_bn_sync_bwd_reduce": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _LL, _I, _P, _I, _P],
+    "forge_bn_sync_bwd_apply": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _LL, _LL, _I, _P, _I, _P, _I, _P],
     "forge_affine_act_bwd": [_P, _I, _P, _I, _P, _F, _P, _I, _LL, _I, _P],
     "forge_sse_groups_blocks": [],
     "forge_sse_groups_fwd": [_P, _LL, _LL, _LL, _LL, _P, _P] + [_I] * 7 + [_P],

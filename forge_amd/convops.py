@@ -482,13 +482,18 @@ def _batch_stride_rows(x):
 @_lib.on_tensor_device
 def colsum(x):
     """Sum over the rows of a channels-last tensor [..., C] -> [C] - the bias gradient of a convolution - on forge_colsum (float64 partial sums in a
-    fixed order: deterministic, and more accurate than a fp32 tree). Channel counts that are not multiples of 4 (the 1- and 3-channel direct
-    convolutions) keep torch's reduction."""
+    fixed order: deterministic, and more accurate than a fp32 tree). Channel counts that are not multiples of 4 (the 1- and 3-channel outputs of the
+    density head / conv_rgb) take the kernel's flat walk over the dense matrix."""
     C = x.shape[-1]
     rows = x.reshape(-1, C)
-    if C % 4 or not (rows.is_cuda and rows.dtype == torch.float32):
-        return rows.sum(dim=0)
-    rows = rows if (rows.stride(1) == 1 and rows.stride(0) >= C and rows.stride(0) % 4 == 0) else rows.contiguous()
+    if not (rows.is_cuda and rows.dtype == torch.float32):
+        raise RuntimeError("forge_amd: colsum runs only on the MI355X HIP kernels (float32 cuda tensor); got %s on %s" % (rows.dtype, rows.device))
+    if C % 4:
+        if C > 32:
+            raise RuntimeError("forge_amd: colsum needs C %% 4 == 0 or C <= 32 (got %d)" % C)
+        rows = rows if rows.is_contiguous() else rows.contiguous()
+    else:
+        rows = rows if (rows.stride(1) == 1 and rows.stride(0) >= C and rows.stride(0) % 4 == 0) else rows.contiguous()
     out = torch.empty(C, dtype=torch.float32, device=rows.device)
     ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=rows.device)
     _lib.check(_lib.lib().forge_colsum(_lib.ptr(rows), rows.stride(0), _lib.ptr(out), _lib.ptr(ws), rows.shape[0], C, _lib.current_stream()), "forge_colsum")

@@ -12,6 +12,9 @@
 //             bn_finalize_kernel     dbeta / dgamma (also the two means the apply kernel needs, kept in ws[0])
 //             bn_apply_bwd_kernel    dx = gamma * invstd * (g - mean(g) - xhat * mean(g xhat))
 // Five passes over the activation instead of eight, six launches instead of eight. slope = 1: no activation, slope = 0: ReLU.
+// Residual form (the bottleneck tail of the ResNet trunk, out = relu(bn3(conv3) + identity)): forward y = act(x scale + shift + res) in the
+// same apply pass; backward takes the activation mask from the saved OUTPUT (y > 0 <=> pre-activation > 0 for any slope >= 0), and the
+// apply pass also writes d res = g - what autograd otherwise runs as add, relu, threshold_backward and a gradient accumulation (4 passes).
 // Rows [M][ld] fp32 with C % 4 == 0 channels used; thread = (4 channels, one row group).
 #include "common.h"
 
@@ -20,6 +23,10 @@ namespace forge {
 struct BnArgs {
     const float* x; int ldx;
     const float* dy; int lddy;            // backward only
+    const float* res; int ldres;           // forward, nullable: y = act(bn(x) + res)
+    const float* y; int ldy;               // backward, nullable: the forward's OUTPUT; non-null <=> the residual form (mask = y > 0)
+    float* dres; int lddres;               // backward, nullable: d res = g (written)
+    long long* nbt;                        // forward, nullable: num_batches_tracked, incremented by the finalize step
     float* out; int ldo;                   // forward: y; backward: dx
     const float* gamma; const float* beta; // nullable (affine=False): 1 / 0
     float* mean; float* invstd;            // [C]: written by the forward apply, read by the backward
@@ -89,6 +96,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const BnArgs a,
         if (a.dgamma) a.dgamma[c] = (float)s1;
         return;
     }
+    if (a.nbt && c == 0) *a.nbt += 1;
     const double m = s0 / (double)a.M, var = fmax(s1 / (double)a.M - m * m, 0.0);
     a.mean[c] = (float)m;
     a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -103,6 +111,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const BnArgs a,
 __global__ __launch_bounds__(BN_THREADS) void bn_from_totals_kernel(const BnArgs a, const double* __restrict__ totals) {
     const int c = blockIdx.x * BN_THREADS + threadIdx.x;
     if (c >= a.C) return;
+    if (a.nbt && c == 0) *a.nbt += 1;
     const double n = a.cnt ? *a.cnt : (double)a.Mtot, m = totals[c] / n, var = fmax(totals[a.C + c] / n - m * m, 0.0);
     a.mean[c] = (float)m;
     a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -157,6 +166,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_fwd_kernel(const BnArgs a
     for (long long r = (long long)blockIdx.x * RG + rg; r < a.M; r += (long long)gridDim.x * RG) {
         const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
         float y[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
+        if (a.res) {
+            const float4 q = *reinterpret_cast<const float4*>(a.res + r * a.ldres + c);
+            y[0] += q.x; y[1] += q.y; y[2] += q.z; y[3] += q.w;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) y[k] = y[k] > 0.f ? y[k] : y[k] * a.slope;
         *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = make_float4(y[0], y[1], y[2], y[3]);
@@ -174,20 +187,22 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce_bwd_kernel(const BnArgs 
         bn_affine4(a, c, mean, invstd, sc, sh);
         const long long step = (long long)gridDim.x * RG;
         for (long long r0 = (long long)blockIdx.x * RG + rg; r0 < a.M; r0 += 2 * step) {      // 2 x 2 independent loads in flight per thread
-            float4 v[2], d[2];
+            float4 v[2], d[2], yo[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const long long r = r0 + u * step;
                 const bool ok = r < a.M;
                 v[u] = ok ? *reinterpret_cast<const float4*>(a.x + r * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
                 d[u] = ok ? *reinterpret_cast<const float4*>(a.dy + r * a.lddy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                yo[u] = (ok && a.y) ? *reinterpret_cast<const float4*>(a.y + r * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+                const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w}, yv[4] = {yo[u].x, yo[u].y, yo[u].z, yo[u].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float g = fmaf(xv[k], sc[k], sh[k]) > 0.f ? dv[k] : dv[k] * a.slope;     // dy = 0 beyond M: contributes nothing
+                    const float pre = a.y ? yv[k] : fmaf(xv[k], sc[k], sh[k]);                      // residual form: the sign of the saved output
+                    const float g = pre > 0.f ? dv[k] : dv[k] * a.slope;                            // dy = 0 beyond M: contributes nothing
                     acc[k] += g;
                     acc[4 + k] += (double)g * ((xv[k] - mean[k]) * invstd[k]);
                 }
@@ -216,14 +231,41 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_bwd_kernel(const BnArgs a
     for (long long r = (long long)blockIdx.x * RG + rg; r < a.M; r += (long long)gridDim.x * RG) {
         const float4 v = *reinterpret_cast<const float4*>(a.x + r * a.ldx + c);
         const float4 d = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + c);
-        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w};
-        float o[4];
+        const float4 yo = a.y ? *reinterpret_cast<const float4*>(a.y + r * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float xv[4] = {v.x, v.y, v.z, v.w}, dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {yo.x, yo.y, yo.z, yo.w};
+        float o[4], gg[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float g = fmaf(xv[k], sc[k], sh[k]) > 0.f ? dv[k] : dv[k] * a.slope;
+            const float pre = a.y ? yv[k] : fmaf(xv[k], sc[k], sh[k]);
+            const float g = pre > 0.f ? dv[k] : dv[k] * a.slope;
+            gg[k] = g;
             o[k] = k1[k] * (g - k2[k] - (xv[k] - mean[k]) * invstd[k] * k3[k]);
         }
         *reinterpret_cast<float4*>(a.out + r * a.ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (a.dres) *reinterpret_cast<float4*>(a.dres + r * a.lddres + c) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+    }
+}
+
+// Column sums of a DENSE [M][C] matrix for any small C (the 1- and 3-channel outputs of the density head / conv_rgb, whose bias gradients torch's
+// generic reduction took 0.86 ms for at 40 x 256^2 x 3): the matrix is one flat array whose element i belongs to channel i % C; every thread
+// walks it with a stride that is a multiple of C, so its channel is fixed and ONE float64 accumulator suffices. Partials -> ws[block][2][C]
+// (second half zero) for bn_finalize_kernel. Deterministic.
+__global__ __launch_bounds__(BN_THREADS) void colsum_flat_kernel(const float* __restrict__ x, double* __restrict__ ws, long long n, int C, long long stride) {
+    __shared__ double red[BN_THREADS];
+    const long long t0 = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+    double acc = 0.0;
+    if (t0 < stride)                                                 // stride = the thread count rounded DOWN to a multiple of C: the last few threads idle
+        for (long long i = t0; i < n; i += stride) acc += (double)x[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    // thread c < C sums the block's lanes of channel c in lane order; a lane's channel = (blockIdx.x * 256 + lane) % C
+    if ((int)threadIdx.x < C) {
+        const int c = (int)threadIdx.x;
+        int first = (int)((c - ((long long)blockIdx.x * BN_THREADS) % C + C) % C);
+        double s = 0.0;
+        for (int l = first; l < BN_THREADS; l += C) s += red[l];
+        ws[(long long)blockIdx.x * 2 * C + c] = s;
+        ws[(long long)blockIdx.x * 2 * C + C + c] = 0.0;
     }
 }
 
@@ -255,6 +297,24 @@ extern "C" int forge_bn_ws_doubles(int C) { return 2 * C * BN_MAX_PARTIALS; }   
 // (torch: dy.sum(dim = (0, 2, 3, 4)) as a generic reduce kernel of 20-28 us per call). The statistics pass of the BatchNorm kernels above -
 // float64 partial sums, one partial per block, summed in a fixed order: deterministic - with the sum of squares discarded. ws: forge_bn_ws_doubles(C).
 extern "C" int forge_colsum(const float* x, int ldx, float* out, double* ws, long long M, int C, forge_stream_t stream) {
+    if (C > 0 && C <= 32 && (C % 4 != 0 || ldx % 4 != 0) && ldx == C) {
+        // dense narrow matrix: the flat walk (any C <= 32)
+        FORGE_REQUIRE(x && ws && out && M > 0, FORGE_EINVAL, "forge_colsum: null pointer argument / M <= 0");
+        BnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.ws = ws; a.M = M; a.Mtot = M; a.C = C; a.dbeta = out;
+        const long long n = M * C;
+        long long nb = (n + BN_THREADS * 16 - 1) / (BN_THREADS * 16);
+        if (nb > BN_MAX_PARTIALS) nb = BN_MAX_PARTIALS;
+        if (nb < 1) nb = 1;
+        a.nblk = (int)nb;
+        const long long stride = nb * BN_THREADS / C * C;                       // multiple of C: a thread never changes channel
+        hipStream_t st = (hipStream_t)stream;
+        hipLaunchKernelGGL(colsum_flat_kernel, dim3((unsigned)nb), dim3(BN_THREADS), 0, st, x, ws, n, C, stride);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 1);
+        FORGE_LAUNCH_CHECK("forge_colsum");
+        return 0;
+    }
     if (int rc = bn_check("forge_colsum", x, ldx, M, C, ws)) return rc;
     FORGE_REQUIRE(out, FORGE_EINVAL, "forge_colsum: null output pointer");
     BnArgs a;
@@ -269,9 +329,14 @@ extern "C" int forge_colsum(const float* x, int ldx, float* out, double* ws, lon
     return 0;
 }
 
+static int bn_check_side(const char* fn, const char* what, const void* p, int ld, int C) {
+    FORGE_REQUIRE(p == nullptr || (ld >= C && ld % 4 == 0), FORGE_ESHAPE, "%s: %s row stride %d (>= C = %d, multiple of 4)", fn, what, ld, C);
+    return 0;
+}
+
 extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                                   float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
-                                  long long M, int C, forge_stream_t stream) {
+                                  long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_train_fwd", x, ldx, M, C, ws)) return rc;
     FORGE_REQUIRE(y && mean && invstd && ldy >= C && ldy % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr), FORGE_EINVAL,
                   "forge_bn_train_fwd: bad output / running-statistics arguments");
@@ -279,6 +344,8 @@ extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, c
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
     a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.ws = ws; a.eps = eps; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
+    if (int rc = bn_check_side("forge_bn_train_fwd", "residual", res, ldres, C)) return rc;
+    a.res = res; a.ldres = ldres; a.nbt = num_batches_tracked;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr = bn_grid(M, C, true);
     a.nblk = (int)gr.x;
@@ -291,13 +358,17 @@ extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, c
 
 extern "C" int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                                   const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
-                                  forge_stream_t stream) {
+                                  const float* y, int ldy, float* dres, int lddres, forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_train_bwd", x, ldx, M, C, ws)) return rc;
+    if (int rc = bn_check_side("forge_bn_train_bwd", "y", y, ldy, C)) return rc;
+    if (int rc = bn_check_side("forge_bn_train_bwd", "dres", dres, lddres, C)) return rc;
+    FORGE_REQUIRE(dres == nullptr || y != nullptr, FORGE_EINVAL, "forge_bn_train_bwd: the residual form needs the forward's output y");
     FORGE_REQUIRE(dy && dx && mean && invstd && lddy >= C && lddy % 4 == 0 && lddx >= C && lddx % 4 == 0, FORGE_EINVAL, "forge_bn_train_bwd: bad arguments");
     BnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.out = dx; a.ldo = lddx; a.gamma = gamma; a.beta = beta;
     a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
+    a.y = y; a.ldy = ldy; a.dres = dres; a.lddres = lddres;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr = bn_grid(M, C, true);
     a.nblk = (int)gr.x;
@@ -331,8 +402,10 @@ extern "C" int forge_bn_sync_stats(const float* x, int ldx, double* ws, long lon
 
 extern "C" int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                                        float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
-                                       long long M_total, long long M, int C, forge_stream_t stream) {
+                                       long long M_total, long long M, int C, const float* res, int ldres, long long* num_batches_tracked,
+                                       forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_sync_fwd_apply", x, ldx, M, C, totals)) return rc;
+    if (int rc = bn_check_side("forge_bn_sync_fwd_apply", "residual", res, ldres, C)) return rc;
     FORGE_REQUIRE(y && mean && invstd && ldy >= C && ldy % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr) && (M_total == 0 || M_total >= M), FORGE_EINVAL,
                   "forge_bn_sync_fwd_apply: bad output / running-statistics arguments or 0 < M_total < M");
     BnArgs a;
@@ -340,6 +413,7 @@ extern "C" int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gam
     a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
     a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps; a.slope = slope; a.M = M; a.C = C; a.Mtot = M_total;
     a.cnt = M_total == 0 ? totals + 2 * C : nullptr;
+    a.res = res; a.ldres = ldres; a.nbt = num_batches_tracked;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_from_totals_kernel, dim3((unsigned)((C + BN_THREADS - 1) / BN_THREADS)), dim3(BN_THREADS), 0, st, a, totals);
     hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
@@ -349,13 +423,15 @@ extern "C" int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gam
 
 extern "C" int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                                         const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C,
-                                        forge_stream_t stream) {
+                                        const float* y, int ldy, forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_sync_bwd_reduce", x, ldx, M, C, ws)) return rc;
+    if (int rc = bn_check_side("forge_bn_sync_bwd_reduce", "y", y, ldy, C)) return rc;
     FORGE_REQUIRE(dy && mean && invstd && lddy >= C && lddy % 4 == 0, FORGE_EINVAL, "forge_bn_sync_bwd_reduce: bad arguments");
     BnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.gamma = gamma; a.beta = beta; a.mean = const_cast<float*>(mean);
     a.invstd = const_cast<float*>(invstd); a.dgamma = dgamma; a.dbeta = dbeta; a.ws = ws; a.slope = slope; a.M = M; a.C = C; a.Mtot = M;
+    a.y = y; a.ldy = ldy;
     hipStream_t st = (hipStream_t)stream;
     const dim3 gr = bn_grid(M, C, true);
     a.nblk = (int)gr.x;
@@ -367,8 +443,11 @@ extern "C" int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* 
 
 extern "C" int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                                        const float* invstd, float slope, float* dx, int lddx, const double* totals, long long M_total, long long M, int C,
-                                       forge_stream_t stream) {
+                                       const float* y, int ldy, float* dres, int lddres, forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_sync_bwd_apply", x, ldx, M, C, totals)) return rc;
+    if (int rc = bn_check_side("forge_bn_sync_bwd_apply", "y", y, ldy, C)) return rc;
+    if (int rc = bn_check_side("forge_bn_sync_bwd_apply", "dres", dres, lddres, C)) return rc;
+    FORGE_REQUIRE(dres == nullptr || y != nullptr, FORGE_EINVAL, "forge_bn_sync_bwd_apply: the residual form needs the forward's output y");
     FORGE_REQUIRE(dy && dx && mean && invstd && lddy >= C && lddy % 4 == 0 && lddx >= C && lddx % 4 == 0 && (M_total == 0 || M_total >= M), FORGE_EINVAL,
                   "forge_bn_sync_bwd_apply: bad arguments");
     BnArgs a;
@@ -377,6 +456,7 @@ extern "C" int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x
     a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd); a.ws = const_cast<double*>(totals); a.slope = slope; a.M = M; a.C = C;
     a.Mtot = M_total;
     a.cnt = M_total == 0 ? totals + 2 * C : nullptr;
+    a.y = y; a.ldy = ldy; a.dres = dres; a.lddres = lddres;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, (hipStream_t)stream, a);
     FORGE_LAUNCH_CHECK("forge_bn_sync_bwd_apply");
     return 0;

@@ -39,6 +39,19 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+def group_info():
+    """What carried (or would carry) this process's collectives: backend of the default process group ("nccl" = RCCL over xGMI on ROCm,
+    "gloo" for rehearsals with more ranks than GPUs), its size and this rank's device - printed in every bench line so that a multi-GPU
+    record shows which library saw how many ranks."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"initialized": False, "backend": None, "world_size": 1}
+    info = {"initialized": True, "backend": str(dist.get_backend()), "world_size": dist.get_world_size(), "rank": dist.get_rank()}
+    if torch.cuda.is_available():
+        info["device"] = "cuda:%d" % torch.cuda.current_device()
+        info["visible_gpus"] = torch.cuda.device_count()
+    return info
+
+
 def shard_indices(n_items, rank, world):
     """Round-robin shard of scene indices (kubric_eval.py:56: `batch_idx % split_num == exp_id`)."""
     return list(range(rank, n_items, world))
@@ -246,11 +259,14 @@ def broadcast_from_owner(tensors, src, group=None):
     return _BroadcastFromOwner.apply(int(src), group, *tensors)
 
 
-def broadcast_sample(sample, src=0, group=None):
-    """Ray-sharded training renders ONE batch on all ranks: rank `src`'s sample dict (tensors of equal shapes on every rank) is broadcast."""
+def broadcast_sample(sample, src=None, group=None):
+    """Ray-sharded training renders ONE batch on all ranks: rank `src`'s sample dict (tensors of equal shapes on every rank) is broadcast.
+    src is a GLOBAL rank (torch.distributed.broadcast's convention); None = the first rank of `group` (rank 0 of the default group)."""
     rank, world = _group_info(group)
     if world == 1:
         return sample
+    if src is None:
+        src = dist.get_global_rank(group, 0) if group is not None else 0
     out = {}
     for k in sorted(sample):
         v = sample[k]

@@ -258,11 +258,11 @@ class Encoder3D(co.PackedModule):
                 idn = x
                 out = self._bn2d_rows(blk.bn1, co.conv2d_rows(x, blk.conv1.weight, None))
                 out = self._bn2d_rows(blk.bn2, co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0]))
-                out = self._bn2d_rows(blk.bn3, co.conv2d_rows(out, blk.conv3.weight, None), relu=False)
                 if blk.downsample is not None:
                     idn = self._bn2d_rows(blk.downsample[1], co.conv2d_rows(x, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0]),
                                           relu=False)
-                x = torch.relu(out + idn)
+                # relu(bn3(conv3) + identity) in bn3's apply pass (and its mask / d identity in bn3's backward apply pass)
+                x = bn_act_rows(blk.bn3, co.conv2d_rows(out, blk.conv3.weight, None), 0.0, residual=idn)
         return x
 
     def _head_autograd_hip(self, head, z):

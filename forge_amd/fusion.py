@@ -37,50 +37,58 @@ def affine_act_bwd(dy, y, scale, slope, out=None):
     return out
 
 
+def _rows_ok(t, C):
+    return t.stride(1) == 1 and t.stride(0) >= C and t.stride(0) % 4 == 0
+
+
 class _BNTrainRows(torch.autograd.Function):
-    """Train-mode BatchNorm + LeakyReLU(slope) on channels-last rows [M, C] (csrc/bnorm.hip): batch statistics in float64, running statistics
-    updated in place, two kernels each way. slope 1 = no activation, 0 = ReLU."""
+    """Train-mode BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C] (csrc/bnorm.hip): batch statistics in float64, running
+    statistics and num_batches_tracked updated in place by the same launches, two passes each way. slope 1 = no activation, 0 = ReLU.
+    residual [M, C] (optional): y = act(bn(x) + residual) - the bottleneck tail of the ResNet trunk - and the backward returns d residual."""
 
     @staticmethod
     @_lib.on_tensor_device
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt):
         M, C = x.shape
         dev = x.device
         y = torch.empty(M, C, dtype=torch.float32, device=dev)
         mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
         ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
         p = _lib.ptr
+        res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
         _lib.check(_lib.lib().forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
-                                                 p(running_mean), p(running_var), float(momentum), p(ws), M, C, _lib.current_stream()), "forge_bn_train_fwd")
-        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+                                                 p(running_mean), p(running_var), float(momentum), p(ws), M, C, p(res), 0 if res is None else res.stride(0),
+                                                 p(nbt), _lib.current_stream()), "forge_bn_train_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, y if res is not None else None)
         ctx.slope = float(slope)
         return y
 
     @staticmethod
     @_lib.on_tensor_device
     def backward(ctx, dy):
-        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
         M, C = x.shape
         dev = x.device
-        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= C) else dy.contiguous()
+        dy = dy if _rows_ok(dy, C) else dy.contiguous()
         dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dres = torch.empty(M, C, dtype=torch.float32, device=dev) if (y is not None and ctx.needs_input_grad[8]) else None
         dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
         db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
         ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
         p = _lib.ptr
         _lib.check(_lib.lib().forge_bn_train_bwd(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C,
-                                                 p(dg), p(db), p(ws), M, C, _lib.current_stream()), "forge_bn_train_bwd")
-        return dx, dg, db, None, None, None, None, None
+                                                 p(dg), p(db), p(ws), M, C, p(y), C, p(dres), C, _lib.current_stream()), "forge_bn_train_bwd")
+        return dx, dg, db, None, None, None, None, None, dres, None
 
 
 class _SyncBNTrainRows(torch.autograd.Function):
-    """Train-mode SyncBatchNorm + LeakyReLU(slope) on channels-last rows [M, C]: the kernels of _BNTrainRows with ONE all-reduce of the
-    float64 (sum x, sum x^2, row count) forward and of (sum g, sum g xhat) backward over `group` (RCCL over xGMI; torch's SyncBatchNorm
+    """Train-mode SyncBatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C]: the kernels of _BNTrainRows with ONE all-reduce of
+    the float64 (sum x, sum x^2, row count) forward and of (sum g, sum g xhat) backward over `group` (RCCL over xGMI; torch's SyncBatchNorm
     all-gathers per-rank mean / invstd / count instead). dgamma / dbeta are this rank's sums, as torch's: DDP averages them."""
 
     @staticmethod
     @_lib.on_tensor_device
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, group):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group):
         import torch.distributed as tdist
         M, C = x.shape
         dev = x.device
@@ -93,9 +101,11 @@ class _SyncBNTrainRows(torch.autograd.Function):
         m_total = 0                                                 # = "read totals[2C]"
         y = torch.empty(M, C, dtype=torch.float32, device=dev)
         mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+        res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
         _lib.check(L.forge_bn_sync_fwd_apply(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
-                                             p(running_mean), p(running_var), float(momentum), p(tot), m_total, M, C, st()), "forge_bn_sync_fwd_apply")
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, tot[2 * C:].clone())
+                                             p(running_mean), p(running_var), float(momentum), p(tot), m_total, M, C, p(res),
+                                             0 if res is None else res.stride(0), p(nbt), st()), "forge_bn_sync_fwd_apply")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, tot[2 * C:].clone(), y if res is not None else None)
         ctx.slope, ctx.group = float(slope), group
         return y
 
@@ -103,23 +113,24 @@ class _SyncBNTrainRows(torch.autograd.Function):
     @_lib.on_tensor_device
     def backward(ctx, dy):
         import torch.distributed as tdist
-        x, gamma, beta, mean, invstd, count = ctx.saved_tensors
+        x, gamma, beta, mean, invstd, count, y = ctx.saved_tensors
         M, C = x.shape
         dev = x.device
-        dy = dy if (dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.stride(0) >= C) else dy.contiguous()
+        dy = dy if _rows_ok(dy, C) else dy.contiguous()
         dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+        dres = torch.empty(M, C, dtype=torch.float32, device=dev) if (y is not None and ctx.needs_input_grad[8]) else None
         dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
         db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
         _lib.check(L.forge_bn_sync_bwd_reduce(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dg), p(db), p(ws),
-                                              M, C, st()), "forge_bn_sync_bwd_reduce")
+                                              M, C, p(y), C, st()), "forge_bn_sync_bwd_reduce")
         tot = ws[:2 * C]
         tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=ctx.group)
         ws[2 * C:2 * C + 1].copy_(count)                            # the forward's all-rank row count, read by the kernel at totals[2C]
         _lib.check(L.forge_bn_sync_bwd_apply(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C, p(ws),
-                                             0, M, C, st()), "forge_bn_sync_bwd_apply")
-        return dx, dg, db, None, None, None, None, None, None
+                                             0, M, C, p(y), C, p(dres), C, st()), "forge_bn_sync_bwd_apply")
+        return dx, dg, db, None, None, None, None, None, dres, None, None
 
 
 def _sync_world(bn):
@@ -130,30 +141,33 @@ def _sync_world(bn):
     return tdist.get_world_size(bn.process_group)
 
 
-def bn_act_rows(bn, rows, slope=1.0):
-    """BatchNorm module `bn` + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C]. Train mode runs the HIP kernels of
-    csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process group for nn.SyncBatchNorm (one
-    all-reduce of 2C+1 float64 forward, 2C backward: _SyncBNTrainRows); eval mode under autograd and a cumulative-average momentum keep the
-    torch module (on an NC... view of the same memory) followed by the activation."""
+def bn_act_rows(bn, rows, slope=1.0, residual=None):
+    """BatchNorm module `bn` (+ `residual`, same shape as rows) + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C].
+    Train mode runs the HIP kernels of csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process
+    group for nn.SyncBatchNorm (one all-reduce of 2C+1 float64 forward, 2C backward: _SyncBNTrainRows), running statistics and
+    num_batches_tracked updated by the same launches; eval mode under autograd and a cumulative-average momentum keep the torch module (on an
+    NC... view of the same memory) followed by the residual add and the activation."""
     C = rows.shape[-1]
     hip = (bn.training and rows.is_cuda and rows.dtype == torch.float32 and C % 4 == 0
            and (bn.momentum is not None or not bn.track_running_stats))
     if hip:
         x = rows.reshape(-1, C)
-        x = x if (x.stride(1) == 1 and x.stride(0) >= C and x.stride(0) % 4 == 0) else x.contiguous()
+        x = x if _rows_ok(x, C) else x.contiguous()
         track = bn.track_running_stats and bn.running_mean is not None
+        res = None if residual is None else residual.reshape(-1, C)
         args = (x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope)
+                bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope, res,
+                bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None)
         if _sync_world(bn) > 1:                          # the reference's training configuration: statistics over all ranks, one all-reduce each way
             y = _SyncBNTrainRows.apply(*args, bn.process_group)
         else:
             y = _BNTrainRows.apply(*args)
-        if track and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         return y.reshape(rows.shape)
     nd = rows.dim()
     y = bn(rows.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)
     y = y if y.is_contiguous() else y.contiguous()
+    if residual is not None:
+        y = y + residual
     if slope == 1.0:
         return y
     return torch.relu(y) if slope == 0.0 else torch.nn.functional.leaky_relu(y, slope)

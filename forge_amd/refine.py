@@ -19,6 +19,8 @@ from .model import chose_selected, sequence_from_distance
 
 
 def _render_views(model, config, dataset, features, pose7, K, device, canonical=None):
+    """The piecewise evaluation calls of kubric_eval.py:456-491 for given 7-D poses (quat2mat, canonical @ rel, rotate, reorder, fuse, heads,
+    render with depth): what callers use to render targets / evaluate refined poses. The optimisation loop itself runs _render_views_fused."""
     b, t = features.shape[:2]
     D = features.shape[3]
     rel = model.encoder_traj.toSE3(pose7)                                              # [b(t-1),4,4]
@@ -83,30 +85,24 @@ class PoseRefiner:
     records it into a hipGraph on `stream` (fixed shapes, no host synchronisation: closed-form pose inverses, device-side view ordering,
     capturable Adam), `step()` replays it (or runs it eagerly). The model's weights must be frozen by the caller (refine_poses does)."""
 
-    def __init__(self, model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=True, stream=None, fused=True):
-        self.fused_pose_chain = bool(fused)   # False: torch pose algebra + torch.optim.Adam (the yardstick of tests/test_gpu_parity.py)
+    def __init__(self, model, config, dataset, features, poses_cam, target_imgs, target_masks, K, device, use_graph=True, stream=None):
         self.model, self.config, self.dataset, self.device = model, config, dataset, device
         self.features = features.detach().to(device)
         self.target_imgs, self.target_masks, self.K = target_imgs.to(device), target_masks.to(device), K.to(device)
         self.canonical = (dataset.get_canonical_pose_cv2(device=device), dataset.get_canonical_extrinsics_cv2(device=device))
         self.rot = poses_cam[:, :4].detach().clone().to(device).requires_grad_(True)
         self.trans = poses_cam[:, 4:].detach().clone().to(device).requires_grad_(True)
+        if not self.features.is_cuda:
+            raise RuntimeError("forge_amd: PoseRefiner runs only on the MI355X HIP kernels (features on %s); there is no CPU path" % self.features.device)
         lr = 0.001
-        if self.fused_pose_chain and self.features.is_cuda:
-            self.opt = _SmallAdam([(self.rot, lr), (self.trans, lr / 2.0)])
-        else:
-            self.opt = torch.optim.Adam([{"params": self.rot, "lr": lr}, {"params": self.trans, "lr": lr / 2.0}], lr=lr, capturable=bool(use_graph))
+        self.opt = _SmallAdam([(self.rot, lr), (self.trans, lr / 2.0)])
         self.w_rgb, self.w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
         self.use_graph, self.graph, self.static_loss = bool(use_graph), None, None
         self.stream = stream
 
     def iteration(self):
-        if self.fused_pose_chain and self.features.is_cuda:
-            imgs, masks, _, _, _ = _render_views_fused(self.model, self.config, self.dataset, self.features, self.rot, self.trans, self.K, self.device,
-                                                       self.canonical)
-        else:
-            pose7 = torch.cat([F.normalize(self.rot), self.trans], dim=1)
-            imgs, masks, _, _, _ = _render_views(self.model, self.config, self.dataset, self.features, pose7, self.K, self.device, self.canonical)
+        imgs, masks, _, _, _ = _render_views_fused(self.model, self.config, self.dataset, self.features, self.rot, self.trans, self.K, self.device,
+                                                   self.canonical)
         loss = self.w_rgb * F.mse_loss(imgs, self.target_imgs) + self.w_mask * F.mse_loss(masks, self.target_masks)
         loss.backward()
         self.opt.step()
@@ -193,20 +189,22 @@ def refine_poses_many(model, config, dataset, problems, device, iter_num=500, de
             group = problems[g0:g0 + depth]
             cur = torch.cuda.current_stream(device)
             refs = [PoseRefiner(model, config, dataset, *pr, device, use_graph=True, stream=torch.cuda.Stream(device=device)) for pr in group]
+            warm = min(3, iter_num)
             for r in refs:                               # warm-up + capture on the caller's stream, one refiner at a time
-                for _ in range(min(3, iter_num)):
+                for _ in range(warm):
                     r.eager_step()
                 r.capture()
             torch.cuda.synchronize(device)
             for r in refs:
                 r.stream.wait_stream(cur)
             t0 = time.perf_counter()
-            for _ in range(iter_num):
+            replays = iter_num + 1 - warm                 # iter_num + 1 optimiser steps in total, as refine_poses and kubric_eval.py:450 (range(iter_num + 1))
+            for _ in range(replays):
                 for r in refs:
                     r.step()
             torch.cuda.synchronize(device)
             dt_total += time.perf_counter() - t0
-            n_iter += iter_num * len(refs)
+            n_iter += replays * len(refs)
             done.extend(r.poses() for r in refs)
         return done, dt_total / max(n_iter, 1)
     finally:

@@ -211,7 +211,8 @@ def train_step(config, sample, dataset, model, optimizer, device, loss_func=comp
     bare = model.module if hasattr(model, "module") else model
     if getattr(getattr(bare, "render", None), "ray_shard", False):
         from . import dist as fdist
-        sample = fdist.broadcast_sample({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}, src=0, group=bare.render.ray_shard_group)
+        # the group's first rank owns the batch (a GLOBAL rank, as torch.distributed.broadcast wants it: sub-groups need not contain rank 0)
+        sample = fdist.broadcast_sample({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in sample.items()}, src=None, group=bare.render.ray_shard_group)
     accumulation = getattr(config.train, "accumulation_step", 1)
     loss, losses, imgs, masks = loss_func(config, epoch, sample, dataset, model, {}, device, perceptual_loss)
     (loss / accumulation).backward()

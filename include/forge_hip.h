@@ -314,17 +314,20 @@ int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const flo
  *         backward; running_mean / running_var (nullable) are updated in place with `momentum` (unbiased variance), as nn.BatchNorm does
  *   bwd   g = dy * (pre-activation > 0 ? 1 : slope); dx = gamma invstd (g - mean(g) - xhat mean(g xhat)); dgamma = sum g xhat, dbeta = sum g
  * x / y / dy / dx rows [M][ld] fp32, C % 4 == 0; gamma / beta nullable (1 / 0); slope 1 = no activation, 0 = ReLU; ws = forge_bn_ws_doubles(C)
- * doubles of scratch (one float64 partial per reduction block, summed by a second kernel in a fixed order: deterministic, no atomics). */
+ * doubles of scratch (one float64 partial per reduction block, summed by a second kernel in a fixed order: deterministic, no atomics).
+ * Residual form (torchvision Bottleneck tail, out = relu(bn3(conv3) + identity)): res [M][ldres] (nullable) is added before the activation
+ * in the same pass; the backward then takes the forward's OUTPUT y (mask = y > 0, valid for slope >= 0) and also writes d res = g to dres
+ * (nullable). num_batches_tracked (nullable, int64 on the device) is incremented by the forward's finalize step - no separate launch. */
 int forge_bn_ws_doubles(int C);
 /* Column sums out[c] = sum_m x[m][c] of a row-major [M][C] matrix with row stride ldx (floats): the bias gradient of a convolution (torch:
  * dy.sum over every dimension but the channels). float64 partial sums in a fixed order (deterministic); ws = forge_bn_ws_doubles(C) doubles. */
 int forge_colsum(const float* x, int ldx, float* out, double* ws, long long M, int C, forge_stream_t stream);
 int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                        float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
-                       long long M, int C, forge_stream_t stream);
+                       long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream);
 int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                        const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
-                       forge_stream_t stream);
+                       const float* y, int ldy, float* dres, int lddres, forge_stream_t stream);
 /* SyncBatchNorm (torch.nn.SyncBatchNorm.convert_sync_batchnorm, kubric_train_pose_3D.py:119, kubric_train_joint.py:136): the same kernels
  * with ONE all-reduce (SUM) of 2 C doubles (+ the row count) between the reduction and the apply step, issued by the caller (RCCL):
  *   forge_bn_sync_stats       ws[0 .. 2C) = this rank's (sum x, sum x^2) over its M rows          -> all-reduce -> totals, M_total
@@ -338,12 +341,13 @@ int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const
 int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, forge_stream_t stream);
 int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                             float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
-                            long long M_total, long long M, int C, forge_stream_t stream);
+                            long long M_total, long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream);
 int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
-                             const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C, forge_stream_t stream);
+                             const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C,
+                             const float* y, int ldy, forge_stream_t stream);
 int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                             const float* invstd, float slope, float* dx, int lddx, const double* totals, long long M_total, long long M, int C,
-                            forge_stream_t stream);
+                            const float* y, int ldy, float* dres, int lddres, forge_stream_t stream);
 
 /* Backward of forge_conv_igemm's epilogue 1 (folded eval-BatchNorm + LeakyReLU / ReLU) for frozen-weight optimisation loops (pose
  * refinement, kubric_eval.py:412-530): dx[m][c] = dy[m][c] * scale[c] * (y[m][c] > 0 ? 1 : slope), y = the forward OUTPUT (its sign

@@ -57,7 +57,8 @@ def test_bn_eval_keeps_the_torch_module_and_single_process_syncbn_runs_hip():
     assert torch.equal(sync.running_var, plain.running_var)
 
 
-@pytest.mark.parametrize("M,C,ld", [(32768, 128, 128), (5120, 2048, 2048), (1000, 32, 64), (7, 8, 8), (262144, 16, 16)])
+@pytest.mark.parametrize("M,C,ld", [(32768, 128, 128), (5120, 2048, 2048), (1000, 32, 64), (7, 8, 8), (262144, 16, 16), (2621440, 3, 3), (100001, 1, 1),
+                                    (999, 7, 7), (5, 3, 3), (40000, 3, 5)])      # C % 4 != 0: the flat walk (conv_rgb's 3-channel bias gradient, the density head's 1)
 def test_colsum_kernel_vs_float64(M, C, ld):
     """forge_colsum (the bias gradients of the training path; float64 partial sums, fixed order) against a float64 torch sum: 2e-7 of the
     column's absolute sum; a strided view (ld > C) and a deterministic repeat."""
@@ -65,7 +66,7 @@ def test_colsum_kernel_vs_float64(M, C, ld):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(M + C)
     buf = (torch.randn(M, ld, generator=g) * 3.0 + 0.5).to(dev)
-    x = buf[:, :C]
+    x = buf[:, :C]                                                        # ld > C: a strided view (copied to dense rows for C % 4 != 0)
     got = co.colsum(x)
     ref = x.double().sum(dim=0)
     scale = x.double().abs().sum(dim=0)
@@ -73,3 +74,44 @@ def test_colsum_kernel_vs_float64(M, C, ld):
     assert torch.equal(got, co.colsum(x))
     x3 = buf.reshape(1, M, ld)[..., :C]                                   # [..., C] input shapes
     assert torch.equal(co.colsum(x3), got)
+
+
+@pytest.mark.parametrize("shape,slope", [((3, 16, 20, 64), 0.0), ((2, 8, 8, 2048), 0.0), ((2, 4, 6, 8, 32), 0.01)])
+def test_bn_train_residual_form_forward_backward(shape, slope):
+    """y = act(bn(x) + residual) in ONE apply pass each way (the bottleneck tail relu(bn3(conv3) + identity) of the ResNet trunk,
+    torchvision Bottleneck.forward): output, d x, d residual, d gamma / d beta and the running statistics against the torch modules in float64."""
+    from forge_amd.fusion import bn_act_rows
+    dev = torch.device("cuda:0")
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C + 1)
+    x = (torch.randn(*shape, generator=g) * 1.3 + 0.2)
+    res = torch.randn(*shape, generator=g)
+    dy = torch.randn(*shape, generator=g)
+    bn = (nn.BatchNorm3d if len(shape) == 5 else nn.BatchNorm2d)(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    ref_bn = copy.deepcopy(bn).double().train()
+    nd = len(shape)
+    x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    y64 = ref_bn(x64.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + r64
+    y64 = torch.relu(y64) if slope == 0.0 else torch.nn.functional.leaky_relu(y64, slope)
+    y64.backward(dy.double())
+    hb = bn.to(dev).train()
+    xd, rd = x.to(dev).requires_grad_(True), res.to(dev).requires_grad_(True)
+    y = bn_act_rows(hb, xd, slope, residual=rd)
+    y.backward(dy.to(dev))
+    scale = max(1.0, y64.abs().max().item())
+    assert (y.detach().double().cpu() - y64.detach()).abs().max().item() < 2e-6 * scale
+    for got, ref in ((xd.grad, x64.grad), (rd.grad, r64.grad)):
+        e = (got.double().cpu() - ref).abs()
+        assert (e > 1e-5 * ref.abs().max()).double().mean().item() < 1e-4 and e.norm().item() < 1e-4 * ref.norm().item()
+    assert (hb.weight.grad.double().cpu() - ref_bn.weight.grad).abs().max().item() < 2e-5 * max(1.0, ref_bn.weight.grad.abs().max().item())
+    assert (hb.bias.grad.double().cpu() - ref_bn.bias.grad).abs().max().item() < 2e-5 * max(1.0, ref_bn.bias.grad.abs().max().item())
+    assert (hb.running_var.double().cpu() - ref_bn.running_var).abs().max().item() < 1e-5
+    assert int(hb.num_batches_tracked) == 1
+    # eval mode under autograd (the torch module + add + activation) gives the same function of (x, residual)
+    he = copy.deepcopy(hb).eval()
+    ye = bn_act_rows(he, xd.detach(), slope, residual=rd.detach())
+    re = he(xd.detach().permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + rd.detach()
+    assert torch.equal(ye, torch.relu(re) if slope == 0.0 else torch.nn.functional.leaky_relu(re, slope))

@@ -1274,7 +1274,7 @@ def test_refinement_iteration_fused_pose_chain_equals_torch_pose_algebra(dev):
     init[:, 4:] += 0.02 * torch.randn(t - 1, 3, generator=g).to(dev)
     res = {}
     for fused in (True, False):
-        r = refine.PoseRefiner(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, use_graph=False, fused=fused)
+        r = refine.PoseRefiner(model, cfg, ds, feats, init, tgt_i, tgt_m, sample["K_cv2"], dev, use_graph=False)
         can = r.canonical
         if fused:
             imgs, masks, _, origin, poses = refine._render_views_fused(model, cfg, ds, r.features, r.rot, r.trans, r.K, dev, can)
@@ -1414,7 +1414,7 @@ def test_pose_refinement_two_instances_in_flight_match_sequential_runs(dev):
     many, dt = refine.refine_poses_many(model, cfg, ds, problems, dev, iter_num=n, depth=2)
     assert all(p.requires_grad for p in model.parameters())
     for pr, got, gt, init in zip(problems, many, gts, inits):
-        seq, _, _ = refine.refine_poses(model, cfg, ds, *pr, dev, iter_num=n + 2, use_graph=True)     # warm-up 3 eager + n replays vs 3 + (n + 2 - 3 + 1)
+        seq, _, _ = refine.refine_poses(model, cfg, ds, *pr, dev, iter_num=n, use_graph=True)     # both entry points run iter_num + 1 optimiser steps (kubric_eval.py:450)
         assert (got - seq).abs().max().item() < 8e-3 and (got - init).abs().max().item() > 5e-3
         e0, e1 = refine.pose_errors(init, gt), refine.pose_errors(got, gt)
         assert e1[0].mean().item() < e0[0].mean().item()

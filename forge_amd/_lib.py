@@ -52,8 +52,8 @@ SIGNATURES = {
     "forge_conv_direct_wgrad": [_P, _I, _P, _I, _P] + [_I] * 6 + [_P, _I, _P],
     "forge_gru_gates_fwd": [_P, _P, _P, _P, _P, _LL, _I, _P],
     "forge_gru_state_fwd": [_P, _P, _P, _P, _LL, _I, _P],
-    "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P],
-    "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P],
+    "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _LL, _LL, _I, _P],
+    "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P, _LL, _LL, _I, _P],
     "forge_bn_ws_doubles": [_I],
     "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P, _I, _P, _P],
     "forge_bn_train_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _LL, _I, _P, _I, _P, _I, _P],

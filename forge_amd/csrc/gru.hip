@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void gru_state_fwd_kernel(float* __restrict__ 
 
 __global__ __launch_bounds__(256) void gru_state_bwd_kernel(const float* __restrict__ dhn, int ld_dhn, const float* __restrict__ h, const float* __restrict__ z,
                                                             const float* __restrict__ cand, float* __restrict__ dh, float* __restrict__ dz,
-                                                            float* __restrict__ dc, long long n4, int C4) {
+                                                            float* __restrict__ dc, long long n4, int C4, float* __restrict__ acc, long long acc_bs,
+                                                            long long vol, int acc_mode) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
         const float4 g = *reinterpret_cast<const float4*>(dhn + m * ld_dhn + ((i - m * C4) << 2)), hv = reinterpret_cast<const float4*>(h)[i];
@@ -59,12 +60,19 @@ __global__ __launch_bounds__(256) void gru_state_bwd_kernel(const float* __restr
         reinterpret_cast<float4*>(dh)[i] = a;
         reinterpret_cast<float4*>(dz)[i] = b;
         reinterpret_cast<float4*>(dc)[i] = c;
+        if (acc_mode) {                                               // the candidate conv's input half is shared by several fusions: its gradient is summed per view
+            const long long bi = m / vol;
+            float4* ap = reinterpret_cast<float4*>(acc + (bi * acc_bs + (m - bi * vol)) * (long long)(C4 << 2)) + (i - m * C4);
+            if (acc_mode == 2) { const float4 o = *ap; c.x += o.x; c.y += o.y; c.z += o.z; c.w += o.w; }
+            *ap = c;
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restrict__ dz, const float* dhr /* may alias dh_out */, int ld_dhr,
                                                             const float* __restrict__ h, const float* __restrict__ z, const float* __restrict__ r,
-                                                            float* __restrict__ dg, const float* __restrict__ dh, float* dh_out, int ld_dh_out, long long M, int C) {
+                                                            float* __restrict__ dg, const float* __restrict__ dh, float* dh_out, int ld_dh_out, long long M, int C,
+                                                            float* __restrict__ acc, long long acc_bs, long long vol, int acc_mode) {
     const int C4 = C >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < M * C4; i += (long long)gridDim.x * 256) {
         const long long m = i / C4;
@@ -80,6 +88,16 @@ __global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float* __restr
         *reinterpret_cast<float4*>(dg + m * 2 * C + c) = gz;
         *reinterpret_cast<float4*>(dg + m * 2 * C + C + c) = gr;
         *reinterpret_cast<float4*>(dh_out + m * ld_dh_out + c) = dhv;
+        if (acc_mode) {                                               // gradient of the gate conv's shared input half, summed per view over the fusions
+            const long long bi = m / vol;
+            float* ap = acc + (bi * acc_bs + (m - bi * vol)) * 2 * C + c;
+            if (acc_mode == 2) {
+                const float4 oz = *reinterpret_cast<const float4*>(ap), orr = *reinterpret_cast<const float4*>(ap + C);
+                gz.x += oz.x; gz.y += oz.y; gz.z += oz.z; gz.w += oz.w; gr.x += orr.x; gr.y += orr.y; gr.z += orr.z; gr.w += orr.w;
+            }
+            *reinterpret_cast<float4*>(ap) = gz;
+            *reinterpret_cast<float4*>(ap + C) = gr;
+        }
     }
 }
 
@@ -121,25 +139,34 @@ extern "C" int forge_gru_state_fwd(float* c_cand, const float* h, const float* z
     return 0;
 }
 
+static int gru_acc_check(const char* fn, const float* acc, long long acc_bs, long long vol, int acc_mode, long long M) {
+    FORGE_REQUIRE(acc_mode >= 0 && acc_mode <= 2 && (acc_mode == 0 || (acc && vol > 0 && M % vol == 0 && acc_bs >= vol)), FORGE_EINVAL,
+                  "%s: accumulator mode %d needs a buffer, vol > 0 dividing M and a batch stride >= vol rows", fn, acc_mode);
+    return 0;
+}
+
 extern "C" int forge_gru_state_bwd(const float* dhn, int ld_dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
-                                   long long M, int C, forge_stream_t stream) {
+                                   long long M, int C, float* dc_acc, long long acc_bs, long long vol, int acc_mode, forge_stream_t stream) {
     FORGE_REQUIRE(dhn && h && z && cand && dh && dz && dc, FORGE_EINVAL, "forge_gru_state_bwd: null pointer argument");
+    if (int rc = gru_acc_check("forge_gru_state_bwd", dc_acc, acc_bs, vol, acc_mode, M)) return rc;
     FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld_dhn >= C && ld_dhn % 4 == 0, FORGE_ESHAPE,
                   "forge_gru_state_bwd: M=%lld C=%d ld_dhn=%d (multiples of 4, ld_dhn >= C)", M, C, ld_dhn);
     hipLaunchKernelGGL(gru_state_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dhn, ld_dhn, h, z, cand, dh, dz, dc,
-                       M * (C / 4), C / 4);
+                       M * (C / 4), C / 4, dc_acc, acc_bs, vol > 0 ? vol : 1, acc_mode);
     FORGE_LAUNCH_CHECK("forge_gru_state_bwd");
     return 0;
 }
 
 extern "C" int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
-                                   float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, forge_stream_t stream) {
+                                   float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, float* dg_acc, long long acc_bs,
+                                   long long vol, int acc_mode, forge_stream_t stream) {
     FORGE_REQUIRE(dz && dhr && h && z && r && dg && dh, FORGE_EINVAL, "forge_gru_gates_bwd: null pointer argument");
+    if (int rc = gru_acc_check("forge_gru_gates_bwd", dg_acc, acc_bs, vol, acc_mode, M)) return rc;
     FORGE_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && ld_dhr >= C && ld_dhr % 4 == 0, FORGE_ESHAPE,
                   "forge_gru_gates_bwd: M=%lld C=%d ld_dhr=%d (multiples of 4, ld_dhr >= C)", M, C, ld_dhr);
     FORGE_REQUIRE(dh_out == nullptr || (ld_dh_out >= C && ld_dh_out % 4 == 0), FORGE_ESHAPE, "forge_gru_gates_bwd: bad ld_dh_out=%d", ld_dh_out);
     hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(ew_grid(M * (C / 4))), dim3(256), 0, (hipStream_t)stream, dz, dhr, ld_dhr, h, z, r, dg, dh,
-                       dh_out ? dh_out : dh, dh_out ? ld_dh_out : C, M, C);
+                       dh_out ? dh_out : dh, dh_out ? ld_dh_out : C, M, C, dg_acc, acc_bs, vol > 0 ? vol : 1, acc_mode);
     FORGE_LAUNCH_CHECK("forge_gru_gates_bwd");
     return 0;
 }

@@ -41,95 +41,84 @@ def _rows_ok(t, C):
     return t.stride(1) == 1 and t.stride(0) >= C and t.stride(0) % 4 == 0
 
 
-class _BNTrainRows(torch.autograd.Function):
-    """Train-mode BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C] (csrc/bnorm.hip): batch statistics in float64, running
-    statistics and num_batches_tracked updated in place by the same launches, two passes each way. slope 1 = no activation, 0 = ReLU.
-    residual [M, C] (optional): y = act(bn(x) + residual) - the bottleneck tail of the ResNet trunk - and the backward returns d residual."""
-
-    @staticmethod
-    @_lib.on_tensor_device
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt):
-        M, C = x.shape
-        dev = x.device
-        y = torch.empty(M, C, dtype=torch.float32, device=dev)
-        mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
-        ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
-        p = _lib.ptr
-        res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
-        _lib.check(_lib.lib().forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
-                                                 p(running_mean), p(running_var), float(momentum), p(ws), M, C, p(res), 0 if res is None else res.stride(0),
-                                                 p(nbt), _lib.current_stream()), "forge_bn_train_fwd")
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, y if res is not None else None)
-        ctx.slope = float(slope)
-        return y
-
-    @staticmethod
-    @_lib.on_tensor_device
-    def backward(ctx, dy):
-        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
-        M, C = x.shape
-        dev = x.device
-        dy = dy if _rows_ok(dy, C) else dy.contiguous()
-        dx = torch.empty(M, C, dtype=torch.float32, device=dev)
-        dres = torch.empty(M, C, dtype=torch.float32, device=dev) if (y is not None and ctx.needs_input_grad[8]) else None
-        dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
-        db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
-        ws = torch.empty(_lib.lib().forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
-        p = _lib.ptr
-        _lib.check(_lib.lib().forge_bn_train_bwd(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C,
-                                                 p(dg), p(db), p(ws), M, C, p(y), C, p(dres), C, _lib.current_stream()), "forge_bn_train_bwd")
-        return dx, dg, db, None, None, None, None, None, dres, None
-
-
-class _SyncBNTrainRows(torch.autograd.Function):
-    """Train-mode SyncBatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C]: the kernels of _BNTrainRows with ONE all-reduce of
-    the float64 (sum x, sum x^2, row count) forward and of (sum g, sum g xhat) backward over `group` (RCCL over xGMI; torch's SyncBatchNorm
-    all-gathers per-rank mean / invstd / count instead). dgamma / dbeta are this rank's sums, as torch's: DDP averages them."""
-
-    @staticmethod
-    @_lib.on_tensor_device
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group):
+@_lib.on_tensor_device
+def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual=None, nbt=None, group=None):
+    """Train-mode (Sync)BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows x [M, C] (csrc/bnorm.hip): float64 batch statistics, running
+    statistics / num_batches_tracked updated in place by the same launches. group (a process group with > 1 ranks): the statistics are those of
+    all ranks - ONE all-reduce of the float64 (sum x, sum x^2, row count) (RCCL over xGMI; torch's SyncBatchNorm all-gathers per-rank mean /
+    invstd / count instead). Returns (y, saved) with `saved` what bn_rows_bwd needs."""
+    M, C = x.shape
+    dev = x.device
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+    y = torch.empty(M, C, dtype=torch.float32, device=dev)
+    mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
+    res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
+    ldres = 0 if res is None else res.stride(0)
+    count = None
+    if group is None:
+        ws = torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd), p(running_mean),
+                                        p(running_var), float(momentum), p(ws), M, C, p(res), ldres, p(nbt), st()), "forge_bn_train_fwd")
+    else:
         import torch.distributed as tdist
-        M, C = x.shape
-        dev = x.device
-        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
         _lib.check(L.forge_bn_sync_stats(p(x), x.stride(0), p(ws), M, C, st()), "forge_bn_sync_stats")
         tot = ws[:2 * C + 1]
         tot[2 * C:].fill_(float(M))                                 # the row count rides on the same all-reduce and stays on the device
         tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=group)
-        m_total = 0                                                 # = "read totals[2C]"
-        y = torch.empty(M, C, dtype=torch.float32, device=dev)
-        mean, invstd = torch.empty(C, dtype=torch.float32, device=dev), torch.empty(C, dtype=torch.float32, device=dev)
-        res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
         _lib.check(L.forge_bn_sync_fwd_apply(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd),
-                                             p(running_mean), p(running_var), float(momentum), p(tot), m_total, M, C, p(res),
-                                             0 if res is None else res.stride(0), p(nbt), st()), "forge_bn_sync_fwd_apply")
-        ctx.save_for_backward(x, gamma, beta, mean, invstd, tot[2 * C:].clone(), y if res is not None else None)
-        ctx.slope, ctx.group = float(slope), group
+                                             p(running_mean), p(running_var), float(momentum), p(tot), 0, M, C, p(res), ldres, p(nbt), st()),
+                   "forge_bn_sync_fwd_apply")                       # M_total = 0: "read the all-rank row count at totals[2C]"
+        count = tot[2 * C:].clone()
+    return y, (x, gamma, beta, mean, invstd, y if res is not None else None, count, float(slope), group)
+
+
+@_lib.on_tensor_device
+def bn_rows_bwd(saved, dy, need_dres=False):
+    """Backward of bn_rows_fwd: (dx, dgamma, dbeta, dres). Under a process group: one all-reduce of (sum g, sum g xhat); dgamma / dbeta are this
+    rank's sums, as torch's SyncBatchNorm (DDP averages them)."""
+    x, gamma, beta, mean, invstd, y, count, slope, group = saved
+    M, C = x.shape
+    dev = x.device
+    L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+    dy = dy if _rows_ok(dy, C) else dy.contiguous()
+    dx = torch.empty(M, C, dtype=torch.float32, device=dev)
+    dres = torch.empty(M, C, dtype=torch.float32, device=dev) if (y is not None and need_dres) else None
+    dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+    db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
+    if group is None:
+        ws = torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_train_bwd(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), slope, p(dx), C, p(dg), p(db), p(ws),
+                                        M, C, p(y), C, p(dres), C, st()), "forge_bn_train_bwd")
+    else:
+        import torch.distributed as tdist
+        ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_sync_bwd_reduce(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), slope, p(dg), p(db), p(ws),
+                                              M, C, p(y), C, st()), "forge_bn_sync_bwd_reduce")
+        tot = ws[:2 * C]
+        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=group)
+        ws[2 * C:2 * C + 1].copy_(count)                            # the forward's all-rank row count, read by the kernel at totals[2C]
+        _lib.check(L.forge_bn_sync_bwd_apply(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), slope, p(dx), C, p(ws),
+                                             0, M, C, p(y), C, p(dres), C, st()), "forge_bn_sync_bwd_apply")
+    return dx, dg, db, dres
+
+
+class _BNTrainRows(torch.autograd.Function):
+    """Train-mode (Sync)BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C] with autograd: bn_rows_fwd / bn_rows_bwd.
+    slope 1 = no activation, 0 = ReLU. residual [M, C] (optional): y = act(bn(x) + residual) - the bottleneck tail of the ResNet trunk -
+    and the backward returns d residual."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group):
+        y, saved = bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group)
+        tensors = tuple(saved[:7])
+        ctx.save_for_backward(*tensors)
+        ctx.slope, ctx.group = saved[7], saved[8]
         return y
 
     @staticmethod
-    @_lib.on_tensor_device
     def backward(ctx, dy):
-        import torch.distributed as tdist
-        x, gamma, beta, mean, invstd, count, y = ctx.saved_tensors
-        M, C = x.shape
-        dev = x.device
-        dy = dy if _rows_ok(dy, C) else dy.contiguous()
-        dx = torch.empty(M, C, dtype=torch.float32, device=dev)
-        dres = torch.empty(M, C, dtype=torch.float32, device=dev) if (y is not None and ctx.needs_input_grad[8]) else None
-        dg = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
-        db = torch.empty(C, dtype=torch.float32, device=dev) if beta is not None else None
-        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
-        ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
-        _lib.check(L.forge_bn_sync_bwd_reduce(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dg), p(db), p(ws),
-                                              M, C, p(y), C, st()), "forge_bn_sync_bwd_reduce")
-        tot = ws[:2 * C]
-        tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=ctx.group)
-        ws[2 * C:2 * C + 1].copy_(count)                            # the forward's all-rank row count, read by the kernel at totals[2C]
-        _lib.check(L.forge_bn_sync_bwd_apply(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C, p(ws),
-                                             0, M, C, p(y), C, p(dres), C, st()), "forge_bn_sync_bwd_apply")
+        dx, dg, db, dres = bn_rows_bwd(tuple(ctx.saved_tensors) + (ctx.slope, ctx.group), dy, need_dres=ctx.needs_input_grad[8])
         return dx, dg, db, None, None, None, None, None, dres, None, None
 
 
@@ -141,27 +130,43 @@ def _sync_world(bn):
     return tdist.get_world_size(bn.process_group)
 
 
+def _bn_group(bn):
+    """The process group a SyncBatchNorm module's statistics are taken over (torch.distributed's default group when the module has none), or
+    None for plain BatchNorm / a single process."""
+    if _sync_world(bn) <= 1:
+        return None
+    import torch.distributed as tdist
+    return bn.process_group if bn.process_group is not None else tdist.group.WORLD
+
+
+def bn_hip_train(bn, rows):
+    """True when bn_act_rows runs `bn` on the HIP kernels with batch statistics (train mode, fp32 rows on the MI355X, C % 4 == 0, a momentum)."""
+    return (bn.training and rows.is_cuda and rows.dtype == torch.float32 and rows.shape[-1] % 4 == 0
+            and (bn.momentum is not None or not bn.track_running_stats))
+
+
+def bn_module_args(bn):
+    """(running_mean, running_var, momentum, eps, num_batches_tracked, group) of a BatchNorm module for bn_rows_fwd."""
+    track = bn.track_running_stats and bn.running_mean is not None
+    return (bn.running_mean if track else None, bn.running_var if track else None, bn.momentum if bn.momentum is not None else 0.0, bn.eps,
+            bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None, _bn_group(bn))
+
+
 def bn_act_rows(bn, rows, slope=1.0, residual=None):
     """BatchNorm module `bn` (+ `residual`, same shape as rows) + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C].
     Train mode runs the HIP kernels of csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process
-    group for nn.SyncBatchNorm (one all-reduce of 2C+1 float64 forward, 2C backward: _SyncBNTrainRows), running statistics and
+    group for nn.SyncBatchNorm (one all-reduce of 2C+1 float64 forward, 2C backward: bn_rows_fwd / bn_rows_bwd), running statistics and
     num_batches_tracked updated by the same launches; eval mode under autograd and a cumulative-average momentum keep the torch module (on an
     NC... view of the same memory) followed by the residual add and the activation."""
     C = rows.shape[-1]
-    hip = (bn.training and rows.is_cuda and rows.dtype == torch.float32 and C % 4 == 0
-           and (bn.momentum is not None or not bn.track_running_stats))
-    if hip:
+    if bn_hip_train(bn, rows):
         x = rows.reshape(-1, C)
         x = x if _rows_ok(x, C) else x.contiguous()
-        track = bn.track_running_stats and bn.running_mean is not None
+        rm, rv, mom, eps, nbt, group = bn_module_args(bn)
         res = None if residual is None else residual.reshape(-1, C)
-        args = (x, bn.weight, bn.bias, bn.running_mean if track else None, bn.running_var if track else None,
-                bn.momentum if bn.momentum is not None else 0.0, bn.eps, slope, res,
-                bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None)
-        if _sync_world(bn) > 1:                          # the reference's training configuration: statistics over all ranks, one all-reduce each way
-            y = _SyncBNTrainRows.apply(*args, bn.process_group)
-        else:
-            y = _BNTrainRows.apply(*args)
+        args = (x, bn.weight, bn.bias, rm, rv, mom, eps, slope, res, nbt)
+        # SyncBatchNorm in a job with > 1 ranks (the reference's training configuration): statistics over all ranks, one all-reduce each way
+        y = _BNTrainRows.apply(*args, group)
         return y.reshape(rows.shape)
     nd = rows.dim()
     y = bn(rows.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)
@@ -226,7 +231,7 @@ class _GRUCellRows(torch.autograd.Function):
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
         dh, dz, dc = new(C), new(C), new(C)
-        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
+        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, None, 0, 0, 0, st()), "forge_gru_state_bwd")
         # candidate conv: c = conv([x | h r], wo)
         dxh = new(2 * C)                                                                   # (dx | d(h r))
         co.conv3_launch(dc, C, None, 0, wo, None, dxh, grid, 2 * C, dgrad=True)
@@ -238,7 +243,7 @@ class _GRUCellRows(torch.autograd.Function):
             dbo = co.colsum(dc.reshape(M, C))
         # gates: g = conv([x | h], wg); z = sigmoid(g[:C]), r = sigmoid(g[C:]), hr = h r
         dg = new(2 * C)
-        _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
+        _lib.check(L.forge_gru_gates_bwd(p(dz), _lib.ptr(dxh[..., C:]), 2 * C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, None, 0, 0, 0, st()), "forge_gru_gates_bwd")
         dxh2 = new(2 * C)
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dxh2, grid, 2 * C, dgrad=True)
         if ctx.needs_input_grad[2]:
@@ -294,7 +299,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
         dhn = dhn.contiguous()
         dh, dz, dc = new(C), new(C), new(C)
-        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, st()), "forge_gru_state_bwd")
+        _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, None, 0, 0, 0, st()), "forge_gru_state_bwd")
         dhr = new(C)
         co.conv3_launch(dc, C, None, 0, wo, None, dhr, grid, C, dgrad=True)
         dwo = dbo = dwg = dbg = None
@@ -304,7 +309,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         if ctx.has_bias[1] and ctx.needs_input_grad[6]:
             dbo = co.colsum(dc.reshape(M, C))
         dg = new(2 * C)
-        _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, st()), "forge_gru_gates_bwd")
+        _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, None, 0, 0, 0, st()), "forge_gru_gates_bwd")
         dh_total = new(C)                                          # dh (state + reset paths) + conv^T(dg, Wg_h), added in the GEMM epilogue
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dh_total, grid, C, residual=dh, dgrad=True)
         if ctx.needs_input_grad[3]:
@@ -398,12 +403,12 @@ class _FuseFrozen(torch.autograd.Function):
         for ti in reversed(range(t)):
             h, z, r, cand = steps[ti]
             dh, dz, dc, dg = new(), new(), new(), new(2 * C)
-            _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, st()), "forge_gru_state_bwd")
+            _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, None, 0, 0, 0, st()), "forge_gru_state_bwd")
             dxh = new(2 * C)                                                 # (d x_t | d (h r)) of the candidate conv
             dgrad(dc, C, "out", dxh, 2 * C)
             # dg = gate pre-activation gradients; dh + d(hr) r lands in dxh's right half (over d(hr)): dxh = (dx_t part 1 | dh partial)
             _lib.check(L.forge_gru_gates_bwd(ptr(dz), ptr(dxh[:, C:]), 2 * C, ptr(h), ptr(z), ptr(r), ptr(dg), ptr(dh), ptr(dxh[:, C:]), 2 * C, M, C,
-                                             st()), "forge_gru_gates_bwd")
+                                             None, 0, 0, 0, st()), "forge_gru_gates_bwd")
             tot = new(2 * C)                                                 # conv^T(dg, Wg) + dxh = (d x_t | d h_{t-1})
             dgrad(dg, 2 * C, "gate", tot, 2 * C, residual=dxh)
             dx[:, ti] = tot.view(b, D, H, W, 2 * C)[..., :C]
@@ -418,6 +423,205 @@ class _FuseFrozen(torch.autograd.Function):
         dgrad(g, C, "fc0", g2, C)
         dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
         return dx.permute(0, 1, 5, 2, 3, 4), None
+
+
+class _FuseGroupsTrain(torch.autograd.Function):
+    """Several ConvGRU fusions over subsets of the SAME views WITH weight gradients (the GT-pose training step, model_single_pose_estimator.py:
+    108-120: views (0,1,2), (3,4), (0..4)) as ONE autograd node whose forward and backward are hand-scheduled on the Winograd launches:
+      forward   the views are transformed once (V_x) and the point products of the INPUT halves of both GRU convolutions are made once, for
+                all views, and stay in the Winograd domain (MX = V_x (x) U_x: never inverse-transformed); every (group, view) step runs the
+                hidden-state halves only and the inverse transform adds the view's MX before the fused GRU tails (wino_output EPI_GRU_GATES /
+                EPI_GRU_OUT, which also emit r and tanh(c) for the backward); train-mode BatchNorm (batch statistics, SyncBN) through
+                bn_rows_fwd. The transforms V_h / V_hr of every step are KEPT: the weight gradient needs exactly them.
+      backward  per step (reverse): state half, data + weight gradient of the candidate conv's hidden half, gate half, data + weight gradient
+                of the gate conv's hidden half; the two element-wise kernels also SUM their dc / dg into per-view buffers
+                (forge_gru_*_bwd acc_mode), so that the shared input halves are differentiated once per view at the end - two data-gradient
+                and two weight-gradient launches over all views - instead of once per (group, view); weight gradients accumulate in the
+                Winograd domain over all steps (dU) and are brought back (G^T dU G) once per weight.
+    Against the autograd-composed form (_GRUCellPreRows per step) this removes, per step, two input transforms, the separate gate / state
+    forward kernels, the gx / cx residual round trips and autograd's gradient accumulations, stacks and zero-fills; the arithmetic is the same up
+    to the order of fp32 additions (the input halves are added before the inverse transform instead of after it).
+    x [b,t,C,D,H,W] (channels-last memory), weights = the module's parameters; returns one fused volume [b,C,D,H,W] per group."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, Wg, bg, Wo, bo, w0, b0, g1, be1, w3, b3, g4, be4, gn, bn_, gru, groups):
+        b, t, C, D, H, W = x.shape
+        xr = x.detach().permute(0, 1, 3, 4, 5, 2)
+        xr = xr if xr.is_contiguous() else xr.contiguous()
+        dev, M, vol, Ht, Wt = x.device, b * D * H * W, D * H * W, H // 2, W // 2
+        R1 = D * Ht * Wt
+        R = b * R1
+        geo = (b, D, H, W)
+        fc, norm = gru.fusion_conv, gru.fusion_norm
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        newV = lambda rows, c: torch.empty(16, rows, c, dtype=torch.float32, device=dev)
+        pk = lambda w: co.pack_conv3d_weight(w)                              # [27][Cout][Cin]
+        wpg, wpo = pk(Wg), pk(Wo)
+        packs = {"gx": wpg[:, :, :C].contiguous(), "gh": wpg[:, :, C:].contiguous(), "ox": wpo[:, :, :C].contiguous(), "oh": wpo[:, :, C:].contiguous(),
+                 "f0": pk(w0), "f3": pk(w3)}
+        U = {k: co.wino_pack_packed(v) for k, v in packs.items()}
+        Vx = co.wino_input(xr, C, C, b * t, D, H, W)                         # [16][b t R1][C]: all views of all scenes
+        MXg, MXc = newV(b * t * R1, 2 * C), newV(b * t * R1, C)
+        co.wino_gemm(Vx, C, None, 0, U["gx"], MXg, b * t, D, Ht, Wt, 2 * C)
+        co.wino_gemm(Vx, C, None, 0, U["ox"], MXc, b * t, D, Ht, Wt, C)
+        Mm = newV(R, 2 * C)
+        Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)                         # the C-column problems reuse the front of the buffer
+        bnargs = lambda m: bn_module_args(m)
+        outs, saved_groups = [], []
+        for grp in groups:
+            grp = list(grp)
+            run = grp == list(range(grp[0], grp[0] + len(grp)))
+            Vm = newV(R, C)
+            if run:                                                          # the view mean is taken inside the input transform
+                co.wino_input(xr[:, grp[0]:], C, C, b, D, H, W, bs=t * vol, out=Vm, nsum=len(grp), sum_stride=vol)
+            else:
+                co.wino_input(torch.stack([xr[:, ti] for ti in grp], dim=1).mean(dim=1).reshape(M, C), C, C, b, D, H, W, out=Vm)
+            a0 = new()
+            co.wino_gemm(Vm, C, None, 0, U["f0"], Mc, b, D, Ht, Wt, C)
+            co.wino_output(Mc, b0, None, None, 1.0, None, None, None, a0, None, None, *geo, C, C, co.EPI_BIAS)
+            rm, rv, mom, eps, nbt, group = bnargs(fc[1])
+            t0, sv1 = bn_rows_fwd(a0, g1, be1, rm, rv, mom, eps, 0.01, None, nbt, group)
+            Vt0 = co.wino_input(t0, C, C, b, D, H, W)
+            a1 = new()
+            co.wino_gemm(Vt0, C, None, 0, U["f3"], Mc, b, D, Ht, Wt, C)
+            co.wino_output(Mc, b3, None, None, 1.0, None, None, None, a1, None, None, *geo, C, C, co.EPI_BIAS)
+            rm, rv, mom, eps, nbt, group = bnargs(fc[4])
+            h, sv4 = bn_rows_fwd(a1, g4, be4, rm, rv, mom, eps, 0.01, None, nbt, group)
+            steps = []
+            for ti in grp:
+                Vh = co.wino_input(h, C, C, b, D, H, W)
+                co.wino_gemm(Vh, C, None, 0, U["gh"], Mm, b, D, Ht, Wt, 2 * C)
+                z, hr, r = new(), new(), new()
+                co.wino_output(Mm, bg, None, None, 1.0, None, h, None, z, hr, r, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t)
+                Vhr = co.wino_input(hr, C, C, b, D, H, W)
+                co.wino_gemm(Vhr, C, None, 0, U["oh"], Mc, b, D, Ht, Wt, C)
+                hn, cand = new(), new()
+                co.wino_output(Mc, bo, None, None, 1.0, None, h, z, hn, None, cand, *geo, C, C, co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t)
+                steps.append((ti, h, z, r, cand, Vh, Vhr))
+                h = hn
+            rm, rv, mom, eps, nbt, group = bnargs(norm)
+            out, svn = bn_rows_fwd(h, gn, bn_, rm, rv, mom, eps, 1.0, None, nbt, group)
+            outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
+            saved_groups.append((grp, Vm, sv1, Vt0, sv4, steps, svn))
+        ctx.packs, ctx.Vx, ctx.groups_saved, ctx.shape = packs, Vx, saved_groups, (b, t, C, D, H, W)
+        ctx.has_bias = tuple(v is not None for v in (bg, bo, b0, b3))
+        return tuple(outs)
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, *douts):
+        b, t, C, D, H, W = ctx.shape
+        packs, Vx, saved_groups = ctx.packs, ctx.Vx, ctx.groups_saved
+        dev = Vx.device
+        M, vol, Ht, Wt = b * D * H * W, D * H * W, H // 2, W // 2
+        R1 = D * Ht * Wt
+        R = b * R1
+        geo = (b, D, H, W)
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
+        newV = lambda rows, c: torch.empty(16, rows, c, dtype=torch.float32, device=dev)
+        UT = {k: co.wino_pack_packed(v, transpose=True) for k, v in packs.items()}     # Winograd-domain data-gradient weights [16][3][Cin][Cout]
+        dU = {k: torch.zeros(16, 3, v.shape[1], v.shape[2], dtype=torch.float32, device=dev) for k, v in packs.items()}
+        Mm = newV(R, 2 * C)
+        Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
+
+        def dgrad(dy, Cdy, key, dst, residual=None):
+            """dst [M, C] = conv^T(dy [M, Cdy], hidden-half / fusion_conv weights `key`) (+ residual): input transform, point GEMMs, inverse"""
+            V = co.wino_input(dy, Cdy, Cdy, b, D, H, W)
+            co.wino_gemm(V, Cdy, None, 0, UT[key], Mc, b, D, Ht, Wt, C)
+            co.wino_output(Mc, None, None, None, 1.0, residual, None, None, dst, None, None, *geo, C, C, co.EPI_BIAS)
+            return dst
+
+        def wgrad(dy, Cdy, Vin, key, n=b, rows=R):
+            """dU[key] += (A dy A^T)^T (x) Vin over the n volumes of dy"""
+            dM = newV(rows, Cdy)
+            _lib.check(L.forge_wino_dy(p(dy), Cdy, p(dM), n, D, H, W, Cdy, st()), "forge_wino_dy")
+            _lib.check(L.forge_wino_wgrad(p(dM), p(Vin), C, 0, 0, None, 0, 0, 0, p(dU[key]), n, D, Ht, Wt, Cdy, 3, st()), "forge_wino_wgrad")
+
+        dg_acc = torch.empty(b, t, D, H, W, 2 * C, dtype=torch.float32, device=dev)     # d (gate pre-activations) summed per view over the groups
+        dc_acc = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
+        seen = [False] * t
+        grads_bn = {k: None for k in ("g1", "be1", "g4", "be4", "gn", "bn")}
+        add = lambda old, g: g if old is None else old + g
+        db0 = db3 = None
+        dmeans = []
+        for gi in reversed(range(len(saved_groups))):
+            grp, Vm, sv1, Vt0, sv4, steps, svn = saved_groups[gi]
+            dout = douts[gi]
+            if dout is None:
+                dout = torch.zeros(b, C, D, H, W, dtype=torch.float32, device=dev)
+            dr = dout.permute(0, 2, 3, 4, 1)
+            dr = (dr if dr.is_contiguous() else dr.contiguous()).reshape(M, C)
+            dhn, dgn_, dbn_, _ = bn_rows_bwd(svn, dr)
+            grads_bn["gn"], grads_bn["bn"] = add(grads_bn["gn"], dgn_), add(grads_bn["bn"], dbn_)
+            for ti, h, z, r, cand, Vh, Vhr in reversed(steps):
+                mode = 2 if seen[ti] else 1
+                seen[ti] = True
+                dh, dz, dc = new(), new(), new()
+                _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, p(dc_acc[:, ti]), t * vol, vol, mode, st()),
+                           "forge_gru_state_bwd")
+                dhr = dgrad(dc, C, "oh", new())
+                wgrad(dc, C, Vhr, "oh")
+                dg = new(2 * C)
+                _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, p(dg_acc[:, ti]), t * vol, vol, mode, st()),
+                           "forge_gru_gates_bwd")
+                dhn = dgrad(dg, 2 * C, "gh", new(), residual=dh)            # dh (state + reset paths) + conv^T(dg, Wg_h)
+                wgrad(dg, 2 * C, Vh, "gh")
+            # h0 = lrelu(bn4(conv(lrelu(bn1(conv(mean))))))
+            da1, dg4, dbe4, _ = bn_rows_bwd(sv4, dhn)
+            grads_bn["g4"], grads_bn["be4"] = add(grads_bn["g4"], dg4), add(grads_bn["be4"], dbe4)
+            wgrad(da1, C, Vt0, "f3")
+            if ctx.has_bias[3]:
+                db3 = add(db3, co.colsum(da1))
+            dt0 = dgrad(da1, C, "f3", new())
+            da0, dg1, dbe1, _ = bn_rows_bwd(sv1, dt0)
+            grads_bn["g1"], grads_bn["be1"] = add(grads_bn["g1"], dg1), add(grads_bn["be1"], dbe1)
+            wgrad(da0, C, Vm, "f0")
+            if ctx.has_bias[2]:
+                db0 = add(db0, co.colsum(da0))
+            dmeans.append((grp, dgrad(da0, C, "f0", new())))
+        for ti in range(t):
+            if not seen[ti]:                                                 # a view no group uses: no gradient through the GRU input halves
+                dg_acc[:, ti].zero_()
+                dc_acc[:, ti].zero_()
+        # the shared input halves, once for all views: weight gradients against V_x, data gradient = conv^T(dg, Wg_x) + conv^T(dc, Wo_x)
+        nbt_, Rall = b * t, b * t * R1
+        wgrad(dg_acc, 2 * C, Vx, "gx", n=nbt_, rows=Rall)
+        wgrad(dc_acc, C, Vx, "ox", n=nbt_, rows=Rall)
+        dx = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
+        MA = newV(Rall, C)
+        Vg = co.wino_input(dg_acc, 2 * C, 2 * C, nbt_, D, H, W)
+        co.wino_gemm(Vg, 2 * C, None, 0, UT["gx"], MA, nbt_, D, Ht, Wt, C)
+        del Vg
+        Vc = co.wino_input(dc_acc, C, C, nbt_, D, H, W)
+        MB = newV(Rall, C)
+        co.wino_gemm(Vc, C, None, 0, UT["ox"], MB, nbt_, D, Ht, Wt, C)
+        del Vc
+        co.wino_output(MA, None, None, None, 1.0, None, None, None, dx, None, None, nbt_, D, H, W, C, C, co.EPI_BIAS, Mm2=MB, view=0, views=1)
+        for grp, dmean in dmeans:                                            # d mean / d x_ti = 1 / |group|
+            dm = dmean.reshape(b, 1, D, H, W, C)
+            if grp == list(range(grp[0], grp[0] + len(grp))):
+                dx[:, grp[0]:grp[0] + len(grp)].add_(dm, alpha=1.0 / len(grp))
+            else:
+                for ti in grp:
+                    dx[:, ti].add_(dm[:, 0], alpha=1.0 / len(grp))
+        dbg = co.colsum(dg_acc.reshape(-1, 2 * C)) if ctx.has_bias[0] else None
+        dbo = co.colsum(dc_acc.reshape(-1, C)) if ctx.has_bias[1] else None
+
+        def unpack(*keys):
+            """G^T dU G of the listed halves, concatenated along Cin, in the nn.Conv3d layout [Cout, Cin, 3, 3, 3]"""
+            parts = []
+            for k in keys:
+                dwp = torch.zeros_like(packs[k])
+                _lib.check(L.forge_wino_dw(p(dU[k]), p(dwp), dwp.shape[1], dwp.shape[2], 3, st()), "forge_wino_dw")
+                parts.append(dwp)
+            dwp = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)
+            return dwp.permute(1, 2, 0).reshape(dwp.shape[1], dwp.shape[2], 3, 3, 3)
+        need = ctx.needs_input_grad
+        return (dx.permute(0, 1, 5, 2, 3, 4) if need[0] else None, unpack("gx", "gh") if need[1] else None, dbg, unpack("ox", "oh") if need[3] else None, dbo,
+                unpack("f0") if need[5] else None, db0, grads_bn["g1"], grads_bn["be1"], unpack("f3") if need[9] else None, db3,
+                grads_bn["g4"], grads_bn["be4"], grads_bn["gn"], grads_bn["bn"], None, None)
 
 
 def gru_cell_rows(x, h, gate_weight, gate_bias, out_weight, out_bias):
@@ -730,8 +934,17 @@ class ConvGRU_3D(co.PackedModule):
         assert self.n_layers == 1 and self.input_size == self.hidden_size
         require_hip_input("ConvGRU_3D.fuse_groups_autograd_hip", x, x.shape[2])
         b, t, C, D, H, W = x.shape
-        xt = x.permute(1, 0, 3, 4, 5, 2).contiguous()                                   # [t,b,D,H,W,C]: a view's rows are dense
         cell, fc = self.cells[0], self.fusion_conv
+        bns = (fc[1], fc[4], self.fusion_norm)
+        rows_probe = x.permute(0, 1, 3, 4, 5, 2)
+        if (co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t) and co.wino_wgrad_applies(b, D, H, W, C, 0, C)
+                and all(bn_hip_train(m, rows_probe) and m.weight is not None for m in bns) and isinstance(fc[2], nn.LeakyReLU)):
+            # the training step proper (every BatchNorm on batch statistics): one hand-scheduled autograd node for all groups
+            outs = _FuseGroupsTrain.apply(x, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias,
+                                          fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, fc[4].weight, fc[4].bias,
+                                          self.fusion_norm.weight, self.fusion_norm.bias, self, tuple(tuple(g) for g in groups))
+            return list(outs)
+        xt = x.permute(1, 0, 3, 4, 5, 2).contiguous()                                   # [t,b,D,H,W,C]: a view's rows are dense
         Wg, Wo = cell.conv_gate.weight, cell.out_gate.weight
         flat = xt.reshape(t * b, D, H, W, C)
         # per-view tensors via unbind: their gradients (one per group that uses the view) are summed view-sized and stacked once

@@ -303,10 +303,14 @@ int forge_conv_direct_wgrad(const float* dy, int ld_dy, const float* x, int ld_x
  */
 int forge_gru_gates_fwd(const float* g, const float* h, float* z, float* r, float* hr, long long M, int C, forge_stream_t stream);
 int forge_gru_state_fwd(float* c_cand, const float* h, const float* z, float* hn, long long M, int C, forge_stream_t stream);
+/* dc_acc / dg_acc (acc_mode 0: unused, 1: written, 2: added to): a second copy of dc / dg for the gradient of a convolution INPUT HALF that several
+ * fusions share (model_single_pose_estimator.py:108-120 fuses views (0,1,2), (3,4), (0..4) of the same features): rows of batch element n land at
+ * acc + (n acc_bs + row within the volume of `vol` rows) x (C | 2C) floats, i.e. view ti of a [b][t] stack is acc = base + ti vol ld, acc_bs = t vol. */
 int forge_gru_state_bwd(const float* dhn, int ld_dhn, const float* h, const float* z, const float* cand, float* dh, float* dz, float* dc,
-                        long long M, int C, forge_stream_t stream);
+                        long long M, int C, float* dc_acc, long long acc_bs, long long vol, int acc_mode, forge_stream_t stream);
 int forge_gru_gates_bwd(const float* dz, const float* dhr, int ld_dhr, const float* h, const float* z, const float* r,
-                        float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, forge_stream_t stream);
+                        float* dg, float* dh, float* dh_out, int ld_dh_out, long long M, int C, float* dg_acc, long long acc_bs, long long vol,
+                        int acc_mode, forge_stream_t stream);
 
 /* Train-mode BatchNorm (+ LeakyReLU / ReLU) on channels-last rows (training path; torch.nn.BatchNorm{2,3}d(train) + activation of
  * models/fusion.py:49-58, models/encoder.py:16-40, models/volume_render.py:29-37 and the torchvision bottlenecks):

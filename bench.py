@@ -709,7 +709,7 @@ def extra_configs(dev, steps=5):
     holder.clear()
     # --- one GT-pose training step (configs[3] per-GPU step at the reference-native 32^3 / 64^3 grids): forward + backward + clip + Adam, eager
     m3 = m3.train()
-    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=1e-4)
+    opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=1e-4, fused=True)     # torch's multi-tensor Adam: same update, one launch chain
 
     def train_step():
         imgs, masks = m3(s1, ds, dev)
@@ -812,7 +812,7 @@ def train_bench(args, rank, world, dev, affinity):
         if world > 1:
             model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
             model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)     # kubric_train_pose_3D.py:124
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.train.lr)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg.train.lr, fused=True)
         sample = {k: v.to(dev) for k, v in syn.make_sample(B, T_IN, 256, 1.5, seed=1000 + rank).items()}
         ds = syn.SyntheticDataset(1.5)
 

@@ -26,6 +26,8 @@ def _taps_array(taps):
 
 
 TAPS_3x3x3 = [(kz - 1, ky - 1, kx - 1) for kz in range(3) for ky in range(3) for kx in range(3)]
+TAPS_3x3 = [(0, ky - 1, kx - 1) for ky in range(3) for kx in range(3)]        # a 2-D 3x3 convolution on a D = 1 grid (ResNet bottleneck conv2)
+WINO2D_MIN_C = 256                  # 2-D Winograd (one "depth" tap, K = Cin per point) from this channel count: ResNet layer3 / layer4 (inference sweep, TUNING_LOG)
 
 
 def pack_conv3d_weight(w):
@@ -325,21 +327,23 @@ def conv3_launch(x1, C1, x2, C2, wp, bias, out, grid, Cout, bs1=0, residual=None
                       epilogue=EPI_AFFINE_ACT, bs1=bs1)
 
 
-def wino_wgrad_applies(n, D, H, W, C1, C2, Cout):
+def wino_wgrad_applies(n, D, H, W, C1, C2, Cout, taps=None):
     """The Winograd weight gradient runs on the 128-wide tiles of the wgrad kernel: wide layers only (with two inputs its Cin tiles must
     not straddle them: C1 a multiple of 128)."""
-    return (wino_applies(TAPS_3x3x3, 1, n, D, H, W, C1, C2, Cout) and C1 + C2 >= 128 and Cout >= 64 and (C2 == 0 or C1 % 128 == 0)
+    return (wino_applies(TAPS_3x3x3 if taps is None else taps, 1, n, D, H, W, C1, C2, Cout) and C1 + C2 >= 128 and Cout >= 64 and (C2 == 0 or C1 % 128 == 0)
             and n * D * (H // 2) * (W // 2) * Cout * 4 <= MAX_OPERAND_BYTES)
 
 
 @_lib.on_tensor_device
-def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0):
-    """dwp [27][Cout][C1+C2] (zero-filled by the caller) += the weight gradient of conv3x3x3(cat(x1, x2)) for the upstream gradient dy
-    [rows][Cout]. Wide layers take the Winograd form - dMm = A dy A^T, dU[p] = dMm[p]^T (x) V[p] as 16 batched problems of the wgrad
+def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None):
+    """dwp [27 | 9][Cout][C1+C2] (zero-filled by the caller) += the weight gradient of conv3x3x3 / conv3x3 (cat(x1, x2)) for the upstream gradient
+    dy [rows][Cout]. Wide layers take the Winograd form - dMm = A dy A^T, dU[p] = dMm[p]^T (x) V[p] as 16 batched problems of the wgrad
     GEMM kernel (2.25x fewer FLOPs), dw = G^T dU G - the others the direct kernel (conv_wgrad)."""
     n, D, H, W = grid
-    if not wino_wgrad_applies(n, D, H, W, C1, C2, Cout):
-        return conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, (D, H, W), Cout, TAPS_3x3x3, bs1=bs1)
+    taps = TAPS_3x3x3 if taps is None else list(taps)
+    if not wino_wgrad_applies(n, D, H, W, C1, C2, Cout, taps):
+        return conv_wgrad(dy, x1, C1, x2, C2, dwp, grid, (D, H, W), Cout, taps, bs1=bs1)
+    kd = len(taps) // 9
     L, st = _lib.lib(), _lib.current_stream()
     Ht, Wt = H // 2, W // 2
     R = n * D * Ht * Wt
@@ -348,18 +352,25 @@ def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0):
     V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
     dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
     _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
-    dU = torch.zeros(16, 3, Cout, C1 + C2, dtype=torch.float32, device=dev)
-    _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, 3, st), "forge_wino_wgrad")
-    _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, 3, st), "forge_wino_dw")
+    dU = torch.zeros(16, kd, Cout, C1 + C2, dtype=torch.float32, device=dev)
+    _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, kd, st), "forge_wino_wgrad")
+    _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, kd, st), "forge_wino_dw")
     return dwp
 
 
 def wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
     """Stride-1 3x3x3 problems with GEMM-sized channel counts take the Winograd launches: K = 3 Cin per point must amortise the GEMM
     prologue (measured, tools/wino_gemm_sweep.py: conv1's Cin = 64 -> 128 still runs at 95 TF of MFMA work = 214 TF direct-equivalent
-    against 120 TF on the direct kernel); narrower layers (the heads' 32 -> 16 / 8) stay on the direct kernels."""
-    return (wino_enabled() and istride == 1 and len(taps) == 27 and tuple(tuple(t) for t in taps) == tuple(TAPS_3x3x3) and C1 % 32 == 0 and C2 % 32 == 0
-            and C1 + C2 >= 64 and Cout >= 32 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1)))
+    against 120 TF on the direct kernel); narrower layers (the heads' 32 -> 16 / 8) stay on the direct kernels. 2-D 3x3 convolutions on a
+    D = 1 grid (one depth tap, K = Cin per point) from WINO2D_MIN_C channels: the bottleneck conv2 of ResNet layer3 / layer4."""
+    tt = tuple(tuple(t) for t in taps)
+    if not (wino_enabled() and istride == 1 and C1 % 32 == 0 and C2 % 32 == 0 and Cout % 8 == 0 and wino_fits(n, D, H, W, max(C1, C2, 1))):
+        return False
+    if len(tt) == 27 and tt == tuple(TAPS_3x3x3):
+        return C1 + C2 >= 64 and Cout >= 32
+    if len(tt) == 9 and tt == tuple(TAPS_3x3) and D == 1:
+        return C2 == 0 and C1 >= WINO2D_MIN_C and Cout >= WINO2D_MIN_C
+    return False
 
 
 def wino_enabled():
@@ -580,13 +591,60 @@ class _ConvTapsRows(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             dwp = torch.zeros_like(wp)
             if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout) and (x2 is None or _batch_stride_rows(x2) == 0):
-                conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1))
+                conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1), taps=taps)
             else:
                 conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
                            bs2=0 if x2 is None else _batch_stride_rows(x2))
         if has_bias and ctx.needs_input_grad[3]:
             db = colsum(dy.reshape(-1, Cout))
         return dx1, dx2, dwp, db, None, None, None
+
+
+class _Conv1x1RowsSkip(torch.autograd.Function):
+    """y = x @ w^T (a 1x1 stride-1 convolution without bias on NHWC rows) that ALSO hands its input through as a second output: the first
+    convolution of a ResNet bottleneck, whose input feeds the identity path (or the downsample convolution) as well. Autograd then delivers
+    the gradient of that second use to THIS node, and the data-gradient GEMM adds it in its epilogue (residual operand) - instead of a
+    separate element-wise accumulation of two activation-sized gradients per block (torchvision Bottleneck.forward: out += identity)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        N, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        wp = w.detach().reshape(1, Cout, Cin).contiguous()
+        out = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
+        conv_igemm(x, Cin, Cin, None, 0, 0, wp, None, None, None, 1.0, None, None, None, out, None, (N, 1, H, W), (1, H, W), Cout, Cout, [(0, 0, 0)],
+                   epilogue=EPI_BIAS)
+        ctx.save_for_backward(x, wp)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, wp = ctx.saved_tensors
+        N, H, W, Cin = x.shape
+        Cout = wp.shape[1]
+        dy = dy.contiguous()
+        dx = dw = None
+        grid, ig, T1 = (N, 1, H, W), (1, H, W), [(0, 0, 0)]
+        if ctx.needs_input_grad[0]:
+            wd = wp.transpose(1, 2).contiguous()                               # [1][Cin][Cout]
+            dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dy.device)
+            if dskip is None:
+                conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, grid, ig, Cin, Cin, T1, epilogue=EPI_BIAS)
+            else:
+                one, zero = _one_zero(dy.device, Cin)
+                conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, one, zero, 1.0, dskip.contiguous(), None, None, dx, None, grid, ig, Cin, Cin, T1,
+                           epilogue=EPI_AFFINE_ACT)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros_like(wp)
+            conv_wgrad(dy.reshape(N, 1, H, W, Cout), x.reshape(N, 1, H, W, Cin), Cin, None, 0, dwp, grid, ig, Cout, T1)
+            dw = dwp.reshape(Cout, Cin, 1, 1)
+        return dx, dw
+
+
+def conv1x1_rows_skip(x, weight):
+    """(conv1x1(x, weight), x) on NHWC rows [N,H,W,Cin] with autograd; weight [Cout,Cin,1,1], Cin and Cout multiples of 32. Use the returned
+    alias of x for every OTHER consumer of x: its gradient is then added inside this convolution's data-gradient GEMM."""
+    return _Conv1x1RowsSkip.apply(x, weight)
 
 
 def conv_taps_rows(x1, x2, wp, bias, taps, istride=1, out_spatial=None):

@@ -255,11 +255,12 @@ class Encoder3D(co.PackedModule):
         x = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         for li in (4, 5, 6, 7):
             for blk in fe[li]:
-                idn = x
-                out = self._bn2d_rows(blk.bn1, co.conv2d_rows(x, blk.conv1.weight, None))
+                # conv1 hands its input through: the gradients of the identity / downsample path are added inside conv1's data-gradient GEMM
+                y1, idn = co.conv1x1_rows_skip(x, blk.conv1.weight)
+                out = self._bn2d_rows(blk.bn1, y1)
                 out = self._bn2d_rows(blk.bn2, co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0]))
                 if blk.downsample is not None:
-                    idn = self._bn2d_rows(blk.downsample[1], co.conv2d_rows(x, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0]),
+                    idn = self._bn2d_rows(blk.downsample[1], co.conv2d_rows(idn, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0]),
                                           relu=False)
                 # relu(bn3(conv3) + identity) in bn3's apply pass (and its mask / d identity in bn3's backward apply pass)
                 x = bn_act_rows(blk.bn3, co.conv2d_rows(out, blk.conv3.weight, None), 0.0, residual=idn)

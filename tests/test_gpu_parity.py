@@ -998,6 +998,34 @@ def test_conv2d_rows_strided_autograd_vs_torch(dev):
         assert (wd.grad.cpu() - wa.grad).abs().max().item() < 1e-4 * wa.grad.abs().max().item(), tag
 
 
+def test_conv2d_rows_winograd_2d_training_path_vs_float64(dev):
+    """The bottleneck conv2 of ResNet layer3 / layer4 in TRAINING (3x3, stride 1, 256 / 512 channels at 32 x 32): forward, data gradient and
+    weight gradient take the 2-D Winograd launches (one depth tap, convops.wino_applies) - against torch's float64 convolution, and against
+    the direct kernels (convops.winograd(False)) as the fp32 yard-stick; a narrower layer stays on the direct kernels (same results path)."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(31)
+    for C, hw in ((256, 32), (512, 16), (128, 16)):
+        x = torch.randn(3, C, hw, hw, generator=g)
+        w = torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5
+        xa, wa = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        ref = torch.nn.functional.conv2d(xa, wa, None, stride=1, padding=1)
+        gy = torch.randn(ref.shape, generator=g)
+        ref.backward(gy.double())
+        assert co.wino_applies(co.TAPS_3x3, 1, 3, 1, hw, hw, C, 0, C) == (C >= co.WINO2D_MIN_C)
+        res = {}
+        for wino in (True, False):
+            with co.winograd(wino):
+                xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+                wd = w.to(dev).requires_grad_(True)
+                out = co.conv2d_rows(xd, wd, None)
+                out.backward(gy.permute(0, 2, 3, 1).contiguous().to(dev))
+            res[wino] = (out.detach().permute(0, 3, 1, 2).cpu().double(), xd.grad.permute(0, 3, 1, 2).cpu().double(), wd.grad.cpu().double())
+        for i, r64 in enumerate((ref.detach(), xa.grad, wa.grad)):
+            ew, ed = (res[True][i] - r64).abs().max().item(), (res[False][i] - r64).abs().max().item()
+            scale = r64.abs().max().item()
+            assert ed < 2e-5 * scale and ew < 6e-5 * scale, (C, i, ew / scale, ed / scale)      # Winograd: <= ~3x the direct kernel's fp32 error
+
+
 def test_get_feat3D_train_hip_vs_oracle(dev):
     """Encoder (ResNet trunk + lift + conv1) in TRAIN mode through the HIP convs: output and a few gradients vs the oracle autograd."""
     from forge_amd.encoder import Encoder3D

@@ -22,7 +22,7 @@ model = FORGE_poseEstimator3D(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).train()
 use_graph = os.environ.get("TRAIN_GRAPH", "0") == "1"       # capture fwd + bwd + clip + Adam into one hipGraph (forge_amd.graph.GraphedStep)
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=use_graph)
+opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4, capturable=use_graph, fused=not use_graph)
 sample = {k: v.to(dev) for k, v in syn.make_sample(b, 5, 256, 1.5, seed=3).items()}
 ds = syn.SyntheticDataset(1.5)
 from forge_amd import geo_utils  # noqa: E402

@@ -362,8 +362,8 @@ def test_conv_launcher_batch_chunking_is_exact(dev, monkeypatch):
 def test_training_loss_and_gradients_vs_oracle_autograd(dev):
     """End-to-end pin of the TRAINING path: FORGE_poseEstimator3D in train mode (BatchNorm batch statistics, three fusions, heads
     batched as the reference batches them), loss = 5 MSE(rgb) + MSE(mask), against autograd through the CPU oracle (training=True) on
-    the same sample and weights: loss value, and the gradient of parameters from every stage. Stated tolerance: 1e-2 of each
-    gradient's max magnitude (~150 layers of fp32 forward + backward, fp32 atomics in the weight-gradient kernels)."""
+    the same sample and weights: loss value, and the gradient of parameters from every stage. Stated tolerance: 1e-2 of each gradient's max
+    magnitude (1.5e-2 on the ResNet trunk's parameters) and a per-layer cosine >= 0.99995 - see test_training_gradients_vs_reference_golden."""
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
     cfg = syn.kubric_config()
     model = FORGE_poseEstimator3D(cfg)
@@ -390,12 +390,11 @@ def test_training_loss_and_gradients_vs_oracle_autograd(dev):
     for k in keys:
         ref, got = wo[k].grad, named[k].grad.cpu()
         err = (got - ref).abs().max().item()
-        # 3e-2 of the gradient's max, as in test_training_gradients_vs_reference_golden: two fp32 evaluations of this graph (the oracle's and
-        # any kernel family's) sit 0.3-1.6e-2 apart on the trunk's parameter gradients (tools/debug/feat3d_train_noise.py, float64 yardstick)
-        assert err < 3e-2 * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
+        tol = 1.5e-2 if "feature_extraction" in k else 1e-2       # as in test_training_gradients_vs_reference_golden
+        assert err < tol * ref.abs().max().item() + 1e-9, (k, err, ref.abs().max().item())
         if ref.numel() > 1:                          # per-layer direction check (see test_training_gradients_vs_reference_golden)
             cos = torch.nn.functional.cosine_similarity(got.double().flatten(), ref.double().flatten(), dim=0).item()
-            assert cos > 0.9999, (k, cos)
+            assert cos > 0.99995, (k, cos)
 
 
 def test_training_gradients_vs_reference_golden(dev, golden):
@@ -421,16 +420,19 @@ def test_training_gradients_vs_reference_golden(dev, golden):
     for k in keys:
         ref = torch.from_numpy(gold["grad__" + k])
         err = (named[k].grad.cpu() - ref).abs().max().item()
-        # 3e-2 of the gradient's max: the reference's own fp32 gradients sit 0.3-1.6e-2 from a float64 evaluation of the same graph (53
-        # train-mode BatchNorm layers over a batch of 5 amplify reordering noise, a ReLU argument at rounding distance of zero flips whole
-        # gradient entries; tools/debug/feat3d_train_noise.py measures fp32 oracle / direct kernels / Winograd against float64)
-        assert err < 3e-2 * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
-        # direction check per layer: a max-norm band of 3 % cannot see a gradient that is wrong by a few percent everywhere, the
-        # cosine can (0.9999 <=> 1.4 % relative L2); single flipped entries cost little here. Tensors whose gradient is pure cancellation noise
-        # (|g| < 1e-3 of the largest gradient) are not direction-checked.
+        # Round 4: the step's own run-to-run distance is now <= 1.1e-6 of each gradient's max (the ray-march backward is a deterministic gather;
+        # what is left are the fp32 atomics of the weight-gradient split-K: tools/debug/train_grad_margins.py), so the bound is no longer a noise
+        # floor of this build but the distance between two fp32 evaluations of the graph: measured against this golden 2.4e-4 ... 2.9e-3 outside
+        # the trunk, 6.6e-3 / 1.2e-2 on the trunk's first convolution / last BatchNorm weight - where the reference's own fp32 gradients sit
+        # 0.3-1.6e-2 from a float64 evaluation (53 train-mode BatchNorm layers over a batch of 5; tools/debug/feat3d_train_noise.py).
+        tol = 1.5e-2 if "feature_extraction" in k else 1e-2
+        assert err < tol * max(ref.abs().max().item(), 1e-3 * gscale), (k, err, ref.abs().max().item())
+        # direction check per layer: a max-norm band cannot see a gradient that is wrong by a percent everywhere, the cosine can
+        # (0.99995 <=> 1 % relative L2; measured 1 - cos <= 3.8e-5). Tensors whose gradient is pure cancellation noise (|g| < 1e-3 of the
+        # largest gradient: biases in front of a BatchNorm) are not direction-checked.
         if ref.numel() > 1 and ref.abs().max().item() > 1e-3 * gscale:
             cos = torch.nn.functional.cosine_similarity(named[k].grad.cpu().double().flatten(), ref.double().flatten(), dim=0).item()
-            assert cos > 0.9999, (k, cos)
+            assert cos > 0.99995, (k, cos)
 
 
 def test_training_step_runs(dev):

@@ -289,6 +289,54 @@ def physical_cores():
     return max(1, min(n, allowed)), allowed
 
 
+def cpu_quota_cores():
+    """CPU-time budget of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable. The GPU boxes of
+    this pool list 256 hardware threads but run the job under `cpu.max = 1600000 100000` = 16 cores: more runnable threads than that are
+    throttled, which is what made round 3's 8 x 16-thread leg take 8x longer per forward than one process (tools/cpu_quota_probe.py)."""
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()
+        if a != "max":
+            return float(a) / float(b)
+    except Exception:
+        pass
+    try:
+        q, p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / float(p_)
+    except Exception:
+        pass
+    return None
+
+
+def _spin(seconds, q):
+    t0, n, x = time.perf_counter(), 0, 1
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20000):
+            x = (x * 1103515245 + 12345) & 0x7fffffff
+        n += 20000
+    q.put(n)
+
+
+def effective_parallelism(ks, seconds=0.5):
+    """Aggregate rate of k single-thread spin loops relative to one: what the scheduler really grants this container (a plateau = the quota)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    out, base = {}, None
+    for k in ks:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_spin, args=(seconds, q)) for _ in range(k)]
+        t0 = time.perf_counter()
+        for p_ in ps:
+            p_.start()
+        tot = sum(q.get() for _ in ps)
+        for p_ in ps:
+            p_.join()
+        rate = tot / (time.perf_counter() - t0)
+        base = base or rate
+        out[str(k)] = round(rate / base, 2)
+    return out
+
+
 def _cpu_forward_fn(seed, threads):
     """(run, ref-holder) of one oracle hot-path forward of ONE seeded scene on `threads` torch-CPU threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -356,7 +404,10 @@ def cpu_baseline(sample, weights, cfg):
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import forge_oracle as fo
-    phys, hw = physical_cores()
+    phys_listed, hw = physical_cores()
+    quota = cpu_quota_cores()
+    # the cores this job can actually USE: the cgroup CPU-time quota when there is one (threads beyond it are throttled, not run)
+    phys = max(1, min(phys_listed, int(quota))) if quota else phys_listed
     one = {k: v[:1].cpu() for k, v in sample.items()}
 
     def run():
@@ -364,7 +415,7 @@ def cpu_baseline(sample, weights, cfg):
             return fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN],
                                        one["cam_extrinsics_cv2_canonicalized"][:, :T_IN], one["K_cv2"][:, :T_IN],
                                        weights, cfg, order_by_distance=True)
-    cands = sorted({c for c in (8, 16, 32, 64, phys) if 1 <= c <= phys})
+    cands = sorted({c for c in (4, 8, 16, 32, 64, phys) if 1 <= c <= phys})
     sweep, ref = {}, None
     for nt in cands:
         torch.set_num_threads(nt)
@@ -387,10 +438,10 @@ def cpu_baseline(sample, weights, cfg):
         run()
         times.append(time.time() - t0)
     single = {"threads": best_nt, "timed_forwards": 5, "s_per_forward": sum(times) / 5, "views_per_s": V_OUT * 5 / sum(times)}
-    # scene-parallel over all physical cores
-    tpp = min(16, phys)
+    # scene-parallel over all USABLE cores: processes x threads = the budget (8 threads per process: the oracle's convolutions scale to ~8)
+    tpp = min(8, phys)
     nproc = max(1, phys // tpp)
-    nfw = 1
+    nfw = 2
     par = None
     try:
         sets = core_sets(nproc, tpp)                 # each process pinned to its own 16 physical cores (one socket, no SMT siblings)
@@ -431,7 +482,15 @@ def cpu_baseline(sample, weights, cfg):
         lscpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": value, "unit": "views/s", "cores": cores, "physical_cores": phys, "host_hw_threads": hw, "cpu_model": lscpu, "kind": "port",
+    try:
+        eff = effective_parallelism([1, 8, 16, 32] if hw >= 32 else [1, max(1, hw // 2), hw])
+    except Exception as e:
+        eff = {"error": repr(e)}
+    return {"value": value, "unit": "views/s", "cores": cores, "physical_cores": phys_listed, "usable_cores": phys, "cgroup_cpu_quota_cores": quota,
+            "host_hw_threads": hw, "effective_parallelism": eff, "cpu_model": lscpu, "kind": "port",
+            "note": "cores = the threads that produced `value`. The box lists %d physical cores / %d hardware threads, but the job runs under a cgroup "
+                    "CPU-time quota of %s cores (effective_parallelism: aggregate rate of k spin loops / one - it plateaus at the quota), so the "
+                    "baseline is sized to the quota; a leg with more runnable threads than that is throttled, not faster" % (phys_listed, hw, quota),
             "sample": "oracle hot path, 1 scene per forward (5x256^2 in, 32^3/64^3 grids, 5x128^2x64 rays out), torch-CPU fp32; "
                       "thread sweep %s; single process: 1 warm-up + 5 timed forwards at %d threads; scene-parallel: %s"
                       % (sorted(sweep), best_nt, ("%d processes x %d threads, 1 warm-up + %d timed forwards each" % (nproc, tpp, nfw))),

@@ -345,6 +345,122 @@ __global__ __launch_bounds__(256) void conv_wgrad_lines_kernel(const WgradArgs a
     }
 }
 
+// The same for Cout <= 16 on the 16x16x4 fp32 MFMA (A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[row = 4 (l >> 4) + r][col = l & 15]):
+// the 32-row tile of the kernel above executes 2x (Cout = 16: the features head's 32 -> 16) to 4x (Cout = 8: the density head's 32 -> 8,
+// conv_rgb's 16 -> 8) the useful matrix work. CIT = 32: the Cin tile is two 16-column MFMAs fed by ONE 8-byte LDS read per lane (even / odd
+// input channel); CIT = 16: one MFMA. dYs rows are 16 floats, so the four voxel rows a wave-instruction reads fall into disjoint banks.
+typedef __attribute__((ext_vector_type(4))) float f32x4w;
+
+template <int CIT>
+__global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_kernel(const WgradArgs a, const LineTable lt) {
+    constexpr int NT = CIT / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // dYs [LSEG][16] | Xs [nlines][LSEG + 2 rx][CIT]
+    float* dYs = smem;
+    float* Xs = smem + LSEG * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int Cin = a.C1, xrows = LSEG + 2 * lt.rx;
+    const int nsx = (a.W + LSEG - 1) / LSEG;
+    const long long nseg = (long long)a.n * a.D * a.H * nsx;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, (int)a.span1, 0x00020000);
+    // staging: one float4 per thread per pass; CIT / 4 threads per X row (4 per dY row: threads 0..127 stage the 32 dY rows)
+    constexpr int TPR = CIT / 4, RPP = 256 / TPR;                    // threads per row, rows per pass
+    const int c4 = (tid % TPR) << 2, srow = tid / TPR;
+    const int yc4 = (tid & 3) << 2, yrow = tid >> 2;
+    const int xchunks = lt.nlines * xrows;
+    constexpr int XP = (LMAXL * LROWS + RPP - 1) / RPP;
+    float4 ry4 = make_float4(0.f, 0.f, 0.f, 0.f), rx4[XP];
+    auto load_seg = [&](long long sg) {
+        long long q = sg;
+        const int sx = (int)(q % nsx); q /= nsx;
+        const int y = (int)(q % a.H); q /= a.H;
+        const int z = (int)(q % a.D); q /= a.D;
+        const int nn = (int)q, x0 = sx * LSEG;
+        if (yrow < LSEG) {
+            const int x = x0 + yrow;
+            const long long m = (((long long)nn * a.D + z) * a.H + y) * a.W + x;
+            ry4 = buf_load16w(ry, (x < a.W && yc4 < a.Cout) ? (unsigned)((m * a.ldy + yc4) * 4) : OOBW);
+        }
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int r = srow + RPP * p;
+            unsigned off = OOBW;
+            if (r < xchunks && c4 < Cin) {
+                const int ln = r / xrows, xr = r - ln * xrows;
+                const int zi = z + lt.dz[ln], yi = y + lt.dy[ln], xi = x0 - lt.rx + xr;
+                if ((unsigned)zi < (unsigned)a.D && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
+                    off = (unsigned)((((long long)nn * a.bs1r + ((long long)zi * a.H + yi) * a.W + xi) * a.ld1 + c4) * 4);
+            }
+            rx4[p] = buf_load16w(rx_, off);
+        }
+    };
+    auto store_seg = [&]() {
+        if (yrow < LSEG) *reinterpret_cast<float4*>(dYs + yrow * 16 + yc4) = ry4;
+#pragma unroll
+        for (int p = 0; p < XP; ++p) {
+            const int r = srow + RPP * p;
+            if (r < xchunks) *reinterpret_cast<float4*>(Xs + r * CIT + c4) = rx4[p];
+        }
+    };
+    int tb[LTAPS];
+    bool tok[LTAPS];
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j) {
+        const int t = wave + 4 * j;
+        tok[j] = t < a.ntaps;
+        const int tt = tok[j] ? t : 0;
+        tb[j] = (a.tap[tt][3] * xrows + a.tap[tt][2] + lt.rx) * CIT;  // (line, dx + rx)
+    }
+    f32x4w acc[LTAPS][NT];
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][n][r] = 0.f;
+
+    long long sg = blockIdx.x;
+    if (sg < nseg) load_seg(sg);
+    for (; sg < nseg; sg += gridDim.x) {
+        __syncthreads();
+        store_seg();
+        __syncthreads();
+        if (sg + gridDim.x < nseg) load_seg(sg + gridDim.x);
+#pragma unroll 4
+        for (int k = 0; k < LSEG / 4; ++k) {
+            const int row = 4 * k + kq;
+            const float fa = dYs[row * 16 + l15];
+#pragma unroll
+            for (int j = 0; j < LTAPS; ++j) {
+                if (!tok[j]) continue;                               // wave-uniform
+                if constexpr (NT == 2) {
+                    const float2 fb = *reinterpret_cast<const float2*>(Xs + tb[j] + row * CIT + 2 * l15);     // input channels 2 l15, 2 l15 + 1
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb.x, acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb.y, acc[j][1], 0, 0, 0);
+                } else {
+                    const float fb = Xs[tb[j] + row * CIT + l15];
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[j][0], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LTAPS; ++j) {
+        if (!tok[j]) continue;
+        const int t = wave + 4 * j;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ci = NT == 2 ? 2 * l15 + n : l15;
+            if (ci >= Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * kq + r;
+                if (co < a.Cout && acc[j][n][r] != 0.f) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[j][n][r]);
+            }
+        }
+    }
+}
+
 }  // namespace forge
 
 using namespace forge;
@@ -436,8 +552,23 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
             const long long nseg = (long long)n * D * H * ((W + LSEG - 1) / LSEG);
             const size_t lds = (size_t)(LSEG * 32 + lt.nlines * (LSEG + 2 * lt.rx) * 32) * sizeof(float);
             FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines_kernel, (LSEG * 32 + LMAXL * LROWS * 32) * sizeof(float));
-            const long long grid = nseg < 512 ? nseg : 512;          // 2 workgroups per CU (244 VGPRs), each walking its share of the segments
             a.mchunk = 0;
+            if (Cout <= 16) {
+                // narrow outputs: the 16x16x4 MFMA tile (no 32-row padding); 4 workgroups per CU walk the segments
+                const int cit = Cin <= 16 ? 16 : 32;
+                const size_t lds16 = (size_t)(LSEG * 16 + lt.nlines * (LSEG + 2 * lt.rx) * cit) * sizeof(float);
+                const long long grid16 = nseg < (cit == 16 ? 1024 : 768) ? nseg : (cit == 16 ? 1024 : 768);    // 4 / 3 resident workgroups per CU (108 / ~150 VGPRs)
+                if (cit == 16) {
+                    FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines16_kernel<16>, (LSEG * 16 + LMAXL * LROWS * 16) * sizeof(float));
+                    hipLaunchKernelGGL(conv_wgrad_lines16_kernel<16>, dim3((unsigned)grid16), dim3(256), lds16, (hipStream_t)stream, a, lt);
+                } else {
+                    FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines16_kernel<32>, (LSEG * 16 + LMAXL * LROWS * 32) * sizeof(float));
+                    hipLaunchKernelGGL(conv_wgrad_lines16_kernel<32>, dim3((unsigned)grid16), dim3(256), lds16, (hipStream_t)stream, a, lt);
+                }
+                FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+                return 0;
+            }
+            const long long grid = nseg < 512 ? nseg : 512;          // 2 workgroups per CU (244 VGPRs), each walking its share of the segments
             hipLaunchKernelGGL(conv_wgrad_lines_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a, lt);
             FORGE_LAUNCH_CHECK("forge_conv_wgrad");
             return 0;

@@ -237,8 +237,8 @@ def _spawn2(target, args=(), timeout=420):
 RAY_KEYS = ["conv_rgb.0.weight", "conv_rgb.3.weight", "conv_rgb.6.weight", "conv_rgb.6.bias"]
 
 
-def _ray_bwd_case(dev, ray_shard):
-    """VolRender (seeded conv_rgb, eval-mode BatchNorm, trainable weights) on a 64^3 blob volume, 4 cameras: loss of the RGB / mask / depth
+def _ray_bwd_case(dev, ray_shard, D=64, reduce="all"):
+    """VolRender (seeded conv_rgb, eval-mode BatchNorm, trainable weights) on a D^3 blob volume, 4 cameras: loss of the RGB / mask / depth
     maps against fixed random targets, gradients w.r.t. the feature volume, the density, R / T of the cameras and conv_rgb's weights."""
     from forge_amd import synthetic as syn
     from forge_amd.volume_render import VolRender
@@ -247,8 +247,8 @@ def _ray_bwd_case(dev, ray_shard):
     pre = "render."
     vr.load_state_dict({k[len(pre):]: v for k, v in syn.seeded_state_dict({pre + k: v for k, v in vr.state_dict().items()}, 4).items()})
     vr = vr.to(dev).eval()
-    vr.ray_shard = ray_shard
-    feat, dens = syn.blob_volumes(1, 64, 16, seed=5)
+    vr.ray_shard, vr.ray_shard_reduce = ray_shard, reduce
+    feat, dens = syn.blob_volumes(1, D, 16, seed=5)
     feat, dens = feat.to(dev).requires_grad_(True), dens.to(dev).requires_grad_(True)
     _, extr, _ = syn.orbit_cameras(10, 1.5, 15.0)
     E = extr[[0, 3, 5, 8]].to(dev)
@@ -266,16 +266,22 @@ def _ray_bwd_case(dev, ray_shard):
     return float(loss.detach()), {k: v.detach().float().cpu().numpy() for k, v in grads.items()}, rgb.detach().cpu().numpy()
 
 
-def _ray_bwd_worker(rank, world, port, q):
+def _ray_bwd_worker(rank, world, port, q, D=64, reduce="all"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd
     fd.init()
     dev = torch.device("cuda", torch.cuda.current_device())
-    q.put((rank, _ray_bwd_case(dev, True)))
+    loss, g, rgb = _ray_bwd_case(dev, True, D, reduce)
+    if D > 64:                                      # 128^3: the volume gradients are 134 + 8 MB per rank - ship a strided sample and float64 checksums
+        g = {k: ((v[:, :, ::3, ::3, ::3].copy(), float(v.astype("float64").sum()), float((v.astype("float64") ** 2).sum())) if v.ndim == 5 else v)
+             for k, v in g.items()}
+    q.put((rank, (loss, g, rgb)))
     dist.barrier()
     dist.destroy_process_group()
+
+
 
 
 def test_ray_sharded_render_backward_two_ranks_on_the_gpu():
@@ -293,6 +299,43 @@ def test_ray_sharded_render_backward_two_ranks_on_the_gpu():
         for k, ref in ref_g.items():
             err = float(np.abs(g[k] - ref).max())
             assert err <= 1e-5 * max(float(np.abs(ref).max()), 1e-12) + 1e-12, (r, k, err, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("reduce", ["all", "none"])
+def test_ray_sharded_render_backward_128cube_volume_two_ranks(reduce):
+    """BASELINE configs[4]'s volume size: the ray-sharded backward on a 128^3 render volume (142.6 MB of d(volume) per
+    rank: the all-reduce payload of reduce="all"), two ranks sharing the GPU over gloo, against the single-process backward - loss 1e-6, the
+    camera / conv_rgb gradients and a strided sample + float64 checksums of the volume gradients at 1e-5 of each gradient's max.
+    reduce="none" (the partials stay on the ranks for dist.broadcast_from_owner's reduce-to-owner): the two ranks' partials SUM to the
+    single-process gradient."""
+    import numpy as np
+    res = _spawn2(_ray_bwd_worker, args=(128, reduce), timeout=600)
+    ref_loss, ref_g, ref_rgb = _ray_bwd_case(torch.device("cuda:0"), False, 128)
+    part = ("feat", "dens", "R", "T")                # what the band backward produces (partial under reduce="none")
+    for r in (0, 1):
+        loss, g, rgb = res[r]
+        assert np.array_equal(rgb, ref_rgb), r
+        assert abs(loss - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss))
+    for k, ref in ref_g.items():
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        vals = [res[r][1][k] for r in (0, 1)]
+        if ref.ndim == 5:                            # volume gradients: (strided sample, sum, sum of squares)
+            sub = ref[:, :, ::3, ::3, ::3]
+            s1, s2 = float(ref.astype("float64").sum()), float((ref.astype("float64") ** 2).sum())
+            if reduce == "none":
+                got = vals[0][0] + vals[1][0]
+                assert float(np.abs(got - sub).max()) <= 1e-5 * scale, (k, "sample of the summed partials")
+                assert abs(vals[0][1] + vals[1][1] - s1) <= 1e-5 * scale * ref.size ** 0.5 + 1e-9, (k, "checksum")
+                assert abs(vals[0][1]) > 0 and abs(vals[1][1]) > 0, (k, "both bands contribute")
+            else:
+                for r in (0, 1):
+                    assert float(np.abs(vals[r][0] - sub).max()) <= 1e-5 * scale, (r, k)
+                    assert abs(vals[r][1] - s1) <= 1e-5 * scale * ref.size ** 0.5 + 1e-9 and abs(vals[r][2] - s2) <= 1e-4 * s2 + 1e-12, (r, k, "checksums")
+        elif k in part and reduce == "none":
+            assert float(np.abs(vals[0] + vals[1] - ref).max()) <= 1e-5 * scale + 1e-12, (k, "summed camera partials")
+        else:
+            for r in (0, 1):
+                assert float(np.abs(vals[r] - ref).max()) <= 1e-5 * scale + 1e-12, (r, k)
 
 
 JOINT_KEYS = ["pose_head.4.weight", "encoder_traj.pose_head_1.3.weight", "encoder_3d.conv1.0.weight", "encoder_3d.fusion_feature.cells.0.out_gate.weight",

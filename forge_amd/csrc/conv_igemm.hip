@@ -954,7 +954,8 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
 // is the 64x128 tile on every shape of the step (gates 129 TF against 127 / 122 for 128x128 / 64x64; state 128 / 125 / 121; conv1 102 / 98 / 93);
 // the 2-D trunk's tiny launches want many small workgroups. forge_wino_gemm's `tile` argument overrides it (that tool).
 extern "C" int forge_wino_gemm_tile(long long R, int Cout, int Cin) {
-    (void)Cout; (void)Cin;
+    (void)Cin;
+    if (Cout <= 64) return R < 2048 ? 'D' : 'C';               // a 64-wide output (conv1's data gradient, 128 -> 64) would leave half of a 64x128 tile's columns empty
     return R < 2048 ? 'D' : 'B';                                // R < 2048: the 2-D trunk's layer3/4 (R = 320 / 80)
 }
 

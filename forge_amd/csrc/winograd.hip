@@ -32,7 +32,9 @@ struct WinoInArgs {
 // one thread = one tile x 4 channels: 16 float4 loads (zero outside the grid), 32 float4 additions, 16 float4 stores
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     const int C4 = a.C >> 2, Ht = a.H >> 1, Wt = a.W >> 1;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    // each XCD transforms one CONTIGUOUS slab of tiles: neighbouring tiles share half of their 4 x 4 input patches, and with the dispatcher's
+    // round-robin order every XCD's private L2 fetched most of the input again (r03 PMC: 102.5 MB moved for 83.9 MB). Placement only.
+    const long long idx = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const long long R = (long long)a.n * a.D * Ht * Wt;
     if (idx >= R * C4) return;
     const unsigned r = (unsigned)(idx / C4);

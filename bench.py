@@ -891,7 +891,7 @@ def train_bench(args, rank, world, dev, affinity):
             fdist.barrier()
     pg = fdist.group_info()
     dts = fdist.all_reduce_scalars(dts, dev, "max")
-    dt = sorted(dts)[len(dts) // 2]
+    dt = region_stats(dts, args.steps, 1.0)[0]                      # median region
     views, ranks_ok, loss_sum = fdist.all_reduce_scalars([B * 10.0 * ok, ok, loss if ok else 0.0], dev, "sum")
     errs = fdist.gather_strings(err)
     if rank == 0:
@@ -1025,7 +1025,7 @@ def main():
         out, dts = None, [0.0] * R
     pg = fdist.group_info()                                          # which backend actually carried the collectives of this run
     dts = fdist.all_reduce_scalars(dts, dev, "max")                  # every region: the slowest rank's clock
-    dt = sorted(dts)[len(dts) // 2] if len(dts) % 2 else 0.5 * (sorted(dts)[len(dts) // 2 - 1] + sorted(dts)[len(dts) // 2])   # median region
+    dt = region_stats(dts, args.steps, 1.0)[0]                      # median region
     # the one exchange of the inference path: (SSE to the target views, pixel count, views rendered) summed over ranks
     # (RCCL all-reduce of a few doubles) -> whole-job PSNR / view count; ranks_ok rides along
     if ok:

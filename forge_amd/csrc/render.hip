@@ -229,17 +229,32 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
                                                               const float* __restrict__ g_feat, const float* __restrict__ g_opac,
                                                               const float* __restrict__ g_depth, float2* __restrict__ G,
                                                               float* __restrict__ cam_part, int D, int H, int W, int Hr, int Wr,
-                                                              int S, float zmin, float zmax, float hx, float hy, float hz) {
+                                                              int S, float zmin, float zmax, float hx, float hy, float hz, int V, int band_order) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][RPB][S + 1]: (d_s, a_s) -> (T_s d_s, dL/dd_s); row pad: a wave's rays hit distinct banks
     const int SP = S + 1;
     float* lds_d = lds;
     float* lds_a = lds + (size_t)RPB * SP;
-    const int v = blockIdx.z;
+    // workgroup -> (view, pixel tile) as in render_fwd_kernel: with band_order an XCD marches one band of tile rows of EVERY view, so that its
+    // L2 serves all views from the slab of the volume it has already fetched (PMC, 10 views of one 64^3 volume: 342 MB -> see profiles/ r04)
+    const unsigned nx = (unsigned)(Wr + 7) / 8, ny = (unsigned)(Hr + TH - 1) / TH;
+    unsigned bxu, byu, bzu;
+    if (band_order) {
+        const unsigned g = blockIdx.x, xcd = g % NUM_XCD, k = g / NUM_XCD, rows_per = ny / NUM_XCD;
+        bzu = k % (unsigned)V;
+        const unsigned t = k / (unsigned)V;
+        byu = xcd * rows_per + t / nx;
+        bxu = t % nx;
+    } else {
+        bxu = blockIdx.x % nx;
+        byu = (blockIdx.x / nx) % ny;
+        bzu = blockIdx.x / (nx * ny);
+    }
+    const int v = (int)bzu;
     const int cg = threadIdx.x % C4, r = threadIdx.x / C4;
     int lx, ly;
     tile_pixel(r, lx, ly);
-    const int w = blockIdx.x * 8 + lx, h = blockIdx.y * TH + ly;
+    const int w = (int)bxu * 8 + lx, h = (int)byu * TH + ly;
     const bool inside = (w < Wr) && (h < Hr);
     const float* cam = cams + v * 16;
     const long long nvox = (long long)D * H * W;
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
     // write-out, plane-major G [V][S][Hr][Wr] (what the voxel gather wants: the lanes of a wave - neighbouring voxels - read neighbouring
     // pixels of one depth plane): per (s, tile row) 8 pixels = 64 contiguous bytes; samples outside a ray's interval are exact zeros
     {
-        const int x0 = blockIdx.x * 8, y0 = blockIdx.y * TH;
+        const int x0 = (int)bxu * 8, y0 = (int)byu * TH;
         for (int idx = threadIdx.x; idx < RPB * S; idx += 256) {
             const int s = idx / RPB, pp = idx - s * RPB;            // pp = py * 8 + px inside the 8 x TH tile
             const int px_ = pp & 7, py_ = pp >> 3;
@@ -381,20 +396,27 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
             if (lane == 0) red[i][wv] = sacc;
         }
         __syncthreads();
-        const long long blk = ((long long)v * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const long long blk = ((long long)v * ny + byu) * nx + bxu;
         if (threadIdx.x < 16) cam_part[blk * 16 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     }
 }
 
-// dcam [V][16] = the per-workgroup partials of one view summed in workgroup order (deterministic)
-__global__ __launch_bounds__(64) void render_bwd_cam_reduce_kernel(const float* __restrict__ cam_part, float* __restrict__ dcam, int V, int nblk) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= V * 16) return;
-    const int v = i / 16, k = i % 16;
+// dcam [V][16] = the per-workgroup partials of one view summed in a fixed order (deterministic): workgroup = view, thread = (slice j of the
+// partial list, camera entry k); 16 slices are summed in parallel, then in slice order
+__global__ __launch_bounds__(256) void render_bwd_cam_reduce_kernel(const float* __restrict__ cam_part, float* __restrict__ dcam, int V, int nblk) {
+    __shared__ float red[16][16];
+    const int v = blockIdx.x, k = threadIdx.x & 15, j = threadIdx.x >> 4;
     const float* p = cam_part + (long long)v * nblk * 16 + k;
     float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += p[(long long)b * 16];
-    dcam[i] = acc;
+    for (int b = j; b < nblk; b += 16) acc += p[(long long)b * 16];
+    red[j][k] = acc;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
+        dcam[v * 16 + threadIdx.x] = s;
+    }
 }
 
 template <int C4>
@@ -647,17 +669,19 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
     FORGE_REQUIRE((nvox + 255) / 256 < (1ll << 31), FORGE_ESHAPE, "forge_render_bwd: grid too large");
     FORGE_DISPATCH_C4(C, {
         constexpr int TH = (256 / C4) / 8;
-        dim3 grid((Wr + 7) / 8, (Hr + TH - 1) / TH, V);
+        const unsigned nxg = (unsigned)(Wr + 7) / 8, nyg = (unsigned)(Hr + TH - 1) / TH;
+        const int band_order = (nyg % NUM_XCD == 0) ? 1 : 0;     // as forge_render_fwd
+        dim3 grid(nxg * nyg * (unsigned)V);
         if (dcam) {
             FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, true>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_rays_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
-            hipLaunchKernelGGL(render_bwd_cam_reduce_kernel, dim3((V * 16 + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)cam_part, dcam, V,
-                               (int)(grid.x * grid.y));
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
+            hipLaunchKernelGGL(render_bwd_cam_reduce_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, (const float*)cam_part, dcam, V,
+                               (int)(nxg * nyg));
         } else {
             FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, false>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_rays_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
         }
         hipLaunchKernelGGL(render_bwd_voxels_kernel<C4>, dim3((unsigned)((nvox + 255) / 256), nvol), dim3(256), 0, (hipStream_t)stream, cam, view2vol,
                            g_feat, (const float2*)G, dfeat, ddens, V, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);

@@ -1,3 +1,2 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_properties.py tests/test_gpu_winograd.py -x -q -k "train or wgrad or conv or heads or fuse or adjoint" 2>&1 | tail -4
-python tools/debug/train_grad_margins.py 2>&1 | tail -2
-bash tools/gpu/run_trainprof_r4.sh r04_g_train_b4
+python -m pytest tests/test_gpu_properties.py tests/test_gpu_parity.py tests/test_gpu_ddp.py -x -q -k "render or refine or pose or ray_sharded" 2>&1 | tail -3
+bash tools/gpu/run_render_bwd_probe.sh 2>&1 | grep -E "grid|backward" | head -20

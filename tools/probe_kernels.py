@@ -78,5 +78,28 @@ if "wino" in which:
         co.wino_gemm(Vx, Cc, Vh, Cc, U, Mm, 1, D, D // 2, D // 2, 256)
     for _ in range(iters):
         co.wino_output(Mm, bias, None, None, 1.0, None, h, None, z, hr, None, 1, D, D, D, 256, Cc, co.EPI_GRU_GATES)
+if "render_bwd" in which:
+    # the ray-march backward (round 4: ray pass -> per-sample scalars in the workspace, voxel-parallel gather): 10 views of ONE 64^3 x 16 volume,
+    # 128^2 rays x 64 samples, camera gradients on (the refinement / joint-training form) - forge_render_bwd through the C-ABI
+    Dr, Cr, V, Hr, S = 64, 16, 10, 128, 64
+    feat, dens = syn.blob_volumes(1, Dr, Cr, seed=0)
+    feat = feat.to(dev).permute(0, 2, 3, 4, 1).contiguous()
+    dens = dens.to(dev).contiguous()
+    _, extr, _ = syn.orbit_cameras(V, 1.5, 10.0)
+    K = syn.intrinsics(256) / 2.0
+    cam = torch.cat([extr[:, :3, :3].reshape(V, 9), extr[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1),
+                     K[0, 2].expand(V, 1), K[1, 2].expand(V, 1)], dim=1).contiguous().to(dev)
+    v2v = torch.zeros(V, dtype=torch.int32, device=dev)
+    gf, go = torch.randn(V, Hr, Hr, Cr, device=dev), torch.randn(V, Hr, Hr, device=dev)
+    dfe, dde, dca = torch.empty_like(feat), torch.empty_like(dens), torch.empty(V, 16, device=dev)
+    nb = lib.forge_render_bwd_ws_bytes(V, Cr, Hr, Hr, S, 1)
+    ws = torch.empty(nb // 4, device=dev)
+    h = 0.5 * (Dr - 1) / Dr
+    for _ in range(iters):
+        _lib.check(lib.forge_render_bwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(gf), _lib.ptr(go), None, _lib.ptr(dfe),
+                                        _lib.ptr(dde), _lib.ptr(dca), V, 1, Cr, Dr, Dr, Dr, Hr, Hr, S, 0.5, 2.0, h, h, h, _lib.ptr(ws), nb, st), "render_bwd")
+    for _ in range(iters):                                         # and the training form (no camera gradients)
+        _lib.check(lib.forge_render_bwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(gf), _lib.ptr(go), None, _lib.ptr(dfe),
+                                        _lib.ptr(dde), None, V, 1, Cr, Dr, Dr, Dr, Hr, Hr, S, 0.5, 2.0, h, h, h, _lib.ptr(ws), nb, st), "render_bwd")
 torch.cuda.synchronize()
 print("probe done")

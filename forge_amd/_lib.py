@@ -36,7 +36,7 @@ SIGNATURES = {
     "forge_render_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_F] * 5 + [_P, _LL, _P],
     "forge_resize_bilinear_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "forge_resize_bilinear_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 12 + [_P, _LL, _P],
+    "forge_conv_igemm": [_P, _I, _I, _LL, _P, _I, _I, _LL, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P] + [_I] * 12 + [_P, _LL, _P, _P],
     "forge_wino_weights": [_P, _P, _I, _I, _I, _I, _P],
     "forge_wino_dy": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
     "forge_wino_wgrad": [_P, _P, _I, _LL, _LL, _P, _I, _LL, _LL, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -55,9 +55,9 @@ SIGNATURES = {
     "forge_gru_state_bwd": [_P, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _LL, _LL, _I, _P],
     "forge_gru_gates_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _LL, _I, _P, _LL, _LL, _I, _P],
     "forge_bn_ws_doubles": [_I],
-    "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P, _I, _P, _P],
+    "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P, _I, _P, _I, _P],
     "forge_bn_train_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _LL, _I, _P, _I, _P, _I, _P],
-    "forge_bn_sync_stats": [_P, _I, _P, _LL, _I, _P],
+    "forge_bn_sync_stats": [_P, _I, _P, _LL, _I, _I, _P],
     "forge_bn_sync_fwd_apply": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _LL, _I, _P, _I, _P, _P],
     "forge_bn_sync_bwd_reduce": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _LL, _I, _P, _I, _P],
     "forge_bn_sync_bwd_apply": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _LL, _LL, _I, _P, _I, _P, _I, _P],

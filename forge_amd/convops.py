@@ -212,10 +212,12 @@ MAX_OPERAND_BYTES = (1 << 31) - 1       # 32-bit buffer offsets of the kernel's 
 @_lib.on_tensor_device
 def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2,
                grid, in_grid, Cout, ldo, taps, out_grid=None, istride=1, ostride=1, phase=(0, 0, 0), epilogue=EPI_BIAS,
-               bs1=0, bs2=0, lift=0, out3=None):
+               bs1=0, bs2=0, lift=0, out3=None, stats=None):
     """Thin launcher. grid = (n,D,H,W) GEMM-row grid; in_grid = (Di,Hi,Wi); out_grid = (Do,Ho,Wo) (default = grid).
     The kernel addresses its gathered operands through 32-bit buffer offsets (< 2 GiB per operand); batches whose inputs span more
-    (e.g. 32 scenes of 64^3 x 64-channel head activations) are launched in batch chunks here."""
+    (e.g. 32 scenes of 64^3 x 64-channel head activations) are launched in batch chunks here.
+    stats (float64 [stats_blocks(M, tile)][2][Cout], EPI_BIAS only): receives the output's per-block column sums / sums of squares (the batch
+    statistics of a following BatchNorm); only for un-chunked, un-split launches - use conv_stats_buffer(), which returns None otherwise."""
     n, D, H, W = grid
     Di, Hi, Wi = in_grid
     Do, Ho, Wo = out_grid if out_grid is not None else (D, H, W)
@@ -243,6 +245,8 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
         # torch's stream-ordered caching allocator (per-stream pools; inside a hipGraph capture it comes from the graph's private
         # pool and is reused by the graph's later launches) - no process-global workspace
         tile, ksplit = conv_plan(k * D * H * W, Cout, C1 + C2, len(taps), epilogue, ldo, nphase)
+        if stats is not None and (ksplit > 1 or nc < n):
+            raise RuntimeError("forge_amd: conv_igemm output statistics need an un-chunked launch without split-K (use conv_stats_buffer)")
         ws = torch.empty(ksplit * k * D * H * W * Cout, dtype=torch.float32, device=out.device) if ksplit > 1 else None
         o_ld = gate_w if epilogue == EPI_GRU_GATES else ldo
         _lib.check(L.forge_conv_igemm(
@@ -251,9 +255,34 @@ def conv_igemm(in1, C1, ld1, in2, C2, ld2, wp, bias, scale, shift, slope, residu
             off(aux_h, orow * gate_w), off(aux_z, orow * Cout),
             off(out, orow * (Cout if lift else o_ld)), off(out2, orow * o_ld), off(out3, orow * o_ld), k, D, H, W, istride, Di, Hi, Wi, Cout, ldo,
             arr, len(taps), ostride, phase[0], phase[1], phase[2], Do, Ho, Wo, epilogue, int(lift), 0 if tile == "N" else ord(tile), ksplit,
-            _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, st),
+            _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.ptr(stats), st),
             "forge_conv_igemm")
     return out
+
+
+TILE_BM = {"A": 128, "B": 64, "C": 128, "D": 64, "E": 128}          # GEMM rows per workgroup tile ('A'..'E' of forge_conv_igemm_plan)
+
+
+def stats_blocks(M, tile):
+    """32-row blocks forge_conv_igemm's `stats` by-product writes for M GEMM rows on workgroup tile `tile`: whole tiles, every block written."""
+    bm = TILE_BM[tile]
+    return ((int(M) + bm - 1) // bm) * (bm // 32)
+
+
+def conv_stats_buffer(x1, in2, grid, in_grid, Cout, Cin, ntaps, ldo, device):
+    """float64 [stats_blocks(M, tile)][2][Cout] for the BatchNorm statistics by-product of a plain EPI_BIAS conv_igemm launch, or None when this
+    problem would not take one un-split launch of the wide kernel (split-K plan, Cout <= 16, batch chunking)."""
+    n, D, H, W = grid
+    M = n * D * H * W
+    if Cout <= 16 or Cout % 4:
+        return None
+    tile, ksplit = conv_plan(M, Cout, Cin, ntaps, EPI_BIAS, ldo, 1)
+    if ksplit > 1 or tile == "N":
+        return None
+    Di, Hi, Wi = in_grid
+    if ((n - 1) * (Di * Hi * Wi) + Di * Hi * Wi) * max(x1.shape[-1], 0 if in2 is None else in2.shape[-1]) * 4 > MAX_OPERAND_BYTES:
+        return None
+    return torch.empty(stats_blocks(M, tile), 2, Cout, dtype=torch.float64, device=device)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -522,7 +551,7 @@ class _ConvTapsRows(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x1, x2, wp, bias, taps, istride, out_spatial):
+    def forward(ctx, x1, x2, wp, bias, taps, istride, out_spatial, want_stats=False):
         n, Di, Hi, Wi, C1 = x1.shape
         C2 = 0 if x2 is None else x2.shape[-1]
         T, Cout, Cin = wp.shape
@@ -531,17 +560,26 @@ class _ConvTapsRows(torch.autograd.Function):
         out = torch.empty(n, D, H, W, Cout, dtype=torch.float32, device=x1.device)
         bs1 = _batch_stride_rows(x1)
         bs2 = 0 if x2 is None else _batch_stride_rows(x2)
+        stats = None
         if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout):
             wino_conv_rows(x1, x2, wino_pack_packed(wpc), bias, out)
         else:
+            if want_stats and bs1 == 0 and bs2 == 0:
+                # the BatchNorm behind this convolution gets its batch statistics from the GEMM epilogue (float64 column sums per 32-row block)
+                stats = conv_stats_buffer(x1, x2, (n, D, H, W), (Di, Hi, Wi), Cout, Cin, T, Cout, x1.device)
             conv_igemm(x1, C1, C1, x2, C2, C2, wpc, bias, None, None, 1.0, None, None, None, out, None,
-                       (n, D, H, W), (Di, Hi, Wi), Cout, Cout, taps, istride=istride, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2)
+                       (n, D, H, W), (Di, Hi, Wi), Cout, Cout, taps, istride=istride, epilogue=EPI_BIAS, bs1=bs1, bs2=bs2, stats=stats)
         ctx.save_for_backward(x1, x2, wpc)
         ctx.meta = (tuple(taps), istride, (D, H, W), bias is not None)
-        return out
+        if not want_stats:
+            return out
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float64, device=x1.device)      # "none": the BatchNorm runs its own statistics pass
+        ctx.mark_non_differentiable(stats)
+        return out, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dstats=None):
         x1, x2, wp = ctx.saved_tensors
         taps, istride, (D, H, W), has_bias = ctx.meta
         n, Di, Hi, Wi, C1 = x1.shape
@@ -597,7 +635,7 @@ class _ConvTapsRows(torch.autograd.Function):
                            bs2=0 if x2 is None else _batch_stride_rows(x2))
         if has_bias and ctx.needs_input_grad[3]:
             db = colsum(dy.reshape(-1, Cout))
-        return dx1, dx2, dwp, db, None, None, None
+        return dx1, dx2, dwp, db, None, None, None, None
 
 
 class _Conv1x1RowsSkip(torch.autograd.Function):
@@ -612,13 +650,17 @@ class _Conv1x1RowsSkip(torch.autograd.Function):
         Cout = w.shape[0]
         wp = w.detach().reshape(1, Cout, Cin).contiguous()
         out = torch.empty(N, H, W, Cout, dtype=torch.float32, device=x.device)
+        stats = conv_stats_buffer(x, None, (N, 1, H, W), (1, H, W), Cout, Cin, 1, Cout, x.device)      # the batch statistics of bn1, from the epilogue
         conv_igemm(x, Cin, Cin, None, 0, 0, wp, None, None, None, 1.0, None, None, None, out, None, (N, 1, H, W), (1, H, W), Cout, Cout, [(0, 0, 0)],
-                   epilogue=EPI_BIAS)
+                   epilogue=EPI_BIAS, stats=stats)
         ctx.save_for_backward(x, wp)
-        return out, x.view_as(x)
+        if stats is None:
+            stats = torch.empty(0, dtype=torch.float64, device=x.device)
+        ctx.mark_non_differentiable(stats)
+        return out, x.view_as(x), stats
 
     @staticmethod
-    def backward(ctx, dy, dskip):
+    def backward(ctx, dy, dskip, _dstats=None):
         x, wp = ctx.saved_tensors
         N, H, W, Cin = x.shape
         Cout = wp.shape[1]
@@ -642,15 +684,18 @@ class _Conv1x1RowsSkip(torch.autograd.Function):
 
 
 def conv1x1_rows_skip(x, weight):
-    """(conv1x1(x, weight), x) on NHWC rows [N,H,W,Cin] with autograd; weight [Cout,Cin,1,1], Cin and Cout multiples of 32. Use the returned
-    alias of x for every OTHER consumer of x: its gradient is then added inside this convolution's data-gradient GEMM."""
+    """(conv1x1(x, weight), x, stats) on NHWC rows [N,H,W,Cin] with autograd; weight [Cout,Cin,1,1], Cin and Cout multiples of 32. Use the
+    returned alias of x for every OTHER consumer of x: its gradient is then added inside this convolution's data-gradient GEMM. stats: the
+    output's batch statistics from the GEMM epilogue (conv_taps_rows), for the BatchNorm behind the convolution."""
     return _Conv1x1RowsSkip.apply(x, weight)
 
 
-def conv_taps_rows(x1, x2, wp, bias, taps, istride=1, out_spatial=None):
+def conv_taps_rows(x1, x2, wp, bias, taps, istride=1, out_spatial=None, want_stats=False):
+    """want_stats: returns (out, stats) - stats = the output's float64 per-block column sums / sums of squares from the GEMM epilogue
+    ([blocks][2][Cout]; an EMPTY tensor when this launch could not produce them), for bn_act_rows(..., stats=)."""
     if out_spatial is None:
         out_spatial = tuple(x1.shape[1:4])
-    return _ConvTapsRows.apply(x1, x2, wp, bias, tuple(taps), int(istride), tuple(out_spatial))
+    return _ConvTapsRows.apply(x1, x2, wp, bias, tuple(taps), int(istride), tuple(out_spatial), bool(want_stats))
 
 
 def _pack3d(weight):        # differentiable pack_conv3d_weight
@@ -664,13 +709,16 @@ def conv3x3x3_rows(x1, x2, weight, bias):
     return conv_taps_rows(x1, x2, _pack3d(weight), bias, TAPS_3x3x3)
 
 
-def conv2d_rows(x, weight, bias, stride=1):
-    """Conv2d(k, stride, padding=k//2) on NHWC rows [N,H,W,C] with autograd (ResNet bottleneck convolutions in training)."""
+def conv2d_rows(x, weight, bias, stride=1, want_stats=False):
+    """Conv2d(k, stride, padding=k//2) on NHWC rows [N,H,W,C] with autograd (ResNet bottleneck convolutions in training).
+    want_stats: (y, stats) as conv_taps_rows."""
     co_, ci_, kh, kw = weight.shape
     N, H, W, C = x.shape
     taps = [(0, ky - kh // 2, kx - kw // 2) for ky in range(kh) for kx in range(kw)]
     Ho, Wo = (H + 2 * (kh // 2) - kh) // stride + 1, (W + 2 * (kw // 2) - kw) // stride + 1
-    y = conv_taps_rows(x.reshape(N, 1, H, W, C), None, weight.reshape(co_, ci_, kh * kw).permute(2, 0, 1), bias, taps, stride, (1, Ho, Wo))
+    y = conv_taps_rows(x.reshape(N, 1, H, W, C), None, weight.reshape(co_, ci_, kh * kw).permute(2, 0, 1), bias, taps, stride, (1, Ho, Wo), want_stats)
+    if want_stats:
+        return y[0].reshape(N, Ho, Wo, co_), y[1]
     return y.reshape(N, Ho, Wo, co_)
 
 

@@ -336,7 +336,8 @@ static int bn_check_side(const char* fn, const char* what, const void* p, int ld
 
 extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                                   float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
-                                  long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream) {
+                                  long long M, int C, const float* res, int ldres, long long* num_batches_tracked, int nblk_pre,
+                                  forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_train_fwd", x, ldx, M, C, ws)) return rc;
     FORGE_REQUIRE(y && mean && invstd && ldy >= C && ldy % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr), FORGE_EINVAL,
                   "forge_bn_train_fwd: bad output / running-statistics arguments");
@@ -347,9 +348,14 @@ extern "C" int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, c
     if (int rc = bn_check_side("forge_bn_train_fwd", "residual", res, ldres, C)) return rc;
     a.res = res; a.ldres = ldres; a.nbt = num_batches_tracked;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 gr = bn_grid(M, C, true);
-    a.nblk = (int)gr.x;
-    hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    FORGE_REQUIRE(nblk_pre >= 0, FORGE_EINVAL, "forge_bn_train_fwd: nblk_pre < 0");
+    if (nblk_pre > 0) {
+        a.nblk = nblk_pre;                                         // ws already holds nblk_pre partial rows [2][C] (the producing convolution's epilogue)
+    } else {
+        const dim3 gr = bn_grid(M, C, true);
+        a.nblk = (int)gr.x;
+        hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 0);
     hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
     FORGE_LAUNCH_CHECK("forge_bn_train_fwd");
@@ -386,15 +392,20 @@ extern "C" int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int
 //   backward  forge_bn_sync_bwd_reduce  -> ws[0 .. 2C) = this rank's (sum g, sum g xhat); dgamma / dbeta = the LOCAL sums (as torch's
 //                                          SyncBatchNorm: DDP averages parameter gradients afterwards)   [all-reduce SUM]
 //             forge_bn_sync_bwd_apply   dx = gamma invstd (g - mean_all(g) - xhat mean_all(g xhat))
-extern "C" int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, forge_stream_t stream) {
+extern "C" int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, int nblk_pre, forge_stream_t stream) {
     if (int rc = bn_check("forge_bn_sync_stats", x, ldx, M, C, ws)) return rc;
+    FORGE_REQUIRE(nblk_pre >= 0, FORGE_EINVAL, "forge_bn_sync_stats: nblk_pre < 0");
     BnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.ldx = ldx; a.ws = ws; a.M = M; a.C = C; a.Mtot = M;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 gr = bn_grid(M, C, true);
-    a.nblk = (int)gr.x;
-    hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    if (nblk_pre > 0) {
+        a.nblk = nblk_pre;
+    } else {
+        const dim3 gr = bn_grid(M, C, true);
+        a.nblk = (int)gr.x;
+        hipLaunchKernelGGL(bn_stats_kernel, gr, dim3(BN_THREADS), 0, st, a);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(BN_THREADS), 0, st, a, 2);
     FORGE_LAUNCH_CHECK("forge_bn_sync_stats");
     return 0;

@@ -67,6 +67,8 @@ struct ConvArgs {
     int nbat;                              // > 1: nbat independent GEMMs in one launch (the 16 Winograd points, forge_wino_gemm): problem p adds
     long long pt1, pt2, ptw, pto;          //      p * pt1 / pt2 / ptw / pto floats to in1 / in2 / wp / out (EPI_BIAS, no split-K, no phases)
     float* ws; int ksplit;                 // split-K: raw partial tiles go to ws[ks][M][Cout], a second kernel reduces + applies the epilogue
+    double* stats;                         // EPI_BIAS, nullable: per 32-row block of M the column sums / sums of squares of the OUTPUT, [ceil(M/32)..][2][Cout] float64 -
+                                           // the batch statistics of the BatchNorm behind this convolution as a by-product of its epilogue (csrc/bnorm.hip finalizes them)
     signed char tap[MAX_TAPS][4];          // (dz, dy, dx, 0)
 };
 
@@ -394,6 +396,29 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
                             a.out[orow * a.ldo + col] = hn;
                             if (a.out2) a.out2[orow * a.ldo + col] = fmaf(hn, sc, sh);
                             if (a.out3) a.out3[orow * a.ldo + col] = cand;
+                        }
+                    }
+                }
+            }
+            if constexpr (EPI == EPI_BIAS) {
+                if (a.stats) {                                       // workgroup-uniform, off the plain path: a second walk over this column's accumulators
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        double t1 = 0.0, t2 = 0.0;                   // this lane's share of column `col` in the 32-row block (rows beyond M excluded)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (s_row[rl] >= 0) {
+                                const double v = (double)(acc[i][j][r] + bias);
+                                t1 += v; t2 += v * v;
+                            }
+                        }
+                        // the two half-waves hold the rows 4 (lane >> 5) + ... of the block: add them; lanes 0..31 then own one column each
+                        t1 += __shfl_xor(t1, 32, 64); t2 += __shfl_xor(t2, 32, 64);
+                        const long long blk = (m0 + wm * (32 * MT) + i * 32) >> 5;
+                        if (half == 0 && cok) {
+                            a.stats[(blk * 2) * a.Cout + col] = t1;
+                            a.stats[(blk * 2 + 1) * a.Cout + col] = t2;
                         }
                     }
                 }
@@ -865,8 +890,11 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                 const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                                 int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                                 const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                                int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream) {
+                                int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, double* stats,
+                                forge_stream_t stream) {
     FORGE_REQUIRE(in1 && wp && out && taps, FORGE_EINVAL, "forge_conv_igemm: null pointer argument");
+    FORGE_REQUIRE(stats == nullptr || (epilogue == EPI_BIAS && ksplit <= 1 && Cout > 16 && !(pz < 0) && lift == 0), FORGE_EINVAL,
+                  "forge_conv_igemm: output statistics need the plain bias epilogue of the wide kernel without split-K, phases or lift");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && Cout > 0 && ntaps > 0 && ntaps <= MAX_TAPS, FORGE_EINVAL,
                   "forge_conv_igemm: bad dims n=%d D=%d H=%d W=%d Cout=%d ntaps=%d", n, D, H, W, Cout, ntaps);
     const int kstep = Cout <= 16 ? 16 : 32;
@@ -888,7 +916,7 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
     a.span1 = ((long long)(n - 1) * a.bs1r + (long long)Di * Hi * Wi) * ld1 * 4;
     a.span2 = in2 ? ((long long)(n - 1) * a.bs2r + (long long)Di * Hi * Wi) * ld2 * 4 : 0;
     FORGE_REQUIRE(a.span1 < (1ll << 31) && a.span2 < (1ll << 31) && (long long)ntaps * Cout * (C1 + C2) * 4 < (1ll << 31), FORGE_ESHAPE,
-                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = (lift > 0 || epilogue == EPI_GRU_GATES || epilogue == EPI_GRU_OUT) ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
+                  "forge_conv_igemm: an operand spans >= 2 GiB (32-bit buffer offsets); split the batch"); a.is = is; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.residual = residual; a.ldr = (lift > 0 || epilogue == EPI_GRU_GATES || epilogue == EPI_GRU_OUT) ? Cout : ldo; a.lift = lift; a.ws = nullptr; a.ksplit = 1; a.stats = stats; a.wp = wp; a.bias = bias; a.scale = scale; a.shift = shift; a.slope = slope;
     a.aux_h = aux_h; a.aux_z = aux_z; a.out = out; a.out2 = out2; a.out3 = out3; a.n = n; a.D = D; a.H = H; a.W = W; a.Cout = Cout; a.ldo = ldo;
     a.ntaps = ntaps; a.os = os; a.pz = pz; a.py = py; a.px = px; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.epi = epilogue;
     a.nphase = 1; a.tpp = ntaps; a.nbat = 1; a.pt1 = a.pt2 = a.ptw = a.pto = 0;

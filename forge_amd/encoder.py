@@ -250,20 +250,22 @@ class Encoder3D(co.PackedModule):
         _lib.check(_lib.lib().forge_im2col_nchw(_lib.ptr(img.detach().contiguous()), _lib.ptr(patches), N, Ci, Hi, Wi, kh, kw, s0, p0, Kp,
                                                 _lib.current_stream()), "forge_im2col_nchw")
         w0 = torch.nn.functional.pad(conv0.weight.permute(0, 2, 3, 1).reshape(conv0.out_channels, -1), (0, Kp - kh * kw * Ci))[None]
-        x = co.conv_taps_rows(patches, None, w0, None, [(0, 0, 0)]).reshape(N, Hc, Wc, conv0.out_channels)
-        x = self._bn2d_rows(bn0, x)
+        x, st0 = co.conv_taps_rows(patches, None, w0, None, [(0, 0, 0)], want_stats=True)
+        x = bn_act_rows(bn0, x.reshape(N, Hc, Wc, conv0.out_channels), 0.0, stats=st0)
         x = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         for li in (4, 5, 6, 7):
             for blk in fe[li]:
                 # conv1 hands its input through: the gradients of the identity / downsample path are added inside conv1's data-gradient GEMM
-                y1, idn = co.conv1x1_rows_skip(x, blk.conv1.weight)
-                out = self._bn2d_rows(blk.bn1, y1)
-                out = self._bn2d_rows(blk.bn2, co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0]))
+                y1, idn, st1 = co.conv1x1_rows_skip(x, blk.conv1.weight)
+                out = bn_act_rows(blk.bn1, y1, 0.0, stats=st1)            # the statistics of every BatchNorm below come from its convolution's GEMM epilogue
+                y2, st2 = co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0], want_stats=True)
+                out = bn_act_rows(blk.bn2, y2, 0.0, stats=st2)
                 if blk.downsample is not None:
-                    idn = self._bn2d_rows(blk.downsample[1], co.conv2d_rows(idn, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0]),
-                                          relu=False)
+                    yd, std = co.conv2d_rows(idn, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0], want_stats=True)
+                    idn = bn_act_rows(blk.downsample[1], yd, 1.0, stats=std)
                 # relu(bn3(conv3) + identity) in bn3's apply pass (and its mask / d identity in bn3's backward apply pass)
-                x = bn_act_rows(blk.bn3, co.conv2d_rows(out, blk.conv3.weight, None), 0.0, residual=idn)
+                y3, st3 = co.conv2d_rows(out, blk.conv3.weight, None, want_stats=True)
+                x = bn_act_rows(blk.bn3, y3, 0.0, residual=idn, stats=st3)
         return x
 
     def _head_autograd_hip(self, head, z):

@@ -42,11 +42,13 @@ def _rows_ok(t, C):
 
 
 @_lib.on_tensor_device
-def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual=None, nbt=None, group=None):
+def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual=None, nbt=None, group=None, stats=None):
     """Train-mode (Sync)BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows x [M, C] (csrc/bnorm.hip): float64 batch statistics, running
     statistics / num_batches_tracked updated in place by the same launches. group (a process group with > 1 ranks): the statistics are those of
     all ranks - ONE all-reduce of the float64 (sum x, sum x^2, row count) (RCCL over xGMI; torch's SyncBatchNorm all-gathers per-rank mean /
-    invstd / count instead). Returns (y, saved) with `saved` what bn_rows_bwd needs."""
+    invstd / count instead). stats (float64 [blocks][2][C], optional): the per-block column sums / sums of squares of x that the producing
+    convolution's GEMM epilogue already wrote (convops.conv_taps_rows(want_stats=True)) - the statistics pass over x is then skipped.
+    Returns (y, saved) with `saved` what bn_rows_bwd needs."""
     M, C = x.shape
     dev = x.device
     L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
@@ -55,14 +57,22 @@ def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope,
     res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
     ldres = 0 if res is None else res.stride(0)
     count = None
+    pre = 0
+    if stats is not None and stats.numel():
+        if stats.dim() != 3 or stats.shape[1:] != (2, C) or stats.dtype != torch.float64:
+            raise ValueError("bn_rows_fwd: stats must be float64 [blocks][2][%d], got %s %s" % (C, stats.dtype, tuple(stats.shape)))
+        pre = stats.shape[0]
     if group is None:
-        ws = torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
+        ws = stats if pre else torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
         _lib.check(L.forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd), p(running_mean),
-                                        p(running_var), float(momentum), p(ws), M, C, p(res), ldres, p(nbt), st()), "forge_bn_train_fwd")
+                                        p(running_var), float(momentum), p(ws), M, C, p(res), ldres, p(nbt), pre, st()), "forge_bn_train_fwd")
     else:
         import torch.distributed as tdist
-        ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
-        _lib.check(L.forge_bn_sync_stats(p(x), x.stride(0), p(ws), M, C, st()), "forge_bn_sync_stats")
+        if pre:                                                     # the totals land in the first partial row, the row count behind them (pre >= 2 rows)
+            ws = stats.reshape(-1)
+        else:
+            ws = torch.empty(L.forge_bn_ws_doubles(C) + 1, dtype=torch.float64, device=dev)
+        _lib.check(L.forge_bn_sync_stats(p(x), x.stride(0), p(ws), M, C, pre, st()), "forge_bn_sync_stats")
         tot = ws[:2 * C + 1]
         tot[2 * C:].fill_(float(M))                                 # the row count rides on the same all-reduce and stays on the device
         tdist.all_reduce(tot, op=tdist.ReduceOp.SUM, group=group)
@@ -109,8 +119,8 @@ class _BNTrainRows(torch.autograd.Function):
     and the backward returns d residual."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group):
-        y, saved = bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group, stats=None):
+        y, saved = bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope, residual, nbt, group, stats)
         tensors = tuple(saved[:7])
         ctx.save_for_backward(*tensors)
         ctx.slope, ctx.group = saved[7], saved[8]
@@ -119,7 +129,7 @@ class _BNTrainRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         dx, dg, db, dres = bn_rows_bwd(tuple(ctx.saved_tensors) + (ctx.slope, ctx.group), dy, need_dres=ctx.needs_input_grad[8])
-        return dx, dg, db, None, None, None, None, None, dres, None, None
+        return dx, dg, db, None, None, None, None, None, dres, None, None, None
 
 
 def _sync_world(bn):
@@ -152,7 +162,7 @@ def bn_module_args(bn):
             bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None, _bn_group(bn))
 
 
-def bn_act_rows(bn, rows, slope=1.0, residual=None):
+def bn_act_rows(bn, rows, slope=1.0, residual=None, stats=None):
     """BatchNorm module `bn` (+ `residual`, same shape as rows) + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C].
     Train mode runs the HIP kernels of csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process
     group for nn.SyncBatchNorm (one all-reduce of 2C+1 float64 forward, 2C backward: bn_rows_fwd / bn_rows_bwd), running statistics and
@@ -166,7 +176,7 @@ def bn_act_rows(bn, rows, slope=1.0, residual=None):
         res = None if residual is None else residual.reshape(-1, C)
         args = (x, bn.weight, bn.bias, rm, rv, mom, eps, slope, res, nbt)
         # SyncBatchNorm in a job with > 1 ranks (the reference's training configuration): statistics over all ranks, one all-reduce each way
-        y = _BNTrainRows.apply(*args, group)
+        y = _BNTrainRows.apply(*args, group, stats if (stats is not None and stats.numel() and x.data_ptr() == rows.data_ptr()) else None)
         return y.reshape(rows.shape)
     nd = rows.dim()
     y = bn(rows.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)

@@ -203,6 +203,11 @@ int forge_resize_bilinear_bwd(const float* g, float* din, int P, int Hi, int Wi,
  *            (< 512 workgroups, e.g. ResNet layers at M = 5120) the tap x channel reduction is sliced over up to 8 workgroups
  *            per tile; raw partial tiles go to splitk_ws[slice][M][Cout] and a second kernel sums them in a fixed order and
  *            applies the epilogue (epilogues 0 and 1 only). NULL disables it. Results are deterministic either way.
+ *   stats (nullable; epilogue 0 of the wide kernel, plain output mapping, no split-K): the column sums and sums of squares of the OUTPUT per
+ *            32-row block of M, float64, stats[block][2][Cout] for ceil(M / BM) BM / 32 blocks, BM = the tile's rows (128 for tiles A, C, E; 64 for B, D;
+ *            every block is written, blocks past M with partial / zero sums) - the
+ *            batch statistics of the BatchNorm behind the convolution as a by-product of the epilogue (fixed order, no atomics):
+ *            forge_bn_train_fwd / forge_bn_sync_stats take them as their partial sums (nblk_pre) instead of re-reading the activation.
  *   M = n D H W must be < 2^31.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,
@@ -211,7 +216,7 @@ int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const flo
                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
                      int n, int D, int H, int W, int is, int Di, int Hi, int Wi, int Cout, int ldo,
                      const int* taps, int ntaps, int os, int pz, int py, int px, int Do, int Ho, int Wo,
-                     int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, forge_stream_t stream);
+                     int epilogue, int lift, int tile, int ksplit, float* splitk_ws, long long splitk_ws_bytes, double* stats, forge_stream_t stream);
 
 /* The launch plan forge_conv_igemm will use for a problem (M = n*D*H*W GEMM rows, Cout, Cin = C1 + C2, ntaps): *tile gets the
  * workgroup tile ('A' 128x128, 'B' 64x128, 'C' 128x64, 'D' 64x64, 'E' 128x32 output rows x channels; 'N' = the Cout <= 16 kernel),
@@ -328,7 +333,9 @@ int forge_bn_ws_doubles(int C);
 int forge_colsum(const float* x, int ldx, float* out, double* ws, long long M, int C, forge_stream_t stream);
 int forge_bn_train_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                        float* mean, float* invstd, float* running_mean, float* running_var, float momentum, double* ws,
-                       long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream);
+                       long long M, int C, const float* res, int ldres, long long* num_batches_tracked,
+                       int nblk_pre /* > 0: ws already holds that many partial rows [2][C] - forge_conv_igemm's `stats` by-product - and the statistics pass is skipped */,
+                       forge_stream_t stream);
 int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                        const float* invstd, float slope, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long M, int C,
                        const float* y, int ldy, float* dres, int lddres, forge_stream_t stream);
@@ -342,7 +349,7 @@ int forge_bn_train_bwd(const float* dy, int lddy, const float* x, int ldx, const
  * ws as for forge_bn_train_fwd (forge_bn_ws_doubles(C) doubles); totals may alias ws. M_total = 0: the all-rank row count is read from
  * device memory at totals[2 C] (a double, all-reduced with the sums: no host round trip per layer). With M_total = M and no all-reduce the four calls
  * reproduce forge_bn_train_fwd / _bwd bit for bit. */
-int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, forge_stream_t stream);
+int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C, int nblk_pre /* as forge_bn_train_fwd */, forge_stream_t stream);
 int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                             float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
                             long long M_total, long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream);

@@ -115,3 +115,40 @@ def test_bn_train_residual_form_forward_backward(shape, slope):
     ye = bn_act_rows(he, xd.detach(), slope, residual=rd.detach())
     re = he(xd.detach().permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + rd.detach()
     assert torch.equal(ye, torch.relu(re) if slope == 0.0 else torch.nn.functional.leaky_relu(re, slope))
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride", [(3, 32, 32, 256, 512, 1, 1), (2, 16, 16, 64, 96, 3, 1), (5, 12, 20, 64, 128, 3, 2), (1, 7, 9, 32, 32, 1, 1)])
+def test_conv_epilogue_statistics_feed_batchnorm(N, H, W, Cin, Cout, k, stride):
+    """The batch statistics of a BatchNorm as a by-product of the producing convolution's GEMM epilogue (forge_conv_igemm `stats`: float64 column
+    sums / sums of squares per 32-row block, fixed order): the blocks sum to the output's own float64 sums, and bn_act_rows fed with them equals
+    bn_act_rows running its own statistics pass - output, running statistics, and every gradient (the backward is unchanged)."""
+    from forge_amd import convops as co
+    from forge_amd.fusion import bn_act_rows
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5).to(dev)
+    y, st = co.conv2d_rows(x, w, None, stride=stride, want_stats=True)
+    if N * H * W >= 2048:                                  # large enough for an un-split launch of the wide kernel: the by-product exists
+        assert st.numel() > 0
+    if st.numel():                                         # (small problems take a split-K plan: empty stats, the BatchNorm runs its own pass)
+        assert st.dtype == torch.float64 and st.shape[1:] == (2, Cout)
+        rows = y.reshape(-1, Cout).double()
+        assert (st[:, 0].sum(0) - rows.sum(0)).abs().max().item() < 1e-9 * max(1.0, rows.abs().sum(0).max().item())
+        assert (st[:, 1].sum(0) - (rows * rows).sum(0)).abs().max().item() < 1e-9 * (rows * rows).sum(0).max().item()
+    outs = []
+    for use in (True, False):
+        bn = nn.BatchNorm2d(Cout).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(Cout, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(Cout, generator=torch.Generator().manual_seed(2)) * 0.2)
+        xa, wa = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yy, ss = co.conv2d_rows(xa, wa, None, stride=stride, want_stats=True)
+        z = bn_act_rows(bn, yy, 0.0, stats=ss if use else None)
+        (z * torch.linspace(-1, 1, z.numel(), device=dev).reshape(z.shape)).sum().backward()
+        outs.append((z.detach(), bn.running_mean.clone(), bn.running_var.clone(), xa.grad, wa.grad, bn.weight.grad, int(bn.num_batches_tracked)))
+    a, b = outs
+    assert (a[0] - b[0]).abs().max().item() < 2e-6 * max(1.0, b[0].abs().max().item())
+    assert (a[1] - b[1]).abs().max().item() < 1e-7 and (a[2] - b[2]).abs().max().item() < 1e-6 and a[6] == b[6] == 1
+    for i in (3, 4, 5):
+        assert (a[i] - b[i]).abs().max().item() < 2e-5 * max(1e-6, b[i].abs().max().item()), i

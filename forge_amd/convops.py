@@ -150,6 +150,50 @@ def invalidate_packed(module):
             m.invalidate_packed()
 
 
+class _ZeroArena:
+    """Zero-filled scratch for the weight gradients of ONE backward pass from one allocation and ONE fill: every weight-gradient launch
+    accumulates into a zero-filled dW (fp32 atomics over voxel chunks), i.e. ~100 `torch.zeros` launches of 4-5 us per training step. The
+    first request of a backward pass allocates the bytes the PREVIOUS pass used (+ slack) and zero-fills them once; requests are carved out
+    of it in order (256-byte aligned); when it runs out - or on the very first pass - a request falls back to its own `torch.zeros`. The
+    pass ends with an autograd-engine callback (queued on the first request). The carved tensors are views of the arena: they stay valid for
+    as long as anything (a parameter's .grad) references them; the next pass gets a fresh arena."""
+
+    def __init__(self):
+        self.buf, self.off, self.used, self.want, self.active, self.device = None, 0, 0, 0, False, None
+
+    def _end(self):
+        self.want = self.used
+        self.buf, self.off, self.used, self.active = None, 0, 0, False
+
+    def zeros(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = (n * 4 + 255) // 256 * 256
+        if not self.active:
+            self.active, self.device, self.off, self.used = True, device, 0, 0
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(self._end)      # only valid inside a backward pass
+            except RuntimeError:
+                self.active = False
+                return torch.zeros(shape, dtype=torch.float32, device=device)
+            self.buf = torch.zeros(self.want // 4 + 64, dtype=torch.float32, device=device) if self.want else None
+        self.used += nbytes
+        if self.buf is None or device != self.device or self.off + nbytes > self.buf.numel() * 4:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.off // 4:self.off // 4 + n].view(shape)
+        self.off += nbytes
+        return out
+
+
+GRAD_ZEROS = _ZeroArena()
+
+
+def grad_zeros(shape, device):
+    """A zero-filled float32 tensor for a weight gradient (see _ZeroArena): inside a backward pass a slice of the pass's arena, else torch.zeros."""
+    return GRAD_ZEROS.zeros(tuple(shape), device)
+
+
 SPLITK_WS_BYTES = 128 << 20          # cap the plan model may assume for split-K partial tiles (ksplit x M x Cout floats)
 
 TILE_NAMES = {"A": "128, 128, 8, 1", "B": "64, 128, 8, 1", "C": "128, 64, 8, 1", "D": "64, 64, 4, 1", "E": "128, 32, 4, 1"}
@@ -381,7 +425,7 @@ def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None):
     V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
     dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
     _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
-    dU = torch.zeros(16, kd, Cout, C1 + C2, dtype=torch.float32, device=dev)
+    dU = grad_zeros((16, kd, Cout, C1 + C2), dev)
     _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, kd, st), "forge_wino_wgrad")
     _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, kd, st), "forge_wino_dw")
     return dwp
@@ -627,7 +671,7 @@ class _ConvTapsRows(torch.autograd.Function):
             dx1 = dx[..., :C1] if ctx.needs_input_grad[0] else None
             dx2 = dx[..., C1:] if (x2 is not None and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[2]:
-            dwp = torch.zeros_like(wp)
+            dwp = grad_zeros(wp.shape, wp.device)
             if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout) and (x2 is None or _batch_stride_rows(x2) == 0):
                 conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1), taps=taps)
             else:
@@ -677,7 +721,7 @@ class _Conv1x1RowsSkip(torch.autograd.Function):
                 conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, one, zero, 1.0, dskip.contiguous(), None, None, dx, None, grid, ig, Cin, Cin, T1,
                            epilogue=EPI_AFFINE_ACT)
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros_like(wp)
+            dwp = grad_zeros(wp.shape, wp.device)
             conv_wgrad(dy.reshape(N, 1, H, W, Cout), x.reshape(N, 1, H, W, Cin), Cin, None, 0, dwp, grid, ig, Cout, T1)
             dw = dwp.reshape(Cout, Cin, 1, 1)
         return dx, dw
@@ -754,7 +798,7 @@ class _ConvDirectRows(torch.autograd.Function):
             _lib.check(_lib.lib().forge_conv_direct_dgrad(_lib.ptr(dy), Cout, _lib.ptr(wp), _lib.ptr(dx), Cin, n, D, H, W, Cin, Cout,
                                                           _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_dgrad")
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros_like(wp)
+            dwp = grad_zeros(wp.shape, wp.device)
             _lib.check(_lib.lib().forge_conv_direct_wgrad(_lib.ptr(dy), Cout, _lib.ptr(x), Cin, _lib.ptr(dwp), n, D, H, W, Cin, Cout,
                                                           _taps_array(taps), T, _lib.current_stream()), "forge_conv_direct_wgrad")
         if has_bias and ctx.needs_input_grad[2]:
@@ -833,7 +877,7 @@ class _ConvTS2Rows(torch.autograd.Function):
             conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (Do, 2 * H, 2 * W),
                        Cin, Cin, taps, istride=2, epilogue=EPI_BIAS)
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros(kk, Cin, Cout, dtype=torch.float32, device=x.device)             # [k][ci][co]
+            dwp = grad_zeros((kk, Cin, Cout), x.device)                                          # [k][ci][co]
             conv_wgrad(x, dy, Cout, None, 0, dwp, (n, D, H, W), (Do, 2 * H, 2 * W), Cin, taps, istride=2)
             dw = dwp.permute(1, 2, 0).reshape(weight.shape)
         if has_bias and ctx.needs_input_grad[2]:

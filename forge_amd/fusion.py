@@ -247,7 +247,7 @@ class _GRUCellRows(torch.autograd.Function):
         co.conv3_launch(dc, C, None, 0, wo, None, dxh, grid, 2 * C, dgrad=True)
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[4]:
-            dwo = torch.zeros_like(wo)
+            dwo = co.grad_zeros(wo.shape, wo.device)
             co.conv3_wgrad(dc, x, C, hr, C, dwo, grid, C, bs1=bsx)
         if ctx.has_bias[1] and ctx.needs_input_grad[5]:
             dbo = co.colsum(dc.reshape(M, C))
@@ -257,7 +257,7 @@ class _GRUCellRows(torch.autograd.Function):
         dxh2 = new(2 * C)
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dxh2, grid, 2 * C, dgrad=True)
         if ctx.needs_input_grad[2]:
-            dwg = torch.zeros_like(wg)
+            dwg = co.grad_zeros(wg.shape, wg.device)
             co.conv3_wgrad(dg, x, C, h, C, dwg, grid, 2 * C, bs1=bsx)
         if ctx.has_bias[0] and ctx.needs_input_grad[3]:
             dbg = co.colsum(dg.reshape(M, 2 * C))
@@ -314,7 +314,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         co.conv3_launch(dc, C, None, 0, wo, None, dhr, grid, C, dgrad=True)
         dwo = dbo = dwg = dbg = None
         if ctx.needs_input_grad[5]:
-            dwo = torch.zeros_like(wo)
+            dwo = co.grad_zeros(wo.shape, wo.device)
             co.conv3_wgrad(dc, hr, C, None, 0, dwo, grid, C)
         if ctx.has_bias[1] and ctx.needs_input_grad[6]:
             dbo = co.colsum(dc.reshape(M, C))
@@ -323,7 +323,7 @@ class _GRUCellPreRows(torch.autograd.Function):
         dh_total = new(C)                                          # dh (state + reset paths) + conv^T(dg, Wg_h), added in the GEMM epilogue
         co.conv3_launch(dg, 2 * C, None, 0, wg, None, dh_total, grid, C, residual=dh, dgrad=True)
         if ctx.needs_input_grad[3]:
-            dwg = torch.zeros_like(wg)
+            dwg = co.grad_zeros(wg.shape, wg.device)
             co.conv3_wgrad(dg, h, C, None, 0, dwg, grid, 2 * C)
         if ctx.has_bias[0] and ctx.needs_input_grad[4]:
             dbg = co.colsum(dg.reshape(M, 2 * C))
@@ -532,7 +532,7 @@ class _FuseGroupsTrain(torch.autograd.Function):
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         newV = lambda rows, c: torch.empty(16, rows, c, dtype=torch.float32, device=dev)
         UT = {k: co.wino_pack_packed(v, transpose=True) for k, v in packs.items()}     # Winograd-domain data-gradient weights [16][3][Cin][Cout]
-        dU = {k: torch.zeros(16, 3, v.shape[1], v.shape[2], dtype=torch.float32, device=dev) for k, v in packs.items()}
+        dU = {k: co.grad_zeros((16, 3, v.shape[1], v.shape[2]), dev) for k, v in packs.items()}
         Mm = newV(R, 2 * C)
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
 
@@ -623,7 +623,7 @@ class _FuseGroupsTrain(torch.autograd.Function):
             """G^T dU G of the listed halves, concatenated along Cin, in the nn.Conv3d layout [Cout, Cin, 3, 3, 3]"""
             parts = []
             for k in keys:
-                dwp = torch.zeros_like(packs[k])
+                dwp = co.grad_zeros(packs[k].shape, dev)
                 _lib.check(L.forge_wino_dw(p(dU[k]), p(dwp), dwp.shape[1], dwp.shape[2], 3, st()), "forge_wino_dw")
                 parts.append(dwp)
             dwp = parts[0] if len(parts) == 1 else torch.cat(parts, dim=2)

@@ -340,7 +340,8 @@ class _FuseFrozen(torch.autograd.Function):
 
     @staticmethod
     @_lib.on_tensor_device
-    def forward(ctx, x, gru):
+    def forward(ctx, x, gru, skip_dx0=False):
+        ctx.skip_dx0 = bool(skip_dx0)
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
         xr = xr if xr.is_contiguous() else xr.contiguous()
@@ -414,6 +415,17 @@ class _FuseFrozen(torch.autograd.Function):
             h, z, r, cand = steps[ti]
             dh, dz, dc, dg = new(), new(), new(), new(2 * C)
             _lib.check(L.forge_gru_state_bwd(ptr(dhn), ld_dhn, ptr(h), ptr(z), ptr(cand), ptr(dh), ptr(dz), ptr(dc), M, C, None, 0, 0, 0, st()), "forge_gru_state_bwd")
+            if ti == 0 and ctx.skip_dx0:
+                # the first view of the sequence is the un-warped reference view and the caller needs no gradient for it (pose refinement: frozen
+                # features, the reference pose is fixed): both data gradients produce their hidden-state half only (N = C instead of 2C)
+                dhr = dgrad(dc, C, "out_h", new(), C)
+                dhp = new()
+                _lib.check(L.forge_gru_gates_bwd(ptr(dz), ptr(dhr), C, ptr(h), ptr(z), ptr(r), ptr(dg), ptr(dh), ptr(dhp), C, M, C, None, 0, 0, 0, st()),
+                           "forge_gru_gates_bwd")
+                toth = dgrad(dg, 2 * C, "gate_h", new(), C, residual=dhp)
+                dx[:, 0].zero_()
+                dhn, ld_dhn = toth, C
+                continue
             dxh = new(2 * C)                                                 # (d x_t | d (h r)) of the candidate conv
             dgrad(dc, C, "out", dxh, 2 * C)
             # dg = gate pre-activation gradients; dh + d(hr) r lands in dxh's right half (over d(hr)): dxh = (dx_t part 1 | dh partial)
@@ -432,7 +444,7 @@ class _FuseFrozen(torch.autograd.Function):
         affine_act_bwd(g2, t0, p["bn1_scale"], 0.01, out=g)
         dgrad(g, C, "fc0", g2, C)
         dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
-        return dx.permute(0, 1, 5, 2, 3, 4), None
+        return dx.permute(0, 1, 5, 2, 3, 4), None, None
 
 
 class _FuseGroupsTrain(torch.autograd.Function):
@@ -708,13 +720,20 @@ class ConvGRU_3D(co.PackedModule):
             p.update({"gate_wT": tr(p["gate_w"]), "out_wT": tr(p["out_w"]), "fc0_wT": tr(p["fc0_w"]), "fc3_wT": tr(p["fc3_w"]),
                       "norm_scale": p["norm"][0], "bn1_scale": p["bn1"][0], "bn4_scale": p["bn4"][0]})
             p.update({k + "_UT": co.wino_pack_packed(p[k + "_w"], transpose=True) for k in ("gate", "out", "fc0", "fc3")})   # Winograd-domain data-gradient weights
+            C = self.hidden_size
+            for k in ("gate", "out"):                                   # the hidden-state halves alone (data gradient w.r.t. h only: _FuseFrozen skip_dx0)
+                p[k + "_h_w"] = p[k + "_w"][:, :, C:].contiguous()
+                p[k + "_h_wT"] = p[k + "_h_w"].transpose(1, 2).contiguous()
+                p[k + "_h_UT"] = p[k + "_UT"][:, :, C:, :].contiguous()
         return p
 
-    def fuse_frozen_hip(self, x):
-        """Encoder3D.fuse with frozen weights under autograd (pose refinement): fused forward, hand-written data-gradient backward."""
+    def fuse_frozen_hip(self, x, skip_dx0=False):
+        """Encoder3D.fuse with frozen weights under autograd (pose refinement): fused forward, hand-written data-gradient backward.
+        skip_dx0: the caller needs no gradient for view 0 of the sequence (the un-warped reference view of a refinement problem): its slice of
+        the returned gradient is zero and the last backward step produces the hidden-state halves of its two data gradients only."""
         assert self.n_layers == 1 and self.input_size == self.hidden_size
         require_hip_input("ConvGRU_3D.fuse_frozen_hip", x, x.shape[2])
-        return _FuseFrozen.apply(x, self)
+        return _FuseFrozen.apply(x, self, bool(skip_dx0))
 
     def fuse_hip(self, x, h0=None):
         """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs (or the caller's h0

@@ -72,7 +72,9 @@ def _render_views_fused(model, config, dataset, features, rot, trans, K, device,
     can_p, can_e = canonical
     xf, cam, mode, slot, poses, origin = ops.pose_chain(rot, trans, can_p, can_e, K, model.rotate.half_extent(D), b, t)
     ft = ops.rotate_warp(features.reshape(b * t, C, D, D, D), xf, mode, slot).reshape(b, t, C, D, D, D)       # stored in sequence_from_distance's order
-    fused = model.encoder_3d.fuse(ft)
+    # slot 0 always holds view 0 (distance 0, ties broken by index): the fixed reference view, copied un-warped from frozen features - nothing
+    # differentiable lies behind it, so the fusion's backward skips the input-half data gradients of that step
+    fused = model.encoder_3d.fuse(ft, skip_dx0=not features.requires_grad)
     feat, dens = model.encoder_3d.heads(fused)
     v2v = torch.arange(b, device=device, dtype=torch.int32).repeat_interleave(t)
     imgs, masks, depths, origin = model.render({"packed": cam, "origin": origin}, feat, dens, return_origin_proj=True, render_depth=True, view2vol=v2v)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs a
 // it: each wave owns every 4th tap (<= 7 accumulator tiles), one ds_read_b32 per operand per MFMA, conflict-free (a half-wave reads
 // 32 consecutive floats of one LDS row). Workgroups walk segments grid-stride with the next segment's global loads in flight under the
 // current segment's MFMAs, and add their partial 32x32 tiles to dW with fp32 atomics once at the end.
-constexpr int LSEG = 32, LMAXL = 9, LMAXR = 2, LROWS = LSEG + 2 * LMAXR, LTAPS = 7;
+constexpr int LSEG = 32, LMAXL = 9, LMAXR = 3, LROWS = LSEG + 2 * LMAXR, LTAPS = 7;
 
 struct LineTable { signed char dz[LMAXL], dy[LMAXL]; int nlines, rx; };
 
@@ -351,14 +351,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_lines_kernel(const WgradArgs a
 // input channel); CIT = 16: one MFMA. dYs rows are 16 floats, so the four voxel rows a wave-instruction reads fall into disjoint banks.
 typedef __attribute__((ext_vector_type(4))) float f32x4w;
 
-template <int CIT>
-__global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_kernel(const WgradArgs a, const LineTable lt) {
+// IS = 2 (CIT = 16, LT = 9 taps per wave): the gathered operand lives on the 2x finer grid (voxel m reads row 2 m + tap) - the weight gradient of
+// a stride-2 transposed convolution (conv_rgb's ConvTranspose2d(16, 16, 6, stride 2): 36 taps on 6 lines, |dx| <= 3), whose staged X segment is
+// 2 LSEG - 1 + 2 rx rows long and is read with a row stride of 2.
+template <int CIT, int IS = 1, int LT = LTAPS>
+__global__ __launch_bounds__(256, (CIT == 16 && IS == 1) ? 4 : 3) void conv_wgrad_lines16_kernel(const WgradArgs a, const LineTable lt) {
     constexpr int NT = CIT / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // dYs [LSEG][16] | Xs [nlines][LSEG + 2 rx][CIT]
     float* dYs = smem;
     float* Xs = smem + LSEG * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int Cin = a.C1, xrows = LSEG + 2 * lt.rx;
+    const int Cin = a.C1, xrows = (LSEG - 1) * IS + 1 + 2 * lt.rx;
     const int nsx = (a.W + LSEG - 1) / LSEG;
     const long long nseg = (long long)a.n * a.D * a.H * nsx;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_ker
     const int c4 = (tid % TPR) << 2, srow = tid / TPR;
     const int yc4 = (tid & 3) << 2, yrow = tid >> 2;
     const int xchunks = lt.nlines * xrows;
-    constexpr int XP = (LMAXL * LROWS + RPP - 1) / RPP;
+    constexpr int XP = ((IS == 2 ? 6 : LMAXL) * ((LSEG - 1) * IS + 1 + 2 * LMAXR) + RPP - 1) / RPP;   // IS = 2: <= 6 lines (host)
     float4 ry4 = make_float4(0.f, 0.f, 0.f, 0.f), rx4[XP];
     auto load_seg = [&](long long sg) {
         long long q = sg;
@@ -387,9 +390,9 @@ __global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_ker
             unsigned off = OOBW;
             if (r < xchunks && c4 < Cin) {
                 const int ln = r / xrows, xr = r - ln * xrows;
-                const int zi = z + lt.dz[ln], yi = y + lt.dy[ln], xi = x0 - lt.rx + xr;
-                if ((unsigned)zi < (unsigned)a.D && (unsigned)yi < (unsigned)a.H && (unsigned)xi < (unsigned)a.W)
-                    off = (unsigned)((((long long)nn * a.bs1r + ((long long)zi * a.H + yi) * a.W + xi) * a.ld1 + c4) * 4);
+                const int zi = z * IS + lt.dz[ln], yi = y * IS + lt.dy[ln], xi = x0 * IS - lt.rx + xr;
+                if ((unsigned)zi < (unsigned)a.Di && (unsigned)yi < (unsigned)a.Hi && (unsigned)xi < (unsigned)a.Wi)
+                    off = (unsigned)((((long long)nn * a.bs1r + ((long long)zi * a.Hi + yi) * a.Wi + xi) * a.ld1 + c4) * 4);
             }
             rx4[p] = buf_load16w(rx_, off);
         }
@@ -402,18 +405,18 @@ __global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_ker
             if (r < xchunks) *reinterpret_cast<float4*>(Xs + r * CIT + c4) = rx4[p];
         }
     };
-    int tb[LTAPS];
-    bool tok[LTAPS];
+    int tb[LT];
+    bool tok[LT];
 #pragma unroll
-    for (int j = 0; j < LTAPS; ++j) {
+    for (int j = 0; j < LT; ++j) {
         const int t = wave + 4 * j;
         tok[j] = t < a.ntaps;
         const int tt = tok[j] ? t : 0;
         tb[j] = (a.tap[tt][3] * xrows + a.tap[tt][2] + lt.rx) * CIT;  // (line, dx + rx)
     }
-    f32x4w acc[LTAPS][NT];
+    f32x4w acc[LT][NT];
 #pragma unroll
-    for (int j = 0; j < LTAPS; ++j)
+    for (int j = 0; j < LT; ++j)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -431,21 +434,21 @@ __global__ __launch_bounds__(256, CIT == 16 ? 4 : 3) void conv_wgrad_lines16_ker
             const int row = 4 * k + kq;
             const float fa = dYs[row * 16 + l15];
 #pragma unroll
-            for (int j = 0; j < LTAPS; ++j) {
+            for (int j = 0; j < LT; ++j) {
                 if (!tok[j]) continue;                               // wave-uniform
                 if constexpr (NT == 2) {
-                    const float2 fb = *reinterpret_cast<const float2*>(Xs + tb[j] + row * CIT + 2 * l15);     // input channels 2 l15, 2 l15 + 1
+                    const float2 fb = *reinterpret_cast<const float2*>(Xs + tb[j] + row * (CIT * IS) + 2 * l15);     // input channels 2 l15, 2 l15 + 1
                     acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb.x, acc[j][0], 0, 0, 0);
                     acc[j][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb.y, acc[j][1], 0, 0, 0);
                 } else {
-                    const float fb = Xs[tb[j] + row * CIT + l15];
+                    const float fb = Xs[tb[j] + row * (CIT * IS) + l15];
                     acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[j][0], 0, 0, 0);
                 }
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < LTAPS; ++j) {
+    for (int j = 0; j < LT; ++j) {
         if (!tok[j]) continue;
         const int t = wave + 4 * j;
 #pragma unroll
@@ -528,8 +531,9 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
         a.tap[t][3] = 0;
     }
     const int Cin = C1 + C2;
-    if (Cout <= 32 && Cin <= 32 && x2 == nullptr && is == 1 && Di == D && Hi == H && Wi == W && ntaps <= 4 * LTAPS) {
-        // taps grouped by (dz, dy) line; usable when <= 9 lines and |dx| <= 2
+    const bool lines_s2 = is == 2 && Cout <= 16 && Cin <= 16 && ntaps <= 4 * 9;     // stride-2 gathered operand: the 16x16 kernel only
+    if (Cout <= 32 && Cin <= 32 && x2 == nullptr && ((is == 1 && Di == D && Hi == H && Wi == W && ntaps <= 4 * LTAPS) || lines_s2)) {
+        // taps grouped by (dz, dy) line; usable when <= 9 lines and |dx| <= 3
         LineTable lt;
         lt.nlines = 0; lt.rx = 0;
         bool ok = true;
@@ -542,7 +546,7 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
             for (int i = 0; i < lt.nlines; ++i)
                 if (lt.dz[i] == dz && lt.dy[i] == dy_) ln = i;
             if (ln < 0) {
-                if (lt.nlines == LMAXL) { ok = false; break; }
+                if (lt.nlines == (lines_s2 ? 6 : LMAXL)) { ok = false; break; }
                 ln = lt.nlines++;
                 lt.dz[ln] = (signed char)dz; lt.dy[ln] = (signed char)dy_;
             }
@@ -553,6 +557,14 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
             const size_t lds = (size_t)(LSEG * 32 + lt.nlines * (LSEG + 2 * lt.rx) * 32) * sizeof(float);
             FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines_kernel, (LSEG * 32 + LMAXL * LROWS * 32) * sizeof(float));
             a.mchunk = 0;
+            if (lines_s2) {
+                const size_t lds16 = (size_t)(LSEG * 16 + lt.nlines * (2 * LSEG - 1 + 2 * lt.rx) * 16) * sizeof(float);
+                const long long grid16 = nseg < 768 ? nseg : 768;                   // 3 resident workgroups per CU
+                FORGE_SET_MAX_LDS_ONCE((conv_wgrad_lines16_kernel<16, 2, 9>), (LSEG * 16 + 6 * (2 * LSEG - 1 + 2 * LMAXR) * 16) * sizeof(float));
+                hipLaunchKernelGGL((conv_wgrad_lines16_kernel<16, 2, 9>), dim3((unsigned)grid16), dim3(256), lds16, (hipStream_t)stream, a, lt);
+                FORGE_LAUNCH_CHECK("forge_conv_wgrad");
+                return 0;
+            }
             if (Cout <= 16) {
                 // narrow outputs: the 16x16x4 MFMA tile (no 32-row padding); 4 workgroups per CU walk the segments
                 const int cit = Cin <= 16 ? 16 : 32;

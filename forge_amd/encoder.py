@@ -205,14 +205,15 @@ class Encoder3D(co.PackedModule):
             return _HeadsFrozen.apply(z_3d, self)                        # refinement: fused forward, data-gradient-only backward
         return self.get_render_features(z_3d), self.get_density3D(z_3d)
 
-    def fuse(self, x, skip_dx0=False):
+    def fuse(self, x, skip_dx0=False, const0=None):
         """x [b,t,c,d,h,w] -> [b,c,d,h,w] (models/encoder.py:59-63). skip_dx0 (frozen weights under autograd only): the caller needs no gradient
-        for view 0 of the sequence - the fixed, un-warped reference view of a pose-refinement problem (ConvGRU_3D.fuse_frozen_hip)."""
+        for view 0 of the sequence - the fixed, un-warped reference view of a pose-refinement problem (ConvGRU_3D.fuse_frozen_hip); const0: that
+        view is also the SAME in every call made with this dict (its input-half products are computed once and kept there)."""
         if hip_inference(self, x):
             return self.fusion_feature.fuse_hip(x)
         require_hip_input("Encoder3D.fuse", x)
         if frozen_eval(self.fusion_feature, x) and self.fusion_feature.n_layers == 1:
-            return self.fusion_feature.fuse_frozen_hip(x, skip_dx0=skip_dx0)     # refinement: fused forward, data-gradient-only backward
+            return self.fusion_feature.fuse_frozen_hip(x, skip_dx0=skip_dx0, const0=const0)     # refinement: fused forward, data-gradient-only backward
         return self.fusion_feature.fuse_autograd_hip(x)                 # training: HIP convs with autograd
 
     def fuse_groups(self, x, groups):

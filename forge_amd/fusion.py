@@ -340,7 +340,7 @@ class _FuseFrozen(torch.autograd.Function):
 
     @staticmethod
     @_lib.on_tensor_device
-    def forward(ctx, x, gru, skip_dx0=False):
+    def forward(ctx, x, gru, skip_dx0=False, const0=None):
         ctx.skip_dx0 = bool(skip_dx0)
         b, t, C, D, H, W = x.shape
         xr = x.permute(0, 1, 3, 4, 5, 2)
@@ -360,15 +360,36 @@ class _FuseFrozen(torch.autograd.Function):
             Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
             Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
             gru._wino_h0(p, xr, grid, Vh, Mc, t0, h, nsum=t, sum_stride=vol, bs=t * vol)
+            # const0 (a dict the caller keeps across calls; with skip_dx0): view 0 holds the SAME values in every call (the un-warped reference
+            # view of frozen features, kubric_eval.py:456-470) - the point products of its input halves, V_x0 (x) U_x of both GRU convolutions,
+            # are made once and added inside the inverse transforms of step 0, whose GEMMs then contract the hidden-state half only (K = 3 C
+            # instead of 6 C). Same arithmetic up to the order of the fp32 additions (the halves meet before A^T . A instead of inside the K loop).
+            hoist = const0 is not None and skip_dx0
+            if hoist:
+                ps = gru._packed_wino_halves()
+                if "MXg0" not in const0:
+                    Vx0 = co.wino_input(xr[:, 0], C, C, b, D, H, W, bs=t * vol)
+                    const0["MXg0"] = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
+                    const0["MXc0"] = torch.empty(16, R, C, dtype=torch.float32, device=dev)
+                    co.wino_gemm(Vx0, C, None, 0, ps["gate_Ux"], const0["MXg0"], b, D, Ht, Wt, 2 * C)
+                    co.wino_gemm(Vx0, C, None, 0, ps["out_Ux"], const0["MXc0"], b, D, Ht, Wt, C)
             for ti in range(t):
                 z, hr, r, hn, cand = new(), new(), new(), new(), new()
+                first = hoist and ti == 0
                 co.wino_input(h, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t)
-                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, r, *grid, 2 * C, C, co.EPI_GRU_GATES)
+                if first:
+                    co.wino_gemm(Vh, C, None, 0, ps["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C)
+                else:
+                    co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t)
+                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, r, *grid, 2 * C, C, co.EPI_GRU_GATES,
+                               Mm2=const0["MXg0"] if first else None)
                 co.wino_input(hr, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t)
+                if first:
+                    co.wino_gemm(Vh, C, None, 0, ps["out_Uh"], Mc, b, D, Ht, Wt, C)
+                else:
+                    co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t)
                 co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, hn, out if ti == t - 1 else None, cand, *grid, C, C,
-                               co.EPI_GRU_OUT)
+                               co.EPI_GRU_OUT, Mm2=const0["MXc0"] if first else None)
                 steps.append((h, z, r, cand))
                 h = hn
         else:
@@ -444,7 +465,7 @@ class _FuseFrozen(torch.autograd.Function):
         affine_act_bwd(g2, t0, p["bn1_scale"], 0.01, out=g)
         dgrad(g, C, "fc0", g2, C)
         dx.add_(g2.reshape(b, 1, D, H, W, C), alpha=1.0 / t)
-        return dx.permute(0, 1, 5, 2, 3, 4), None, None
+        return dx.permute(0, 1, 5, 2, 3, 4), None, None, None
 
 
 class _FuseGroupsTrain(torch.autograd.Function):
@@ -727,13 +748,16 @@ class ConvGRU_3D(co.PackedModule):
                 p[k + "_h_UT"] = p[k + "_UT"][:, :, C:, :].contiguous()
         return p
 
-    def fuse_frozen_hip(self, x, skip_dx0=False):
+    def fuse_frozen_hip(self, x, skip_dx0=False, const0=None):
         """Encoder3D.fuse with frozen weights under autograd (pose refinement): fused forward, hand-written data-gradient backward.
         skip_dx0: the caller needs no gradient for view 0 of the sequence (the un-warped reference view of a refinement problem): its slice of
-        the returned gradient is zero and the last backward step produces the hidden-state halves of its two data gradients only."""
+        the returned gradient holds only the fusion_conv(mean) share and the last backward step produces the hidden-state halves of its two data gradients only.
+        const0 (with skip_dx0; a dict the caller owns, initially empty): the caller PROMISES that view 0 holds the same values in every call made
+        with this dict and that the weights do not change meanwhile - the products of view 0's input halves are then computed by the first call
+        only (kept in the dict) and step 0 of later calls contracts the hidden-state half alone."""
         assert self.n_layers == 1 and self.input_size == self.hidden_size
         require_hip_input("ConvGRU_3D.fuse_frozen_hip", x, x.shape[2])
-        return _FuseFrozen.apply(x, self, bool(skip_dx0))
+        return _FuseFrozen.apply(x, self, bool(skip_dx0), const0)
 
     def fuse_hip(self, x, h0=None):
         """Encoder3D.fuse on the MI355X: h0 = fusion_conv(mean_t x) as two fused conv+BN+LeakyReLU GEMMs (or the caller's h0
@@ -782,6 +806,19 @@ class ConvGRU_3D(co.PackedModule):
             cell, fc = self.cells[0], self.fusion_conv
             p.update({"gate_U": co.wino_pack_weight(cell.conv_gate.weight), "out_U": co.wino_pack_weight(cell.out_gate.weight),
                       "fc0_U": co.wino_pack_weight(fc[0].weight), "fc3_U": co.wino_pack_weight(fc[3].weight)})
+        return p
+
+    def _packed_wino_halves(self):
+        """The input (x) and hidden-state (h) halves of the two GRU convolutions as separate Winograd-domain weights [16][3][Cout][C]
+        (the frozen-weight refinement forward with a hoisted reference view, _FuseFrozen)."""
+        p = self._packed_wino()
+        if "gate_Ux" not in p:
+            C = self.hidden_size
+            cell = self.cells[0]
+            for k, w in (("gate", cell.conv_gate.weight), ("out", cell.out_gate.weight)):
+                wp = co.pack_conv3d_weight(w)                                # [27][Cout][2 C]: (x | h) input channels
+                p[k + "_Ux"] = co.wino_pack_packed(wp[:, :, :C].contiguous())
+                p[k + "_Uh"] = co.wino_pack_packed(wp[:, :, C:].contiguous())
         return p
 
     @staticmethod

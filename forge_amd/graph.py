@@ -40,6 +40,8 @@ class GraphedForward:
             for k, v in sample.items():
                 if torch.is_tensor(v) and v is not self.static_in[k]:
                     self.static_in[k].copy_(v, non_blocking=True)
+                    if v.is_cuda:                         # the copy reads v on the CURRENT stream (PipelinedForward: a private one): the caching
+                        v.record_stream(torch.cuda.current_stream(self.device))   # allocator must not hand v's block out again before it ran
         self.graph.replay()
         return self.static_out
 
@@ -56,8 +58,12 @@ class PipelinedForward:
     outputs (tools/pipeline_probe.py). This is a throughput device: the latency of one step stays that of a single replay.
 
         p = PipelinedForward(model, sample, dataset, device, depth=3)
-        for s in samples: out = p(s)        # returns the static outputs of the slot used; valid after p.wait() / overwritten `depth` calls later
+        for s in samples: out = p(s)        # returns the static outputs of the slot used; valid ONLY after p.wait(), overwritten `depth` calls later
         p.wait()
+
+    The sample's device tensors are read by a copy on the slot's private stream (ordered after the caller's stream; `record_stream` keeps their
+    memory from being reused before the copy ran): the caller may drop or let the allocator recycle a sample right after p(sample), but must
+    not overwrite it IN PLACE before p.wait() (or an event on the slot's stream) - the copy may still be pending.
     """
 
     def __init__(self, model, sample, dataset, device, depth=3, warmup=3):

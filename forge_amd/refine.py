@@ -63,7 +63,7 @@ class _SmallAdam:
                                                        self.betas[0], self.betas[1], self.eps, _lib.current_stream()), "forge_adam_small")
 
 
-def _render_views_fused(model, config, dataset, features, rot, trans, K, device, canonical):
+def _render_views_fused(model, config, dataset, features, rot, trans, K, device, canonical, const0=None):
     """_render_views with the pose algebra on ONE HIP launch (ops.pose_chain: raw quaternion / translation -> warp affine + packed cameras, Jacobian
     by forward-mode differentiation) instead of ~250 torch launches per iteration; what the refinement loop runs. Same outputs."""
     from . import ops
@@ -74,7 +74,8 @@ def _render_views_fused(model, config, dataset, features, rot, trans, K, device,
     ft = ops.rotate_warp(features.reshape(b * t, C, D, D, D), xf, mode, slot).reshape(b, t, C, D, D, D)       # stored in sequence_from_distance's order
     # slot 0 always holds view 0 (distance 0, ties broken by index): the fixed reference view, copied un-warped from frozen features - nothing
     # differentiable lies behind it, so the fusion's backward skips the input-half data gradients of that step
-    fused = model.encoder_3d.fuse(ft, skip_dx0=not features.requires_grad)
+    # (and, with frozen features, it holds the same values in every iteration: const0, the caller's dict, keeps its input-half products)
+    fused = model.encoder_3d.fuse(ft, skip_dx0=not features.requires_grad, const0=None if features.requires_grad else const0)
     feat, dens = model.encoder_3d.heads(fused)
     v2v = torch.arange(b, device=device, dtype=torch.int32).repeat_interleave(t)
     imgs, masks, depths, origin = model.render({"packed": cam, "origin": origin}, feat, dens, return_origin_proj=True, render_depth=True, view2vol=v2v)
@@ -101,10 +102,13 @@ class PoseRefiner:
         self.w_rgb, self.w_mask = config.loss.recon_rgb, config.loss.recon_mask     # (the reference's ExponentialLR has gamma = 1: a constant rate)
         self.use_graph, self.graph, self.static_loss = bool(use_graph), None, None
         self.stream = stream
+        # iteration-invariant products of the reference view (slot 0: frozen features, fixed pose), filled by the first forward, valid for THIS
+        # instance's features and the model's frozen weights (ConvGRU_3D.fuse_frozen_hip)
+        self.fuse_const = {}
 
     def iteration(self):
         imgs, masks, _, _, _ = _render_views_fused(self.model, self.config, self.dataset, self.features, self.rot, self.trans, self.K, self.device,
-                                                   self.canonical)
+                                                   self.canonical, const0=self.fuse_const)
         loss = self.w_rgb * F.mse_loss(imgs, self.target_imgs) + self.w_mask * F.mse_loss(masks, self.target_masks)
         loss.backward()
         self.opt.step()
@@ -115,6 +119,10 @@ class PoseRefiner:
         return self.iteration()
 
     def capture(self):
+        if not self.fuse_const:                          # the hoisted products must exist BEFORE the capture (else they would be recomputed,
+            with torch.no_grad():                        # inside the graph's pool, by every replay): one forward pass, no optimiser step
+                _render_views_fused(self.model, self.config, self.dataset, self.features, self.rot, self.trans, self.K, self.device, self.canonical,
+                                    const0=self.fuse_const)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)             # gradients are (re)allocated inside the graph's private pool

@@ -145,7 +145,7 @@ int main(void) {
             CHECK_HIP(hipMemset(d_y, 0xff, (size_t)Mr * Cc * sizeof(float)));
             CHECK_FORGE(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL,
                                          1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc, taps, 1, 1, 0, 0, 0, 4, 8, 8, /*epilogue*/ 0, /*lift*/ 0,
-                                         pass ? 'D' : 0, 1, NULL, 0, (forge_stream_t)st));
+                                         pass ? 'D' : 0, 1, NULL, 0, /*stats*/ NULL, (forge_stream_t)st));
             CHECK_HIP(hipStreamSynchronize(st));
             CHECK_HIP(hipMemcpy(h_y, d_y, (size_t)Mr * Cc * sizeof(float), hipMemcpyDeviceToHost));
             for (int i = 0; i < Mr * Cc; ++i) EXPECT(h_y[i] == h_x[i] + 0.25f, "identity 1x1 convolution + bias must reproduce x + 0.25 exactly");
@@ -154,7 +154,7 @@ int main(void) {
         CHECK_FORGE(forge_conv_igemm_plan(32768, 256, 256, 27, 1, 2, 128, 0, &tile, &ks));
         EXPECT(tile >= 'A' && tile <= 'E' && ks == 1, "the plan query must name a tile A..E and no split-K without a workspace");
         EXPECT(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL, 1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc,
-                                taps, 1, 1, 0, 0, 0, 4, 8, 8, 0, 0, 'Z', 1, NULL, 0, (forge_stream_t)st) == FORGE_EINVAL, "an unknown tile letter must be refused");
+                                taps, 1, 1, 0, 0, 0, 4, 8, 8, 0, 0, 'Z', 1, NULL, 0, NULL, (forge_stream_t)st) == FORGE_EINVAL, "an unknown tile letter must be refused");
     }
     /* ---------------- bilinear x2 of a constant plane and of a column ramp (align_corners = False: interior values are the 0.25 / 0.75 blends) */
     {

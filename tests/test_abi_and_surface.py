@@ -30,6 +30,22 @@ def test_header_symbols_exported(built_lib):
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_c_host_program_compiles_against_the_header():
+    """tests/c_host/c_abi_smoke.c (the plain-C driver of the boundary, run on the GPU by tests/test_gpu_c_host.py) must compile against the
+    CURRENT include/forge_hip.h: a changed entry-point signature is caught here, on the CPU, not at round end."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("needs gcc and the HIP runtime headers")
+    r = subprocess.run([gcc, "-std=c11", "-fsyntax-only", "-Werror=implicit-function-declaration", "-I", os.path.join(rocm, "include"),
+                        "-I", os.path.join(root, "include"), "-D__HIP_PLATFORM_AMD__", os.path.join(root, "tests", "c_host", "c_abi_smoke.c")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+
+
 def test_version_and_error_codes(built_lib):
     l = _lib.lib()
     assert l.forge_version() >= 100

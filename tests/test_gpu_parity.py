@@ -876,6 +876,39 @@ def test_graphed_forward_matches_eager(dev):
     assert not torch.equal(o1[0], o2[0])
 
 
+def test_pipelined_forward_matches_eager_with_samples_dropped_after_the_call(dev):
+    """PipelinedForward (several hipGraph replays in flight on private streams): every step's outputs equal the eager forward bit for bit,
+    also when the caller drops each sample right after p(sample) and allocates other tensors of the same size on its own stream (a
+    data-loader loop): the sample's memory is held (record_stream) until the slot's copy has read it."""
+    from forge_amd.graph import PipelinedForward
+    from forge_amd.model import FORGE
+    cfg = syn.kubric_config()
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+    ds = syn.SyntheticDataset(1.5)
+    host = [syn.make_sample(1, 5, 256, 1.5, seed=20 + i) for i in range(5)]
+    with torch.no_grad():
+        eager = [[t.clone() for t in model({k: v.to(dev) for k, v in h.items()}, ds, dev)] for h in host]
+    p = PipelinedForward(model, {k: v.to(dev) for k, v in host[0].items()}, ds, dev, depth=3, warmup=1)
+    for rnd in range(2):                                   # 10 calls on 3 slots: every slot is reused
+        outs = []
+        for i, h in enumerate(host):
+            s = {k: v.to(dev) for k, v in h.items()}
+            o = p(s)
+            shapes = [v.shape for v in s.values() if torch.is_tensor(v)]
+            del s                                          # the allocator may now recycle the blocks ...
+            junk = [torch.full(sh, float("nan"), device=dev) for sh in shapes]      # ... and the caller's stream writes same-sized tensors at once
+            if (i + 1) % 3 == 0 or i == len(host) - 1:     # outputs of a slot are valid after wait() and until the slot's next call
+                p.wait()
+                torch.cuda.synchronize()
+                outs.append((i, [t.clone() for t in o]))
+            del junk
+        for i, o in outs:
+            for a, b in zip(eager[i], o):
+                assert torch.equal(a, b), (rnd, i)
+
+
 def test_render_360_vs_oracle(dev):
     """row f3: 28-view orbit + depth from ONE volume in one launch vs the oracle renderer fed the same (quirky) cameras."""
     from forge_amd import nvs

@@ -181,6 +181,40 @@ def test_frozen_fusion_winograd_matches_direct(monkeypatch):
     assert rel(res["1"][1], res["0"][1]) < 1e-3        # sign flips of LeakyReLU arguments within 1e-6 of zero move single elements (test_gpu_configs)
 
 
+def test_frozen_fusion_hoisted_reference_view_equals_the_plain_frozen_fusion():
+    """_FuseFrozen with const0 (pose refinement: view 0 is the fixed, un-warped reference view of frozen features - its input-half point
+    products are made once and added inside step 0's inverse transforms, whose GEMMs contract the hidden-state half only): over three
+    "iterations" that change views 1.. but not view 0, and two scenes, output and input gradient equal the plain skip_dx0 form to fp32
+    rounding (only the order of additions differs); the dict is filled by the first call and reused."""
+    from forge_amd import synthetic as syn
+    from forge_amd.fusion import ConvGRU_3D
+    dev = _dev()
+    gru = ConvGRU_3D(syn.kubric_config(), n_layers=1, input_size=128, hidden_size=128)
+    gru.load_state_dict(syn.seeded_state_dict(gru.state_dict(), 3))
+    gru = gru.to(dev).eval()
+    for p_ in gru.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(2, 1, 128, 8, 8, 8, generator=g) * 0.5).to(dev)
+    wgt = torch.randn(2, 128, 8, 8, 8, generator=g).to(dev)
+    const0 = {}
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    for it in range(3):
+        rest = (torch.randn(2, 3, 128, 8, 8, 8, generator=g) * 0.5).to(dev)
+        outs = []
+        for c in (const0, None):
+            xi = torch.cat([x0, rest], dim=1).requires_grad_(True)
+            out = gru.fuse_frozen_hip(xi, skip_dx0=True, const0=c)
+            (out * wgt).sum().backward()
+            outs.append((out.detach(), xi.grad))
+        if it == 0:
+            assert set(const0) == {"MXg0", "MXc0"}
+            kept = (const0["MXg0"].data_ptr(), const0["MXg0"].clone())
+        assert const0["MXg0"].data_ptr() == kept[0] and torch.equal(const0["MXg0"], kept[1])      # computed once, never rewritten
+        assert rel(outs[0][0], outs[1][0]) < 2e-6, it
+        assert rel(outs[0][1], outs[1][1]) < 1e-3, it      # (LeakyReLU arguments within rounding of zero may take the other slope, as above)
+
+
 def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     """convops.conv3_wgrad (dMm = A dy A^T, 16 batched wgrad problems, G^T dU G) against float64 autograd and the direct wgrad kernel:
     two-input form with a batch-strided first operand (the GRU cells' layout) and a single-input form."""

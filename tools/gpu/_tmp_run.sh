@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_winograd.py tests/test_gpu_configs.py tests/test_gpu_parity.py -m gpu -q -x -k "frozen or refine or pipelined or conv_rgb" 2>&1 | tail -5
-python tools/refine_probe.py 2>&1 | tail -6
+python -m pytest tests/test_gpu_bnorm.py -m gpu -q -x 2>&1 | tail -2
+TRAIN_SCENES=4 bash tools/gpu/run_trainprof_r4.sh r04_train_b4 > /dev/null 2>&1
+grep -E "finalize|lines16|small_kernel|per step" gpurun_out/r04_train_b4_kernel_stats.txt
+tail -1 gpurun_out/r04_train_b4.log

@@ -348,6 +348,12 @@ def _joint_step(dev, ray_shard):
     5 input + 5 novel views, loss, backward. BatchNorm on running statistics and Dropout off so that two processes are comparable."""
     from forge_amd import synthetic as syn, train
     from forge_amd.model import FORGE
+    # The pose networks of the joint model run on stock PyTorch kernels whose default backward algorithms (MIOpen / rocBLAS) are not
+    # reproducible run to run; their gradients flow back into the trunk / conv1 and made two SINGLE-process runs differ by 5e-3 relative L2
+    # (tools/debug/joint_shard_noise.py). Pinned to their deterministic algorithms the same two runs agree to 2e-6 - what is left is the
+    # distance the test is about: this repo's kernels, sharded vs not.
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    torch.use_deterministic_algorithms(True, warn_only=True)
     cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
     model = FORGE(cfg)
     model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
@@ -361,6 +367,8 @@ def _joint_step(dev, ray_shard):
     loss.backward()
     torch.cuda.synchronize()
     named = dict(model.named_parameters())
+    torch.use_deterministic_algorithms(False)
+    torch.backends.cudnn.deterministic = False
     return float(loss.detach()), losses, {k: named[k].grad.detach().cpu().numpy() for k in JOINT_KEYS}
 
 
@@ -381,22 +389,23 @@ def test_joint_finetune_step_ray_sharded_two_ranks_equal_one_process():
     two ranks (model.render.ray_shard): loss terms and parameter gradients from the pose head, the 3-D pose estimator, the trunk, conv1,
     the GRU, both heads and conv_rgb equal the single-process step on both ranks."""
     import numpy as np
-    res = _spawn2(_joint_worker, timeout=600)
+    # the single-process step FIRST: on a fresh box the first processes to run the stock-torch pose networks find a cold MIOpen kernel cache
+    # and (two ranks racing through it) end up on other solvers than any later process - their gradients then differ by 1e-2 from everybody
+    # else's, and from each other (tools/debug/joint_shard_noise.py with JOINT_SPAWN_FIRST=1); with the cache warmed here all processes agree
     ref_loss, ref_terms, ref_g = _joint_step(torch.device("cuda:0"), False)
-    more = [_joint_step(torch.device("cuda:0"), False)[2] for _ in range(2)]
+    res = _spawn2(_joint_worker, timeout=600)
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-20))
     for r in (0, 1):
         loss, terms, g = res[r]
-        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (r, loss, ref_loss)
+        assert abs(loss - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss)), (r, loss, ref_loss)
         for k, v in ref_terms.items():
-            assert abs(terms[k] - v) <= 1e-5 * max(1.0, abs(v)), (r, k)
+            assert abs(terms[k] - v) <= 1e-6 * max(1.0, abs(v)), (r, k)
         for k, ref in ref_g.items():
-            # the step's parameter gradients are not bit-reproducible run to run (fp32 atomics in the ray-march / weight-gradient kernels feed
-            # ill-conditioned sums: tools/debug/joint_shard_noise.py measures 3e-5 ... 4e-3 relative L2 between two SINGLE-process runs), so the
-            # bound is that noise floor - the largest distance among THREE single-process runs of this very process, the distribution is heavy-tailed -
-            # not zero; the exact hand-over (d volume, d cameras at 1e-5) is pinned by the test above
-            floor = max(rel(more[0][k], ref), rel(more[1][k], ref), rel(more[1][k], more[0][k]))
-            assert rel(g[k], ref) <= max(1e-3, 5.0 * floor), (r, k, rel(g[k], ref), floor)
+            # a FIXED bound (round 3 had to use the run-to-run noise of the step, up to 4e-3): the ray-march backward is deterministic now and the
+            # stock-torch pose networks are pinned to their deterministic algorithms (_joint_step), so two single-process runs agree to <= 3e-6
+            # relative L2 (the weight-gradient kernels' fp32 atomics) and so does the sharded step: measured <= 3.2e-6 on every key
+            # (tools/debug/joint_shard_noise.py)
+            assert rel(g[k], ref) <= 2e-5, (r, k, rel(g[k], ref))
 
 
 def _syncbn_worker(rank, world, port, q):

@@ -619,6 +619,33 @@ def test_conv_rgb_autograd_hip_vs_torch(dev):
         assert rel(bh.float(), br.float()) < 1e-4
 
 
+@pytest.mark.parametrize("n,H,W,k,pad", [(3, 24, 40, 6, 2), (1, 7, 33, 6, 2), (2, 16, 64, 4, 1), (5, 9, 5, 6, 2)])
+def test_narrow_transposed_conv_s2_autograd_vs_torch(dev, n, H, W, k, pad):
+    """ConvTranspose2d(16, 16, k, stride 2) on NHWC rows (conv_rgb[0], models/volume_render.py:29-31) with autograd: forward (phase GEMMs on the
+    narrow-N kernel), data gradient (stride-2 gather GEMM) and weight gradient - conv_wgrad_lines16_kernel<16, 2, 9>: k^2 <= 36 taps on <= 6
+    lines, the gathered operand on the 2x finer grid - against torch's own autograd; widths that are no multiple of the 32-voxel segment,
+    single rows of segments, several images."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(n * 100 + W)
+    x = torch.randn(n, 16, H, W, generator=g)
+    w = torch.randn(16, 16, k, k, generator=g) * 0.1
+    b = torch.randn(16, generator=g) * 0.1
+    gy = torch.randn(n, 16, 2 * H, 2 * W, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2, padding=pad)
+    ref.backward(gy)
+    xd = x.permute(0, 2, 3, 1).reshape(n, 1, H, W, 16).contiguous().to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = co.convT_s2_rows(xd, wd, bd, pad, 2)
+    assert out.shape == (n, 1, 2 * H, 2 * W, 16)
+    out.backward(gy.permute(0, 2, 3, 1).reshape(n, 1, 2 * H, 2 * W, 16).contiguous().to(dev))
+    rel = lambda a, e: (a.cpu() - e).abs().max().item() / max(e.abs().max().item(), 1e-12)
+    assert rel(out.detach()[:, 0].permute(0, 3, 1, 2), ref.detach()) < 3e-5
+    assert rel(xd.grad[:, 0].permute(0, 3, 1, 2), xr.grad) < 1e-4
+    assert rel(wd.grad, wr.grad) < 1e-4
+    assert rel(bd.grad, br.grad) < 1e-4
+
+
 def test_conv_igemm_strided2d_and_transpose_phases(dev):
     from forge_amd import convops as co
     g = torch.Generator().manual_seed(2)

@@ -14,9 +14,14 @@ import test_gpu_ddp as T  # noqa: E402
 
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
-    la, ta, ga = T._joint_step(dev, False)
-    lb, tb, gb = T._joint_step(dev, False)
-    res = T._spawn2(T._joint_worker, timeout=600)
+    if os.environ.get("JOINT_SPAWN_FIRST") == "1":          # the test's order: the two ranks first, then this process
+        res = T._spawn2(T._joint_worker, timeout=600)
+        la, ta, ga = T._joint_step(dev, False)
+        lb, tb, gb = T._joint_step(dev, False)
+    else:
+        la, ta, ga = T._joint_step(dev, False)
+        lb, tb, gb = T._joint_step(dev, False)
+        res = T._spawn2(T._joint_worker, timeout=600)
     rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-20))
     print("loss single a/b: %.8f %.8f  sharded r0/r1: %.8f %.8f" % (la, lb, res[0][0], res[1][0]))
     for k in T.JOINT_KEYS:

@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_bnorm.py -m gpu -q -x 2>&1 | tail -2
-TRAIN_SCENES=4 bash tools/gpu/run_trainprof_r4.sh r04_train_b4 > /dev/null 2>&1
-grep -E "finalize|lines16|small_kernel|per step" gpurun_out/r04_train_b4_kernel_stats.txt
-tail -1 gpurun_out/r04_train_b4.log
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "narrow_transposed" 2>&1 | tail -3
+python tools/debug/joint_shard_noise.py 2>&1 | grep -v Warning | tail -40 > gpurun_out/joint_noise_plain.txt
+JOINT_DETERMINISTIC=1 python tools/debug/joint_shard_noise.py 2>&1 | grep -v Warning | tail -40 > gpurun_out/joint_noise_det.txt
+cat gpurun_out/joint_noise_plain.txt | cut -c1-200
+echo ======
+cat gpurun_out/joint_noise_det.txt | cut -c1-200

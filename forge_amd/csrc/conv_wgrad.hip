@@ -46,22 +46,28 @@ constexpr int WT = 128, WK = 16, WJ = WK / 8;  // tile 128 x 128, K-step 16 voxe
 // CIW = width of the Cin tile: 128 (4 waves as 2 x 2, wave tile 64 co x 64 ci, even/odd interleave on both operands), or for
 // narrow inputs 64 / 32 (4 waves as 4 x 1, wave tile 32 co x CIW ci) so that a Cin <= 64 problem (conv1: 64, the transpose conv
 // of the heads: 32) does not execute a mostly empty 128-wide tile.
-template <int CIW>
+// TG > 1 (single input, Cin <= CIW): the 128 columns of the B image are TG TAPS x CIW channels - column c belongs to tap t TG + c / CIW,
+// channel c % CIW - so a narrow-input problem with many taps (the heads' ConvTranspose3d(128, 32, 4, s2): 64 taps x 32 channels; conv1: 27 x 64)
+// runs the full 128 x 128 tile with its 32 MFMAs per wave and K-step instead of 8 / 16 (4 / 2 x the matrix work per barrier and per staged
+// dY row): a thread's staged chunk simply gathers at ITS tap's offset.
+template <int CIW, int TG = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-    constexpr int P = CIW == 128 ? 2 : 1, Q = CIW == 32 ? 1 : 2;    // accumulators per wave: P co-parities x Q ci-parities
+    constexpr int NWID = CIW * TG;                                  // used columns of the B image
+    static_assert(NWID <= 128 && (TG == 1 || NWID == 128), "tap groups fill the 128-column tile");
+    constexpr int P = NWID == 128 ? 2 : 1, Q = NWID == 32 ? 1 : 2;  // accumulators per wave: P co-parities x Q ci-parities
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][2][WK][WT]: A (dY) and B (X) images, row = voxel, col = channel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = CIW == 128 ? wave >> 1 : wave, wn = CIW == 128 ? wave & 1 : 0;
+    const int wm = NWID == 128 ? wave >> 1 : wave, wn = NWID == 128 ? wave & 1 : 0;
     const int l31 = lane & 31, half = lane >> 5;
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int Cin = a.C1 + a.C2;
-    const int cot = (a.Cout + WT - 1) / WT, cit = (Cin + CIW - 1) / CIW;
+    const int cot = (a.Cout + WT - 1) / WT, cit = TG > 1 ? 1 : (Cin + CIW - 1) / CIW;
     const int nchunk = (int)((M + a.mchunk - 1) / a.mchunk);
     unsigned bid = blockIdx.x;
     const int chunk = bid % nchunk; bid /= nchunk;
     const int ci_t = bid % cit; bid /= cit;
     const int co_t = bid % cot; bid /= cot;
-    const int t = bid;                                              // tap
+    const int t = bid;                                              // tap (TG = 1) / group of TG taps
     const long long mbeg = (long long)chunk * a.mchunk;
     const long long mend = mbeg + a.mchunk < M ? mbeg + a.mchunk : M;
     const int nsteps = (int)((mend - mbeg + WK - 1) / WK);
@@ -73,11 +79,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const forge_v4i32 rx = make_rsrc_words(second ? a.x2 + pb * a.pt2 : a.x1 + pb * a.pt1, second ? a.span2 : a.span1);
     const int ldx = second ? a.ld2 : a.ld1, cx0 = second ? ci0 - a.C1 : ci0, Cx = second ? a.C2 : a.C1;
     const long long bsx = second ? a.bs2r : a.bs1r;
-    const int dz = a.tap[t][0], dy_ = a.tap[t][1], dx = a.tap[t][2];
-
     // staging: tile rows = 32 voxels, 32 chunks of 16 B per row; thread -> (row = (tid >> 5) + 8 j, chunk = tid & 31)
     const int sc4 = (tid & 31) << 2;
-    const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = sc4 < CIW && cx0 + sc4 < Cx;
+    const int tg = TG > 1 ? sc4 / CIW : 0, sc4c = TG > 1 ? sc4 % CIW : sc4;      // this thread's chunk: tap t TG + tg, channel sc4c
+    int dz = 0, dy_ = 0, dx = 0;
+    bool tap_ok = false;
+#pragma unroll
+    for (int g = 0; g < TG; ++g) {                                   // uniform indices into the kernarg table, selected per thread
+        const int tt = t * TG + g;
+        if (tg == g && tt < a.ntaps) { dz = a.tap[tt][0]; dy_ = a.tap[tt][1]; dx = a.tap[tt][2]; tap_ok = true; }
+    }
+    const bool ycol_ok = co0 + sc4 < a.Cout, xcol_ok = tap_ok && (TG > 1 || sc4 < CIW) && cx0 + sc4c < Cx;
     // voxel coordinates of the staged rows, advanced by WK rows per K-step (no per-step divisions)
     int rx_[WJ], ry_[WJ], rz_[WJ], rn_[WJ];
 #pragma unroll
@@ -91,7 +103,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     // loop-invariant scalars pulled out of the kernarg struct once (re-loading them inside the K-loop costs a scalar-memory
     // round trip + an lgkmcnt(0) wait — which also drains the LDS queue — per use)
     const unsigned ldy_u = (unsigned)a.ldy, ldx_u = (unsigned)ldx, bsx_u = (unsigned)bsx, mbeg_u = (unsigned)mbeg, mend_u = (unsigned)mend;
-    const unsigned ycol_off = (unsigned)(co0 + sc4), xcol_off = (unsigned)(cx0 + sc4);
+    const unsigned ycol_off = (unsigned)(co0 + sc4), xcol_off = (unsigned)(cx0 + sc4c);
     const int is_ = a.is, Wg = a.W, Hg = a.H, Dg = a.D, Wi_ = a.Wi, Hi_ = a.Hi, Di_ = a.Di;
     const int trow = tid >> 5;
     // LDS-DMA staging (common.h: lds_dma16): chunk j of this thread is LDS bytes 16 tid + 4096 j of the A / B image = per wave a lane-linear
@@ -155,15 +167,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     // D[i][j]: col j = lane & 31, row i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-        const int ci = ci0 + (Q == 2 ? wn * 64 + 2 * l31 + q : l31);
-        if (ci >= Cin || (second ? ci - a.C1 >= a.C2 : ci >= a.C1)) continue;
+        const int col = Q == 2 ? wn * 64 + 2 * l31 + q : l31;       // column of the tile
+        const int te = TG > 1 ? t * TG + col / CIW : t;              // its tap
+        const int ci = TG > 1 ? col % CIW : ci0 + col;
+        if (te >= a.ntaps || ci >= Cin || (second ? ci - a.C1 >= a.C2 : ci >= a.C1)) continue;
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int co = co0 + (P == 2 ? wm * 64 + 2 * i + p : wm * 32 + i);
-                if (co < a.Cout) atomic_add_f32(a.dw + ((long long)t * a.Cout + co) * Cin + ci, acc[p][q][r]);
+                if (co < a.Cout) atomic_add_f32(a.dw + ((long long)te * a.Cout + co) * Cin + ci, acc[p][q][r]);
             }
     }
 }
@@ -472,7 +486,11 @@ using namespace forge;
 static int launch_wgrad_tiles(WgradArgs& a, int ciw, hipStream_t stream) {
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int Cin = a.C1 + a.C2, Cout = a.Cout, ntaps = a.ntaps;
-    const long long tiles = (long long)ntaps * ((Cout + WT - 1) / WT) * ((Cin + ciw - 1) / ciw);
+    // narrow single inputs with several taps: TG taps share one 128-column tile (kernel header)
+    // (large problems only: on the trunk's 64 -> 64 3x3 layers, M = 81920, the coarser tiles leave the chip under-filled: 125 -> 166 us)
+    const bool grp = a.x2 == nullptr && a.tpp == 0 && M >= 131072;
+    const int tg = (grp && ciw == 32 && Cin <= 32 && ntaps >= 4) ? 4 : (grp && ciw == 64 && Cin <= 64 && ntaps >= 2) ? 2 : 1;
+    const long long tiles = (long long)((ntaps + tg - 1) / tg) * ((Cout + WT - 1) / WT) * (tg > 1 ? 1 : (Cin + ciw - 1) / ciw);
     // split the voxel (reduction) axis so that ~4096 workgroups exist, but keep >= 32 K-steps (1024 voxels) per workgroup: every
     // workgroup ends with up to 16 K fp32 atomics for its tile, which must stay small next to its MFMA work. When that leaves the
     // chip under-filled (ResNet at one scene: M = 5120, a handful of tiles) the floor drops to 8 K-steps: those launches are
@@ -492,14 +510,16 @@ static int launch_wgrad_tiles(WgradArgs& a, int ciw, hipStream_t stream) {
     const long long grid = tiles * nchunk;
     FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_conv_wgrad: grid too large");
     const size_t lds = 2 * 2 * WK * WT * sizeof(float);     // 32 KiB
-#define FORGE_LAUNCH_WGRAD(CIWv)                                                                                                     \
+#define FORGE_LAUNCH_WGRAD(CIWv, TGv)                                                                                                \
     do {                                                                                                                             \
-        FORGE_SET_MAX_LDS_ONCE(conv_wgrad_kernel<CIWv>, lds);                                                                        \
-        hipLaunchKernelGGL(conv_wgrad_kernel<CIWv>, dim3((unsigned)grid), dim3(256), lds, stream, a);                  \
+        FORGE_SET_MAX_LDS_ONCE((conv_wgrad_kernel<CIWv, TGv>), lds);                                                                 \
+        hipLaunchKernelGGL((conv_wgrad_kernel<CIWv, TGv>), dim3((unsigned)grid), dim3(256), lds, stream, a);           \
     } while (0)
-    if (ciw == 32) FORGE_LAUNCH_WGRAD(32);
-    else if (ciw == 64) FORGE_LAUNCH_WGRAD(64);
-    else FORGE_LAUNCH_WGRAD(128);
+    if (ciw == 32 && tg == 4) FORGE_LAUNCH_WGRAD(32, 4);
+    else if (ciw == 64 && tg == 2) FORGE_LAUNCH_WGRAD(64, 2);
+    else if (ciw == 32) FORGE_LAUNCH_WGRAD(32, 1);
+    else if (ciw == 64) FORGE_LAUNCH_WGRAD(64, 1);
+    else FORGE_LAUNCH_WGRAD(128, 1);
 #undef FORGE_LAUNCH_WGRAD
     FORGE_LAUNCH_CHECK("forge_conv_wgrad");
     return 0;

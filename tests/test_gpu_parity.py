@@ -646,6 +646,46 @@ def test_narrow_transposed_conv_s2_autograd_vs_torch(dev, n, H, W, k, pad):
     assert rel(bd.grad, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize("case", ["convT3d_128_32", "conv3d_64_128", "conv2d_9taps_32", "conv3d_48_2taps", "small_M_ungrouped"])
+def test_conv_wgrad_tap_grouped_tiles_vs_float64(dev, case):
+    """forge_conv_wgrad on narrow single inputs with several taps and M >= 131072 rows - conv_wgrad_kernel<32, 4> / <64, 2>: TG taps share one
+    128-column tile (the heads' ConvTranspose3d(128, 32, 4, s2) weight gradient: 64 taps, stride-2 gathered operand; conv1's Conv3d(64, 128, 3):
+    27 taps; tap counts that are no multiple of the group; Cin below the group's channel width; a small problem that stays on the ungrouped
+    tiles) - against the float64 contraction dW[t] = dY^T X_t written with torch slices and matmuls (stock float64 kernels)."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(len(case))
+    if case == "convT3d_128_32":        # 'dy' operand = x [n,D,H,W,128] (rows), gathered operand = dY [n,2D,2H,2W,32] at 2 z - 1 + k, 64 taps
+        n, D, H, W, Cy, Cx, ist = 2, 16, 64, 64, 128, 32, 2
+        taps = [(kz - 1, ky - 1, kx - 1) for kz in range(4) for ky in range(4) for kx in range(4)]
+    elif case == "conv3d_64_128":
+        n, D, H, W, Cy, Cx, ist = 1, 33, 64, 63, 128, 64, 1
+        taps = co.TAPS_3x3x3
+    elif case == "conv2d_9taps_32":     # 9 taps in groups of 4: the last group holds one tap
+        n, D, H, W, Cy, Cx, ist = 3, 1, 256, 200, 64, 32, 1
+        taps = [(0, dy, dx) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]
+    elif case == "conv3d_48_2taps":     # Cin = 48 < 64 (ragged channel width inside the group), 2 taps = one group
+        n, D, H, W, Cy, Cx, ist = 2, 8, 96, 90, 96, 48, 1
+        taps = [(0, 0, 0), (1, 0, -1)]
+    else:
+        n, D, H, W, Cy, Cx, ist = 2, 4, 6, 5, 128, 32, 2
+        taps = [(kz - 1, ky - 1, kx - 1) for kz in range(4) for ky in range(4) for kx in range(4)]
+    Di, Hi, Wi = (D * ist if D > 1 else 1), H * ist, W * ist
+    dy = torch.randn(n, D, H, W, Cy, generator=g).to(dev)
+    x = torch.randn(n, Di, Hi, Wi, Cx, generator=g).to(dev)
+    pad = 4
+    xp = torch.nn.functional.pad(x.double(), (0, 0, pad, pad, pad, pad, pad if D > 1 else 0, pad if D > 1 else 0))
+    dyf = dy.double().reshape(-1, Cy)
+    ref = torch.empty(len(taps), Cy, Cx, dtype=torch.float64, device=dev)
+    for t, (dz, dy_, dx) in enumerate(taps):
+        z0 = (dz + pad) if D > 1 else 0
+        xs = xp[:, z0:z0 + (D - 1) * ist + 1:ist, dy_ + pad:dy_ + pad + (H - 1) * ist + 1:ist, dx + pad:dx + pad + (W - 1) * ist + 1:ist]
+        ref[t] = dyf.t() @ xs.reshape(-1, Cx)
+    dw = torch.zeros(len(taps), Cy, Cx, device=dev)
+    co.conv_wgrad(dy, x, Cx, None, 0, dw, (n, D, H, W), (Di, Hi, Wi), Cy, list(taps), istride=ist)
+    err = (dw.double() - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item(), (case, err, ref.abs().max().item())
+
+
 def test_conv_igemm_strided2d_and_transpose_phases(dev):
     from forge_amd import convops as co
     g = torch.Generator().manual_seed(2)

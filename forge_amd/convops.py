@@ -352,19 +352,20 @@ def wino_pack_weight(w):
     return wino_pack_packed(pack_conv3d_weight(w))
 
 
-def wino_conv_rows(x1, x2, U, bias, out, residual=None):
+def wino_conv_rows(x1, x2, U, bias, out, residual=None, V1=None):
     """out [n,D,H,W,Cout] = conv3x3x3(cat(x1, x2)) + bias (+ residual) on channels-last rows through the three Winograd launches.
-    x1 may have a batch stride (a view of a [b,t,...] stack)."""
+    x1 may have a batch stride (a view of a [b,t,...] stack). V1: x1's input transform, if the caller already has it."""
     n, D, H, W, C1 = x1.shape
     return _wino_conv(x1, C1, _batch_stride_rows(x1), x2, 0 if x2 is None else x2.shape[-1], 0 if x2 is None else _batch_stride_rows(x2), U, bias, out,
-                      residual, (n, D, H, W))
+                      residual, (n, D, H, W), V1=V1)
 
 
-def _wino_conv(x1, C1, bs1, x2, C2, bs2, U, bias, out, residual, grid):
+def _wino_conv(x1, C1, bs1, x2, C2, bs2, U, bias, out, residual, grid, V1=None):
     """The three launches of one Winograd convolution with the bias (+ residual) tail: transforms of x1 / x2, point GEMMs, inverse."""
     n, D, H, W = grid
     Cout = U.shape[2]
-    V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
+    if V1 is None:
+        V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
     V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W, bs=bs2)
     Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=out.device)
     wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
@@ -408,7 +409,7 @@ def wino_wgrad_applies(n, D, H, W, C1, C2, Cout, taps=None):
 
 
 @_lib.on_tensor_device
-def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None):
+def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None, dM=None):
     """dwp [27 | 9][Cout][C1+C2] (zero-filled by the caller) += the weight gradient of conv3x3x3 / conv3x3 (cat(x1, x2)) for the upstream gradient
     dy [rows][Cout]. Wide layers take the Winograd form - dMm = A dy A^T, dU[p] = dMm[p]^T (x) V[p] as 16 batched problems of the wgrad
     GEMM kernel (2.25x fewer FLOPs), dw = G^T dU G - the others the direct kernel (conv_wgrad)."""
@@ -423,8 +424,9 @@ def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None):
     dev = dy.device
     V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
     V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W)
-    dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
-    _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
+    if dM is None:                                             # (the caller may hold A dy A^T already: wino_input_dy)
+        dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
+        _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
     dU = grad_zeros((16, kd, Cout, C1 + C2), dev)
     _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, kd, st), "forge_wino_wgrad")
     _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, kd, st), "forge_wino_dw")
@@ -479,6 +481,17 @@ def wino_scene_chunk(b, D, H, W, C, views=1):
 def wino_fits(n, D, H, W, C, views=1):
     """H, W even, and every transformed operand ([n views D H/2 W/2][C] floats per Winograd point) within the kernel's 32-bit buffer offsets."""
     return H % 2 == 0 and W % 2 == 0 and n * views * D * (H // 2) * (W // 2) * C * 4 <= MAX_OPERAND_BYTES
+
+
+@_lib.on_tensor_device
+def wino_input_dy(dy, C, n, D, H, W):
+    """(V, dM) = (B^T dy B, A dy A^T), both [16][n D H/2 W/2][C], of an upstream gradient dy (dense rows [n D H W][C]) in ONE pass over it:
+    the operands of the data-gradient point GEMMs and of the Winograd weight gradient (forge_wino_input_dy)."""
+    R = n * D * (H // 2) * (W // 2)
+    V = torch.empty(16, R, C, dtype=torch.float32, device=dy.device)
+    dM = torch.empty(16, R, C, dtype=torch.float32, device=dy.device)
+    _lib.check(_lib.lib().forge_wino_input_dy(_lib.ptr(dy), C, _lib.ptr(V), _lib.ptr(dM), n, D, H, W, C, _lib.current_stream()), "forge_wino_input_dy")
+    return V, dM
 
 
 @_lib.on_tensor_device
@@ -631,7 +644,15 @@ class _ConvTapsRows(torch.autograd.Function):
         T, Cout, Cin = wp.shape
         dy = dy.contiguous()
         dx1 = dx2 = dwp = db = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        same = (D, H, W) == (Di, Hi, Wi)
+        wino_dx = need_dx and istride == 1 and Cout > 16 and same and wino_applies(taps, istride, n, D, H, W, Cout, 0, Cin)
+        wino_dw = (ctx.needs_input_grad[2] and same and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout)
+                   and (x2 is None or _batch_stride_rows(x2) == 0) and wino_wgrad_applies(n, D, H, W, C1, C2, Cout, taps))
+        Vdy = dMdy = None
+        if wino_dx and wino_dw:                                                      # both Winograd forms of dy from one pass over it
+            Vdy, dMdy = wino_input_dy(dy.reshape(-1, Cout), Cout, n, D, H, W)
+        if need_dx:
             wd = wp.transpose(1, 2).contiguous()                                     # [T][Cin][Cout]
             if istride == 1 and Cout <= 16:
                 # narrow output (forward ran on the Cout <= 16 kernel): the data gradient has K = Cout <= 16 and N = Cin; run it on the
@@ -650,7 +671,7 @@ class _ConvTapsRows(torch.autograd.Function):
                                (n, D, H, W), (D, H, W), nb, Cin, ntaps_, epilogue=EPI_BIAS)
             elif istride == 1 and (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, Cout, 0, Cin):
                 dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
-                wino_conv_rows(dy, None, wino_pack_packed(wp, transpose=True), None, dx)
+                wino_conv_rows(dy, None, wino_pack_packed(wp, transpose=True), None, dx, V1=Vdy)
             elif istride == 1:
                 assert (D, H, W) == (Di, Hi, Wi)
                 dx = torch.empty(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
@@ -673,7 +694,7 @@ class _ConvTapsRows(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             dwp = grad_zeros(wp.shape, wp.device)
             if (D, H, W) == (Di, Hi, Wi) and wino_applies(taps, istride, n, D, H, W, C1, C2, Cout) and (x2 is None or _batch_stride_rows(x2) == 0):
-                conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1), taps=taps)
+                conv3_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), Cout, bs1=_batch_stride_rows(x1), taps=taps, dM=dMdy)
             else:
                 conv_wgrad(dy, x1, C1, x2, C2, dwp, (n, D, H, W), (Di, Hi, Wi), Cout, list(taps), istride=istride, bs1=_batch_stride_rows(x1),
                            bs2=0 if x2 is None else _batch_stride_rows(x2))

@@ -27,9 +27,14 @@ struct WinoInArgs {
     int n, D, H, W, C;
     int nsum; long long ss;                       // nsum > 1: the input is the MEAN of nsum tensors ss rows apart (the view mean of models/encoder.py:62
                                                   // feeding fusion_conv: sum in view order, then x (1 / nsum), as torch.mean) - no separate reduction launch
+    float* dM; long long ptm;                     // DY instantiation: also dM[p] = (A y A^T)[p] of the tile's own 2 x 2 pixels y (rows [n][D][H/2][W/2] x C)
 };
 
-// one thread = one tile x 4 channels: 16 float4 loads (zero outside the grid), 32 float4 additions, 16 float4 stores
+// one thread = one tile x 4 channels: 16 float4 loads (zero outside the grid), 32 float4 additions, 16 float4 stores.
+// DY: the tensor is an upstream gradient that the backward pass needs in BOTH transformed forms - B^T d B for the data-gradient GEMMs and
+// A y A^T (wino_dy_kernel) for the weight-gradient GEMMs; the 2 x 2 pixels of the latter are the centre of the patch already in registers,
+// so one launch writes both (9 instead of 10 passes of the tensor's size, one launch less per gradient).
+template <bool DY>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
     const int C4 = a.C >> 2, Ht = a.H >> 1, Wt = a.W >> 1;
     // each XCD transforms one CONTIGUOUS slab of tiles: neighbouring tiles share half of their 4 x 4 input patches, and with the dispatcher's
@@ -63,6 +68,19 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
                 }
             }
             d[i][j] = v;
+        }
+    }
+    if constexpr (DY) {
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        float* mp = a.dM + (long long)r * a.C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                // rows of A y: y0, y0 + y1, y0 - y1, -y1 (y = d[1..2][1..2]); then (A y) A^T
+            const float4 s0 = i == 0 ? d[1][1] : i == 1 ? f4_add(d[1][1], d[2][1]) : i == 2 ? f4_sub(d[1][1], d[2][1]) : f4_sub(zero, d[2][1]);
+            const float4 s1 = i == 0 ? d[1][2] : i == 1 ? f4_add(d[1][2], d[2][2]) : i == 2 ? f4_sub(d[1][2], d[2][2]) : f4_sub(zero, d[2][2]);
+            *reinterpret_cast<float4*>(mp + (4 * i + 0) * a.ptm) = s0;
+            *reinterpret_cast<float4*>(mp + (4 * i + 1) * a.ptm) = f4_add(s0, s1);
+            *reinterpret_cast<float4*>(mp + (4 * i + 2) * a.ptm) = f4_sub(s0, s1);
+            *reinterpret_cast<float4*>(mp + (4 * i + 3) * a.ptm) = f4_sub(zero, s1);
         }
     }
     float4 w[4][4];                                  // rows: B^T d
@@ -351,8 +369,25 @@ extern "C" int forge_wino_input(const float* in, int ld, long long bs, float* V,
     FORGE_REQUIRE(R < (1ll << 31), FORGE_ESHAPE, "forge_wino_input: more than 2^31 tiles; split the batch");
     const long long total = R * (C / 4), grid = (total + 255) / 256;
     FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_wino_input: grid too large");
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    a.dM = nullptr; a.ptm = 0;
+    hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     FORGE_LAUNCH_CHECK("forge_wino_input");
+    return 0;
+}
+
+extern "C" int forge_wino_input_dy(const float* dy, int ld, float* V, float* dM, int n, int D, int H, int W, int C, forge_stream_t stream) {
+    FORGE_REQUIRE(dy && V && dM, FORGE_EINVAL, "forge_wino_input_dy: null pointer argument");
+    FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, FORGE_ESHAPE,
+                  "forge_wino_input_dy: n=%d D=%d H=%d W=%d C=%d ld=%d (H, W even; C, ld multiples of 4)", n, D, H, W, C, ld);
+    WinoInArgs a;
+    a.in = dy; a.ld = ld; a.bs = (long long)D * H * W; a.V = V; a.ldv = C; a.n = n; a.D = D; a.H = H; a.W = W; a.C = C; a.nsum = 1; a.ss = 0;
+    const long long R = (long long)n * D * (H / 2) * (W / 2);
+    a.ptv = R * C; a.dM = dM; a.ptm = R * C;
+    FORGE_REQUIRE(R < (1ll << 31), FORGE_ESHAPE, "forge_wino_input_dy: more than 2^31 tiles; split the batch");
+    const long long total = R * (C / 4), grid = (total + 255) / 256;
+    FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_wino_input_dy: grid too large");
+    hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    FORGE_LAUNCH_CHECK("forge_wino_input_dy");
     return 0;
 }
 

@@ -569,18 +569,16 @@ class _FuseGroupsTrain(torch.autograd.Function):
         Mm = newV(R, 2 * C)
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
 
-        def dgrad(dy, Cdy, key, dst, residual=None):
-            """dst [M, C] = conv^T(dy [M, Cdy], hidden-half / fusion_conv weights `key`) (+ residual): input transform, point GEMMs, inverse"""
-            V = co.wino_input(dy, Cdy, Cdy, b, D, H, W)
-            co.wino_gemm(V, Cdy, None, 0, UT[key], Mc, b, D, Ht, Wt, C)
+        def both(dy, Cdy, Vin, wkey, dkey, dst, residual=None):
+            """One pass over dy [M, Cdy] for both of its Winograd forms (forge_wino_input_dy), then
+               dU[wkey] += (A dy A^T)^T (x) Vin                                  (weight gradient)
+               dst [M, C] = conv^T(dy, weights `dkey`) (+ residual)              (data gradient: point GEMMs on B^T dy B, inverse transform)"""
+            V, dM = co.wino_input_dy(dy, Cdy, b, D, H, W)
+            _lib.check(L.forge_wino_wgrad(p(dM), p(Vin), C, 0, 0, None, 0, 0, 0, p(dU[wkey]), b, D, Ht, Wt, Cdy, 3, st()), "forge_wino_wgrad")
+            del dM
+            co.wino_gemm(V, Cdy, None, 0, UT[dkey], Mc, b, D, Ht, Wt, C)
             co.wino_output(Mc, None, None, None, 1.0, residual, None, None, dst, None, None, *geo, C, C, co.EPI_BIAS)
             return dst
-
-        def wgrad(dy, Cdy, Vin, key, n=b, rows=R):
-            """dU[key] += (A dy A^T)^T (x) Vin over the n volumes of dy"""
-            dM = newV(rows, Cdy)
-            _lib.check(L.forge_wino_dy(p(dy), Cdy, p(dM), n, D, H, W, Cdy, st()), "forge_wino_dy")
-            _lib.check(L.forge_wino_wgrad(p(dM), p(Vin), C, 0, 0, None, 0, 0, 0, p(dU[key]), n, D, Ht, Wt, Cdy, 3, st()), "forge_wino_wgrad")
 
         dg_acc = torch.empty(b, t, D, H, W, 2 * C, dtype=torch.float32, device=dev)     # d (gate pre-activations) summed per view over the groups
         dc_acc = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
@@ -604,43 +602,36 @@ class _FuseGroupsTrain(torch.autograd.Function):
                 dh, dz, dc = new(), new(), new()
                 _lib.check(L.forge_gru_state_bwd(p(dhn), C, p(h), p(z), p(cand), p(dh), p(dz), p(dc), M, C, p(dc_acc[:, ti]), t * vol, vol, mode, st()),
                            "forge_gru_state_bwd")
-                dhr = dgrad(dc, C, "oh", new())
-                wgrad(dc, C, Vhr, "oh")
+                dhr = both(dc, C, Vhr, "oh", "oh", new())
                 dg = new(2 * C)
                 _lib.check(L.forge_gru_gates_bwd(p(dz), p(dhr), C, p(h), p(z), p(r), p(dg), p(dh), None, 0, M, C, p(dg_acc[:, ti]), t * vol, vol, mode, st()),
                            "forge_gru_gates_bwd")
-                dhn = dgrad(dg, 2 * C, "gh", new(), residual=dh)            # dh (state + reset paths) + conv^T(dg, Wg_h)
-                wgrad(dg, 2 * C, Vh, "gh")
+                dhn = both(dg, 2 * C, Vh, "gh", "gh", new(), residual=dh)  # dh (state + reset paths) + conv^T(dg, Wg_h)
             # h0 = lrelu(bn4(conv(lrelu(bn1(conv(mean))))))
             da1, dg4, dbe4, _ = bn_rows_bwd(sv4, dhn)
             grads_bn["g4"], grads_bn["be4"] = add(grads_bn["g4"], dg4), add(grads_bn["be4"], dbe4)
-            wgrad(da1, C, Vt0, "f3")
+            dt0 = both(da1, C, Vt0, "f3", "f3", new())
             if ctx.has_bias[3]:
                 db3 = add(db3, co.colsum(da1))
-            dt0 = dgrad(da1, C, "f3", new())
             da0, dg1, dbe1, _ = bn_rows_bwd(sv1, dt0)
             grads_bn["g1"], grads_bn["be1"] = add(grads_bn["g1"], dg1), add(grads_bn["be1"], dbe1)
-            wgrad(da0, C, Vm, "f0")
+            dmeans.append((grp, both(da0, C, Vm, "f0", "f0", new())))
             if ctx.has_bias[2]:
                 db0 = add(db0, co.colsum(da0))
-            dmeans.append((grp, dgrad(da0, C, "f0", new())))
         for ti in range(t):
             if not seen[ti]:                                                 # a view no group uses: no gradient through the GRU input halves
                 dg_acc[:, ti].zero_()
                 dc_acc[:, ti].zero_()
         # the shared input halves, once for all views: weight gradients against V_x, data gradient = conv^T(dg, Wg_x) + conv^T(dc, Wo_x)
         nbt_, Rall = b * t, b * t * R1
-        wgrad(dg_acc, 2 * C, Vx, "gx", n=nbt_, rows=Rall)
-        wgrad(dc_acc, C, Vx, "ox", n=nbt_, rows=Rall)
         dx = torch.empty(b, t, D, H, W, C, dtype=torch.float32, device=dev)
-        MA = newV(Rall, C)
-        Vg = co.wino_input(dg_acc, 2 * C, 2 * C, nbt_, D, H, W)
-        co.wino_gemm(Vg, 2 * C, None, 0, UT["gx"], MA, nbt_, D, Ht, Wt, C)
-        del Vg
-        Vc = co.wino_input(dc_acc, C, C, nbt_, D, H, W)
-        MB = newV(Rall, C)
-        co.wino_gemm(Vc, C, None, 0, UT["ox"], MB, nbt_, D, Ht, Wt, C)
-        del Vc
+        MA, MB = newV(Rall, C), newV(Rall, C)
+        for acc, Cacc, key, Mout in ((dg_acc, 2 * C, "gx", MA), (dc_acc, C, "ox", MB)):
+            Va, dMa = co.wino_input_dy(acc.reshape(-1, Cacc), Cacc, nbt_, D, H, W)
+            _lib.check(L.forge_wino_wgrad(p(dMa), p(Vx), C, 0, 0, None, 0, 0, 0, p(dU[key]), nbt_, D, Ht, Wt, Cacc, 3, st()), "forge_wino_wgrad")
+            del dMa
+            co.wino_gemm(Va, Cacc, None, 0, UT[key], Mout, nbt_, D, Ht, Wt, C)
+            del Va
         co.wino_output(MA, None, None, None, 1.0, None, None, None, dx, None, None, nbt_, D, H, W, C, C, co.EPI_BIAS, Mm2=MB, view=0, views=1)
         for grp, dmean in dmeans:                                            # d mean / d x_ti = 1 / |group|
             dm = dmean.reshape(b, 1, D, H, W, C)

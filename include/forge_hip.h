@@ -260,6 +260,10 @@ int forge_wino_dw(const float* dU, float* dw, int Cout, int Cin, int kd, forge_s
 int forge_wino_input(const float* in, int ld, long long bs, float* V, int ldv, long long ptv, int n, int D, int H, int W, int C,
                      int nsum /* >1: transform the MEAN of nsum tensors sum_stride rows apart (models/encoder.py:62 view mean) */, long long sum_stride,
                      forge_stream_t stream);
+/* An upstream gradient dy [n D H W][ld] (C channels) in BOTH transformed forms with one pass over it: V = B^T dy B (as forge_wino_input,
+ * for the data-gradient point GEMMs) and dM = A dy A^T (as forge_wino_dy, for forge_wino_wgrad); both [16][n D H/2 W/2][C], dense.
+ * (Backward of the reference's 3x3x3 convolutions under autograd: models/fusion.py:29-35, 61-68 via scripts/kubric_trainer.py:56.) */
+int forge_wino_input_dy(const float* dy, int ld, float* V, float* dM, int n, int D, int H, int W, int C, forge_stream_t stream);
 int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                     long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile /* 0 = forge_wino_gemm_tile's rule */,
                     forge_stream_t stream);

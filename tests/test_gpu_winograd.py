@@ -215,6 +215,20 @@ def test_frozen_fusion_hoisted_reference_view_equals_the_plain_frozen_fusion():
         assert rel(outs[0][1], outs[1][1]) < 1e-3, it      # (LeakyReLU arguments within rounding of zero may take the other slope, as above)
 
 
+@pytest.mark.parametrize("n,D,H,W,C", [(2, 3, 8, 12, 128), (1, 1, 32, 32, 512), (3, 5, 6, 4, 36)])
+def test_wino_input_dy_equals_the_two_separate_transforms(n, D, H, W, C):
+    """forge_wino_input_dy (one pass over an upstream gradient for both of its Winograd forms) == forge_wino_input and forge_wino_dy, bit for bit."""
+    from forge_amd import _lib
+    from forge_amd import convops as co
+    dev = _dev()
+    dy = torch.randn(n * D * H * W, C, generator=torch.Generator().manual_seed(C)).to(dev)
+    V, dM = co.wino_input_dy(dy, C, n, D, H, W)
+    Vref = co.wino_input(dy, C, C, n, D, H, W)
+    dMref = torch.empty_like(dM)
+    _lib.check(_lib.lib().forge_wino_dy(_lib.ptr(dy), C, _lib.ptr(dMref), n, D, H, W, C, _lib.current_stream()), "forge_wino_dy")
+    assert torch.equal(V, Vref) and torch.equal(dM, dMref)
+
+
 def test_wino_weight_gradient_vs_float64_and_direct_kernel(monkeypatch):
     """convops.conv3_wgrad (dMm = A dy A^T, 16 batched wgrad problems, G^T dU G) against float64 autograd and the direct wgrad kernel:
     two-input form with a batch-strided first operand (the GRU cells' layout) and a single-input form."""

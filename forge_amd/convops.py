@@ -159,24 +159,27 @@ class _ZeroArena:
     as long as anything (a parameter's .grad) references them; the next pass gets a fresh arena."""
 
     def __init__(self):
-        self.buf, self.off, self.used, self.want, self.active, self.device = None, 0, 0, 0, False, None
+        self.buf, self.off, self.used, self.want, self.task, self.device = None, 0, 0, 0, -1, None
 
     def _end(self):
         self.want = self.used
-        self.buf, self.off, self.used, self.active = None, 0, 0, False
+        self.buf, self.off, self.used, self.task = None, 0, 0, -1
 
     def zeros(self, shape, device):
         n = 1
         for d in shape:
             n *= int(d)
         nbytes = (n * 4 + 255) // 256 * 256
-        if not self.active:
-            self.active, self.device, self.off, self.used = True, device, 0, 0
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(self._end)      # only valid inside a backward pass
-            except RuntimeError:
-                self.active = False
-                return torch.zeros(shape, dtype=torch.float32, device=device)
+        task = torch._C._current_graph_task_id()                  # -1 outside a backward pass
+        if task < 0:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        if task != self.task:
+            # a new pass - also when the previous one never reached its callback (an exception inside backward) or a nested backward runs inside
+            # this one: the old arena is dropped, never carved again (its slices may be live gradients), and this pass gets a fresh one
+            if self.task >= 0:
+                self._end()
+            self.task, self.device, self.off, self.used = task, device, 0, 0
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of(task))
             self.buf = torch.zeros(self.want // 4 + 64, dtype=torch.float32, device=device) if self.want else None
         self.used += nbytes
         if self.buf is None or device != self.device or self.off + nbytes > self.buf.numel() * 4:
@@ -184,6 +187,12 @@ class _ZeroArena:
         out = self.buf[self.off // 4:self.off // 4 + n].view(shape)
         self.off += nbytes
         return out
+
+    def _end_of(self, task):
+        def cb():
+            if self.task == task:                                 # (a nested pass may have replaced it meanwhile)
+                self._end()
+        return cb
 
 
 GRAD_ZEROS = _ZeroArena()

@@ -316,3 +316,46 @@ def test_modules_refuse_cpu_tensors_instead_of_falling_back():
                      lambda: enc.fusion_feature(torch.zeros(1, 2, 128, 4, 4, 4), None)):
             with pytest.raises(RuntimeError, match="no CPU or stock-PyTorch path"):
                 call()
+
+
+def test_grad_zero_arena_never_hands_out_memory_twice():
+    """convops.grad_zeros (one zero-filled arena per backward pass for the atomically accumulated weight gradients): plain torch.zeros outside
+    a backward pass; inside one, slices of ONE buffer sized by the previous pass; a pass that dies with an exception, or a nested backward,
+    never makes a later request alias memory handed out before (the old arena is dropped, not rewound)."""
+    from forge_amd import convops as co
+    arena = co._ZeroArena()
+    dev = torch.device("cpu")
+    assert arena.zeros((3, 4), dev).abs().sum() == 0 and arena.task == -1          # outside backward: no arena
+
+    got = []
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fail):
+            ctx.fail = fail
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b = arena.zeros((5, 7), dev), arena.zeros((64,), dev)
+            a.add_(1.0)
+            b.add_(2.0)                                                         # "gradients" accumulated into the slices
+            got.append((a, b))
+            if ctx.fail:
+                raise RuntimeError("boom")
+            return g * 2, None
+
+    x = torch.ones(2, requires_grad=True)
+    Node.apply(x, False).sum().backward()                                        # pass 1: nothing known yet -> own allocations
+    assert arena.task == -1 and arena.want >= (5 * 7 + 64) * 4
+    Node.apply(x, False).sum().backward()                                        # pass 2: both carved from one arena
+    a, b = got[-1]
+    assert a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.data_ptr() != b.data_ptr()
+    with pytest.raises(RuntimeError):
+        Node.apply(x, True).sum().backward()                                     # pass 3 dies: its callback never runs
+    fa, fb = got[-1]
+    Node.apply(x, False).sum().backward()                                        # pass 4 must not rewind pass 3's arena
+    a4, b4 = got[-1]
+    assert a4.untyped_storage().data_ptr() != fa.untyped_storage().data_ptr()
+    assert float(fa.sum()) == 35.0 and float(fb.sum()) == 128.0                  # pass 3's slices untouched by pass 4's zero-fill / adds
+    assert float(a4.sum()) == 35.0 and float(b4.sum()) == 128.0 and arena.task == -1

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "narrow_transposed" 2>&1 | tail -3
-python tools/debug/joint_shard_noise.py 2>&1 | grep -v Warning | tail -40 > gpurun_out/joint_noise_plain.txt
-JOINT_DETERMINISTIC=1 python tools/debug/joint_shard_noise.py 2>&1 | grep -v Warning | tail -40 > gpurun_out/joint_noise_det.txt
-cat gpurun_out/joint_noise_plain.txt | cut -c1-200
-echo ======
-cat gpurun_out/joint_noise_det.txt | cut -c1-200
+for sens in "" g go; do
+  export FORGE_SENS=$sens
+  echo "== sens=$sens"
+  python bench.py --no-extra --no-cpu-baseline --no-microbench --repeats 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'single', round(d['single_stream']['ms_per_step'],3))"
+done

@@ -37,6 +37,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HSA runtime starts (first torch.cuda call): this host driver supports dmabuf IPC only - a rank launched by somebody else's
+# torch.distributed.run (not through rank_env below) must see it too, or RCCL's cross-process buffer exchange fails
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 

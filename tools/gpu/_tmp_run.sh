@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for sens in "" g go; do
-  export FORGE_SENS=$sens
-  echo "== sens=$sens"
-  python bench.py --no-extra --no-cpu-baseline --no-microbench --repeats 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('headline', round(d['value'],1), 'ms', round(d['ms_per_step'],3), 'single', round(d['single_stream']['ms_per_step'],3))"
-done
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "conv_direct or conv_rgb or heads or training" 2>&1 | tail -2
+TRAIN_SCENES=4 bash tools/gpu/run_trainprof_r4.sh r04_train_b4 > /dev/null 2>&1
+grep -E "conv_direct_wgrad|per step" gpurun_out/r04_train_b4_kernel_stats.txt; grep "train step" gpurun_out/r04_train_b4.log

@@ -1,4 +1,3 @@
+# scratch: the command list of the next `gpurun -- 'bash tools/gpu/_tmp_run.sh'` call (overwritten per experiment; outputs under gpurun_out/)
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "conv_direct or conv_rgb or heads or training" 2>&1 | tail -2
-TRAIN_SCENES=4 bash tools/gpu/run_trainprof_r4.sh r04_train_b4 > /dev/null 2>&1
-grep -E "conv_direct_wgrad|per step" gpurun_out/r04_train_b4_kernel_stats.txt; grep "train step" gpurun_out/r04_train_b4.log
+python -m pytest tests -m gpu -q -x 2>&1 | tail -4

@@ -381,7 +381,7 @@ __device__ __forceinline__ float pose_translation(const float* __restrict__ can_
 // One thread per view (b t of them). rot [b (t-1)][4], trans [b (t-1)][3]; can_p / can_e: pose and extrinsics of the reference view (row-major 4x4);
 // K [b t][9] full-resolution intrinsics. Outputs: xf [b t][12], mode [b t], cam [b t][16], poses [b t][16], origin [b t][2] (nullable),
 // jac [b (t-1)][24][7] (nullable): d (xf[0..11], cam[0..11]) / d (quaternion, translation).
-__global__ void pose_chain_fwd_kernel(const float* __restrict__ rot, const float* __restrict__ trans, const float* __restrict__ can_p,
+__global__ __launch_bounds__(64) void pose_chain_fwd_kernel(const float* __restrict__ rot, const float* __restrict__ trans, const float* __restrict__ can_p,
                                       const float* __restrict__ can_e, const float* __restrict__ K, float e, int b, int t, float* __restrict__ xf,
                                       int* __restrict__ mode, int* __restrict__ slot, float* __restrict__ cam, float* __restrict__ poses,
                                       float* __restrict__ origin, float* __restrict__ jac) {

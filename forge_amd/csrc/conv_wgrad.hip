@@ -368,9 +368,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4w;
 // IS = 2 (CIT = 16, LT = 9 taps per wave): the gathered operand lives on the 2x finer grid (voxel m reads row 2 m + tap) - the weight gradient of
 // a stride-2 transposed convolution (conv_rgb's ConvTranspose2d(16, 16, 6, stride 2): 36 taps on 6 lines, |dx| <= 3), whose staged X segment is
 // 2 LSEG - 1 + 2 rx rows long and is read with a row stride of 2.
-template <int CIT, int IS = 1, int LT = LTAPS>
-__global__ __launch_bounds__(256, (CIT == 16 && IS == 1) ? 4 : 3) void conv_wgrad_lines16_kernel(const WgradArgs a, const LineTable lt) {
-    constexpr int NT = CIT / 16;
+// NWV = waves per workgroup: 4, or 8 for CIT = 32 (the heads' 32 -> 16 / 32 -> 8 layers): with 4 waves that instantiation needs 189 VGPRs
+// (7 taps x 2 accumulators per wave + 11 staging passes), i.e. spills at 3 workgroups per CU and runs 1.5x slower at 2 (1124 vs 732 us);
+// 8 waves share one staged segment with 4 taps and 6 staging passes each.
+template <int CIT, int IS = 1, int LT = LTAPS, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : ((CIT == 16 && IS == 1) ? 4 : 3)) void conv_wgrad_lines16_kernel(const WgradArgs a, const LineTable lt) {
+    constexpr int NT = CIT / 16, NTHR = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // dYs [LSEG][16] | Xs [nlines][LSEG + 2 rx][CIT]
     float* dYs = smem;
     float* Xs = smem + LSEG * 16;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, (CIT == 16 && IS == 1) ? 4 : 3) void conv_wgra
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.spany, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.x1, 0, (int)a.span1, 0x00020000);
     // staging: one float4 per thread per pass; CIT / 4 threads per X row (4 per dY row: threads 0..127 stage the 32 dY rows)
-    constexpr int TPR = CIT / 4, RPP = 256 / TPR;                    // threads per row, rows per pass
+    constexpr int TPR = CIT / 4, RPP = NTHR / TPR;                   // threads per row, rows per pass
     const int c4 = (tid % TPR) << 2, srow = tid / TPR;
     const int yc4 = (tid & 3) << 2, yrow = tid >> 2;
     const int xchunks = lt.nlines * xrows;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256, (CIT == 16 && IS == 1) ? 4 : 3) void conv_wgra
     bool tok[LT];
 #pragma unroll
     for (int j = 0; j < LT; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + NWV * j;
         tok[j] = t < a.ntaps;
         const int tt = tok[j] ? t : 0;
         tb[j] = (a.tap[tt][3] * xrows + a.tap[tt][2] + lt.rx) * CIT;  // (line, dx + rx)
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, (CIT == 16 && IS == 1) ? 4 : 3) void conv_wgra
 #pragma unroll
     for (int j = 0; j < LT; ++j) {
         if (!tok[j]) continue;
-        const int t = wave + 4 * j;
+        const int t = wave + NWV * j;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int ci = NT == 2 ? 2 * l15 + n : l15;
@@ -594,8 +597,9 @@ extern "C" int forge_conv_wgrad(const float* dy, int ldy, const float* x1, int C
                     FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines16_kernel<16>, (LSEG * 16 + LMAXL * LROWS * 16) * sizeof(float));
                     hipLaunchKernelGGL(conv_wgrad_lines16_kernel<16>, dim3((unsigned)grid16), dim3(256), lds16, (hipStream_t)stream, a, lt);
                 } else {
-                    FORGE_SET_MAX_LDS_ONCE(conv_wgrad_lines16_kernel<32>, (LSEG * 16 + LMAXL * LROWS * 32) * sizeof(float));
-                    hipLaunchKernelGGL(conv_wgrad_lines16_kernel<32>, dim3((unsigned)grid16), dim3(256), lds16, (hipStream_t)stream, a, lt);
+                    const long long grid32 = nseg < 512 ? nseg : 512;      // 8-wave workgroups, 2 per CU
+                    FORGE_SET_MAX_LDS_ONCE((conv_wgrad_lines16_kernel<32, 1, 4, 8>), (LSEG * 16 + LMAXL * LROWS * 32) * sizeof(float));
+                    hipLaunchKernelGGL((conv_wgrad_lines16_kernel<32, 1, 4, 8>), dim3((unsigned)grid32), dim3(512), lds16, (hipStream_t)stream, a, lt);
                 }
                 FORGE_LAUNCH_CHECK("forge_conv_wgrad");
                 return 0;

@@ -62,12 +62,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const long long M = (long long)a.n * a.D * a.H * a.W;
     const int Cin = a.C1 + a.C2;
     const int cot = (a.Cout + WT - 1) / WT, cit = TG > 1 ? 1 : (Cin + CIW - 1) / CIW;
-    const int nchunk = (int)((M + a.mchunk - 1) / a.mchunk);
-    unsigned bid = blockIdx.x;
-    const int chunk = bid % nchunk; bid /= nchunk;
+    // workgroup order: taps fastest, then the Cin / Cout tiles, the voxel chunk slowest, and each XCD a contiguous run of it - every workgroup
+    // that consumes one chunk's dY / X rows (all taps: the same dY rows, X rows a few voxels apart; all tiles) is dispatched back to back on
+    // ONE XCD, whose L2 then serves them (with the chunk fastest every tap re-read the whole operands from the fabric: conv1's weight gradient
+    // 7 GB per launch): weight gradients of the 4-scene training step 35.9 -> 35.5 ms, conv1's 2.64 -> 2.52 ms)
+    const int ntg = (a.ntaps + TG - 1) / TG;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int t = bid % ntg; bid /= ntg;                             // tap (TG = 1) / group of TG taps
     const int ci_t = bid % cit; bid /= cit;
     const int co_t = bid % cot; bid /= cot;
-    const int t = bid;                                              // tap (TG = 1) / group of TG taps
+    const int chunk = bid;
     const long long mbeg = (long long)chunk * a.mchunk;
     const long long mend = mbeg + a.mchunk < M ? mbeg + a.mchunk : M;
     const int nsteps = (int)((mend - mbeg + WK - 1) / WK);

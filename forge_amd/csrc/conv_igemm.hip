@@ -120,10 +120,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int ks = (int)(bid_all % (unsigned)a.ksplit);           // K-slice of this workgroup (split-K for small M x N problems)
     unsigned bid = bid_all / (unsigned)a.ksplit;
     int phase = 0;
-    if (a.nphase > 1) {                                             // merged transposed-conv phases: workgroups [p tiles, (p+1) tiles) do phase p
-        const unsigned tiles = (unsigned)((M + BM - 1) / BM) * (unsigned)ntile_n;
-        phase = (int)(bid / tiles);
-        bid -= (unsigned)phase * tiles;
+    if (a.nphase > 1) {
+        // merged transposed-conv phases, phase fastest: the 2^nd output phases of one row tile read the same 3^nd neighbourhood of input rows -
+        // dispatched back to back on one XCD (xcd_remap) they share them through its L2 (phase-major, every phase streamed the whole input
+        // again: 8 GB of L2->fabric traffic per heads launch of the 4-scene training step, profiles/r04_train_pmc_traffic_b4.txt; 883 -> 867 us)
+        phase = (int)(bid % (unsigned)a.nphase);
+        bid /= (unsigned)a.nphase;
     }
     const int pz = a.nphase > 1 ? (a.nphase == 8 ? (phase >> 2) & 1 : 0) : a.pz;
     const int py = a.nphase > 1 ? (phase >> 1) & 1 : a.py, px = a.nphase > 1 ? phase & 1 : a.px;

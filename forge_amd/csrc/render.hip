@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
                                                               const float* __restrict__ cams, const int* __restrict__ view2vol,
                                                               const float* __restrict__ g_feat, const float* __restrict__ g_opac,
                                                               const float* __restrict__ g_depth, float2* __restrict__ G,
-                                                              float* __restrict__ cam_part, int D, int H, int W, int Hr, int Wr,
+                                                              float* __restrict__ cam_part, float2* __restrict__ sab, int D, int H, int W, int Hr, int Wr,
                                                               int S, float zmin, float zmax, float hx, float hy, float hz, int V, int band_order) {
     constexpr int RPB = 256 / C4, TH = RPB / 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][RPB][S + 1]: (d_s, a_s) -> (T_s d_s, dL/dd_s); row pad: a wave's rays hit distinct banks
@@ -292,12 +292,26 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
         taps_ac_true(px, py, pz, W, H, D, t);
         float d = 0.f;
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        // CAM: the sample's value is trilinear in its position p, so d loss / d p = T_s d_s SA + (dL/dd_s) SB with SA = sum_k (d w_k / d p)
+        // (F_k . g) and SB = sum_k (d w_k / d p) Dn_k - six scalars made HERE from the corners this pass loads anyway and parked per sample
+        // (`sab`), so that pass C, which learns T_s d_s and dL/dd_s, does not gather the eight corners a second time (0.27 of the 0.36 ms this
+        // launch took per refinement iteration)
+        float sax = 0.f, say = 0.f, saz = 0.f, sbx = 0.f, sby = 0.f, sbz = 0.f;
         if (t.any) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const long long o = tap_off(t, k);
-                d = fmaf(t.w[k], Dn[o], d);
-                f = f4_fma(t.w[k], F[o * C4], f);
+                const float dn = Dn[o];
+                const float4 fv = F[o * C4];
+                d = fmaf(t.w[k], dn, d);
+                f = f4_fma(t.w[k], fv, f);
+                if constexpr (CAM) {
+                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+                    const float cx = t.bx[dx] * t.ay[dy] * t.az[dz], cy = t.ax[dx] * t.by[dy] * t.az[dz], cz = t.ax[dx] * t.ay[dy] * t.bz[dz];
+                    const float q = fv.x * g.x + fv.y * g.y + fv.z * g.z + fv.w * g.w;
+                    sax = fmaf(cx, q, sax); say = fmaf(cy, q, say); saz = fmaf(cz, q, saz);
+                    sbx = fmaf(cx, dn, sbx); sby = fmaf(cy, dn, sby); sbz = fmaf(cz, dn, sbz);
+                }
             }
         }
         float a = g.x * f.x + g.y * f.y + g.z * f.z + g.w * f.w;
@@ -305,6 +319,14 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
         for (int o = 1; o < C4; o <<= 1) a += __shfl_xor(a, o, 64);
         a = fmaf(gdep, z, a);
         if (cg == 0) { row_d[s] = d; row_a[s] = a; }
+        if constexpr (CAM) {
+#pragma unroll
+            for (int o = 1; o < C4; o <<= 1) { sax += __shfl_xor(sax, o, 64); say += __shfl_xor(say, o, 64); saz += __shfl_xor(saz, o, 64); }
+            if (cg == 0) {
+                float2* sp = sab + (((long long)v * plane + pix) * S + s) * 3;
+                sp[0] = make_float2(sax, say); sp[1] = make_float2(saz, sbx); sp[2] = make_float2(sby, sbz);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");        // each ray's rows are written and read by its own C4 lanes (same wave for C4 <= 64)
     __builtin_amdgcn_wave_barrier();
@@ -327,32 +349,16 @@ __global__ __launch_bounds__(256) void render_bwd_rays_kernel(const float4* __re
         __builtin_amdgcn_wave_barrier();
         if (cg == 0) { row_d[s] = wgt; row_a[s] = dLdd; }
         T *= (1.f - d);
-        if (CAM && (wgt != 0.f || dLdd != 0.f)) {
-            // d loss / d pixel coordinate of this sample, this lane's share (its 4 channels; lane cg==0 adds the density term).
-            // Everything downstream is linear, so lanes and rays are summed once at the end.
+        if (CAM && cg == 0 && (wgt != 0.f || dLdd != 0.f)) {
+            // d loss / d sample position from the scalars pass A parked (summed over the ray's channel lanes there); everything downstream is
+            // linear, so rays are summed once at the end
+            const float2* sp = sab + (((long long)v * plane + pix) * S + s) * 3;
+            const float2 q0 = sp[0], q1 = sp[1], q2 = sp[2];
+            const float gpx = fmaf(wgt, q0.x, dLdd * q1.y), gpy = fmaf(wgt, q0.y, dLdd * q2.x), gpz = fmaf(wgt, q1.x, dLdd * q2.y);
             const float z = sample_depth(s, S, zmin, zmax, step);
-            const float px = (((ray.ox + ray.dx * z) / hx + 1.f) / 2.f) * scx;
-            const float py = (((ray.oy + ray.dy * z) / hy + 1.f) / 2.f) * scy;
-            const float pz = (((ray.oz + ray.dz * z) / hz + 1.f) / 2.f) * scz;
-            Taps t;
-            taps_ac_true(px, py, pz, W, H, D, t);
-            if (t.any) {
-                float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-                    const long long o = tap_off(t, k);
-                    const float4 fv = F[o * C4];
-                    float q = wgt * (fv.x * g.x + fv.y * g.y + fv.z * g.z + fv.w * g.w);
-                    if (cg == 0) q = fmaf(Dn[o], dLdd, q);
-                    gpx = fmaf(t.bx[dx] * t.ay[dy] * t.az[dz], q, gpx);
-                    gpy = fmaf(t.ax[dx] * t.by[dy] * t.az[dz], q, gpy);
-                    gpz = fmaf(t.ax[dx] * t.ay[dy] * t.bz[dz], q, gpz);
-                }
-                const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;
-                Go[0] = fmaf(kx, gpx, Go[0]); Go[1] = fmaf(ky, gpy, Go[1]); Go[2] = fmaf(kz, gpz, Go[2]);
-                Gd[0] = fmaf(kx * z, gpx, Gd[0]); Gd[1] = fmaf(ky * z, gpy, Gd[1]); Gd[2] = fmaf(kz * z, gpz, Gd[2]);
-            }
+            const float kx = 0.5f * scx / hx, ky = 0.5f * scy / hy, kz = 0.5f * scz / hz;
+            Go[0] = fmaf(kx, gpx, Go[0]); Go[1] = fmaf(ky, gpy, Go[1]); Go[2] = fmaf(kz, gpz, Go[2]);
+            Gd[0] = fmaf(kx * z, gpx, Gd[0]); Gd[1] = fmaf(ky * z, gpy, Gd[1]); Gd[2] = fmaf(kz * z, gpz, Gd[2]);
         }
     }
     __syncthreads();
@@ -634,13 +640,16 @@ extern "C" int forge_render_fwd(const float* feat, const float* dens, const floa
     return 0;
 }
 
-// bytes of workspace forge_render_bwd needs: G [V][Hr][Wr][S] float2 (+ per-workgroup camera partials when dcam is requested)
-static size_t render_bwd_ws_layout(int V, int C, int Hr, int Wr, int S, int want_cam, size_t* cam_off) {
+// bytes of workspace forge_render_bwd needs: G [V][S][Hr][Wr] float2 (+ per-workgroup camera partials and the per-sample position-gradient scalars when dcam is requested)
+static size_t render_bwd_ws_layout(int V, int C, int Hr, int Wr, int S, int want_cam, size_t* cam_off, size_t* sab_off = nullptr) {
     const int C4 = C / 4, RPB = 256 / C4, TH = RPB / 8;
     const size_t g_bytes = (size_t)V * Hr * Wr * S * sizeof(float2);
     const size_t nblk = (size_t)((Wr + 7) / 8) * ((Hr + TH - 1) / TH);
+    const size_t cam_bytes = want_cam ? ((size_t)V * nblk * 16 * sizeof(float) + 15) / 16 * 16 : 0;
     if (cam_off) *cam_off = g_bytes;
-    return g_bytes + (want_cam ? (size_t)V * nblk * 16 * sizeof(float) : 0);
+    if (sab_off) *sab_off = g_bytes + cam_bytes;
+    // + with camera gradients: six position-gradient scalars per sample, [V][Hr][Wr][S][6] (render_bwd_rays_kernel, pass A -> pass C)
+    return g_bytes + cam_bytes + (want_cam ? (size_t)V * Hr * Wr * S * 6 * sizeof(float) : 0);
 }
 
 extern "C" long long forge_render_bwd_ws_bytes(int V, int C, int Hr, int Wr, int S, int want_cam) {
@@ -656,8 +665,8 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
     if (int rc = check_render_args("forge_render_bwd", feat, dens, cam, view2vol, V, nvol, C, D, H, W, Hr, Wr, S, hx, hy, hz)) return rc;
     FORGE_REQUIRE(g_feat && g_opac && dfeat && ddens, FORGE_EINVAL, "forge_render_bwd: null gradient pointer");
     FORGE_REQUIRE(nvol <= 65535, FORGE_ESHAPE, "forge_render_bwd: nvol=%d exceeds gridDim.y", nvol);
-    size_t cam_off = 0;
-    const size_t need = render_bwd_ws_layout(V, C, Hr, Wr, S, dcam != nullptr, &cam_off);
+    size_t cam_off = 0, sab_off = 0;
+    const size_t need = render_bwd_ws_layout(V, C, Hr, Wr, S, dcam != nullptr, &cam_off, &sab_off);
     FORGE_REQUIRE(ws && ws_bytes >= (long long)need, FORGE_EINVAL, "forge_render_bwd: workspace of %lld B given, %zu B needed (forge_render_bwd_ws_bytes)",
                   ws_bytes, need);
     FORGE_REQUIRE(((size_t)ws & 15) == 0, FORGE_EINVAL, "forge_render_bwd: workspace must be 16-byte aligned");
@@ -665,6 +674,7 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
     FORGE_REQUIRE(lds_bytes <= 160 * 1024 - 2048, FORGE_ESHAPE, "forge_render_bwd: S=%d needs %zu B of LDS (> 160 KiB)", S, lds_bytes);
     float2* G = (float2*)ws;
     float* cam_part = (float*)((char*)ws + cam_off);
+    float2* sab = (float2*)((char*)ws + sab_off);
     const long long nvox = (long long)D * H * W;
     FORGE_REQUIRE((nvox + 255) / 256 < (1ll << 31), FORGE_ESHAPE, "forge_render_bwd: grid too large");
     FORGE_DISPATCH_C4(C, {
@@ -675,13 +685,13 @@ extern "C" int forge_render_bwd(const float* feat, const float* dens, const floa
         if (dcam) {
             FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, true>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_rays_kernel<C4, true>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, sab, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
             hipLaunchKernelGGL(render_bwd_cam_reduce_kernel, dim3(V), dim3(256), 0, (hipStream_t)stream, (const float*)cam_part, dcam, V,
                                (int)(nxg * nyg));
         } else {
             FORGE_SET_MAX_LDS_ONCE((render_bwd_rays_kernel<C4, false>), 160 * 1024 - 2048);
             hipLaunchKernelGGL((render_bwd_rays_kernel<C4, false>), grid, dim3(256), lds_bytes, (hipStream_t)stream, (const float4*)feat, dens, cam,
-                               view2vol, g_feat, g_opac, g_depth, G, cam_part, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
+                               view2vol, g_feat, g_opac, g_depth, G, cam_part, sab, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz, V, band_order);
         }
         hipLaunchKernelGGL(render_bwd_voxels_kernel<C4>, dim3((unsigned)((nvox + 255) / 256), nvol), dim3(256), 0, (hipStream_t)stream, cam, view2vol,
                            g_feat, (const float2*)G, dfeat, ddens, V, D, H, W, Hr, Wr, S, zmin, zmax, hx, hy, hz);

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
 // Gradient w.r.t. the 3x4 affine (pose refinement): per OUTPUT voxel, the upstream gradient dotted with the 8 source taps
 // and chained through the trilinear weights; block reduction + 12 atomics per workgroup. (The volume gradient is the gather
 // kernel below; its first version scatter-added 8 x C fp32 atomics per voxel from here.)
-constexpr int AFF_ITER = 8;
+constexpr int AFF_ITER = 8;            // (4: 82 us, 8: 78, 16: 80, 32: 129 - too few workgroups)
 
 __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __restrict__ dout, const float4* __restrict__ vox,
                                                          const float* __restrict__ xf, const int* __restrict__ mode,
@@ -175,18 +175,26 @@ __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __
         const float4 g = dout[(long long)(src_slot ? src_slot[n] : n) * per_vol + e];     // forge_rotate_fwd_slots stored view n at volume slot[n]
         const long long sW = C4, sH = (long long)W * C4, sD = (long long)H * W * C4;
         float gsx = 0.f, gsy = 0.f, gsz = 0.f;   // d loss / d pixel coordinate
+        // all eight corners are loaded unconditionally (out-of-grid corners read a clamped address and are zeroed by a select): no branch sits
+        // between the gathers, so they are in flight together
+        float4 sv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
             const int xi = t.x0 + dx, yi = t.y0 + dy, zi = t.z0 + dz;
-            if ((unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H && (unsigned)zi < (unsigned)D) {
-                const float wx = dx ? t.wx1 : t.wx0, wy = dy ? t.wy1 : t.wy0, wz = dz ? t.wz1 : t.wz0;
-                const float4 s = vox[(long long)n * per_vol + zi * sD + yi * sH + xi * sW + c4];
-                const float dot = s.x * g.x + s.y * g.y + s.z * g.z + s.w * g.w;
-                gsx += (dx ? 1.f : -1.f) * wy * wz * dot;
-                gsy += (dy ? 1.f : -1.f) * wx * wz * dot;
-                gsz += (dz ? 1.f : -1.f) * wx * wy * dot;
-            }
+            const bool ok = (unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H && (unsigned)zi < (unsigned)D;
+            const int xc = min(max(xi, 0), W - 1), yc = min(max(yi, 0), H - 1), zc = min(max(zi, 0), D - 1);
+            const float4 s = vox[(long long)n * per_vol + zc * sD + yc * sH + xc * sW + c4];
+            sv[k] = ok ? s : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+            const float wx = dx ? t.wx1 : t.wx0, wy = dy ? t.wy1 : t.wy0, wz = dz ? t.wz1 : t.wz0;
+            const float dot = sv[k].x * g.x + sv[k].y * g.y + sv[k].z * g.z + sv[k].w * g.w;
+            gsx += (dx ? 1.f : -1.f) * wy * wz * dot;
+            gsy += (dy ? 1.f : -1.f) * wx * wz * dot;
+            gsz += (dz ? 1.f : -1.f) * wx * wy * dot;
         }
         // d pixel / d s = N/2 per axis (align_corners=False)
         gsx *= 0.5f * (float)W; gsy *= 0.5f * (float)H; gsz *= 0.5f * (float)D;

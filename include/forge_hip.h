@@ -143,7 +143,8 @@ int forge_pack_cameras(const float* R, long long r0, long long r1, long long r2,
  *   dfeat  [nvol][D][H][W][C], ddens [nvol][D][H][W]   WRITTEN (every element; no zero-fill needed, nothing accumulated)
  *   dcam   [V][16] nullable, WRITTEN: d loss / d (R, T, fx, fy, cx, cy)
  *   ws     caller-owned scratch of at least forge_render_bwd_ws_bytes(V, C, Hr, Wr, S, dcam != NULL) bytes, 16-byte aligned
- *          (8 V Hr Wr S bytes + 64 bytes per 8 x (64 / (C/4)) pixel tile and view when dcam is requested); no allocation inside.
+ *          (8 V Hr Wr S bytes; when dcam is requested + 64 bytes per 8 x (64 / (C/4)) pixel tile and view + 24 V Hr Wr S bytes of per-sample
+ *          position-gradient scalars that the ray pass's forward march leaves for its own backward sweep); no allocation inside.
  */
 long long forge_render_bwd_ws_bytes(int V, int C, int Hr, int Wr, int S, int want_cam);     /* < 0: unsupported arguments */
 int forge_render_bwd(const float* feat, const float* dens, const float* cam, const int* view2vol,

@@ -828,6 +828,7 @@ def extra_configs(dev, steps=5):
     except Exception as e:
         out.append({"name": "train_step_4_scenes_grid64", "error": repr(e)[:300]})
     torch.cuda.empty_cache()
+    out.extend(joint_configs(dev, steps=max(3, steps // 2)))
     # the same step captured into ONE hipGraph (forge_amd.graph.GraphedStep: forward, loss, backward, clip, capturable Adam) - single-process
     # training is host-bound at one scene (~1000 launches per step); reported beside the eager number, which is what a DDP wrapper runs
     try:
@@ -853,6 +854,109 @@ def extra_configs(dev, steps=5):
         ts = [x for x in out if x.get("name") == "train_step"]
         if ts:
             ts[-1]["hipgraph_replay"] = {"error": repr(e)[:200]}
+    return out
+
+
+def joint_stock_share():
+    """Share of the joint step's kernel time spent in stock-torch (MIOpen / rocBLAS / ATen) kernels, from the committed rocprofv3 kernel trace
+    of tools/joint_step_probe.py (profiles/r05_joint_*_kernel_share.json, written by tools/joint_kernel_share.py): a per-name attribution the
+    process cannot make about itself. None when no profile is committed."""
+    import glob
+    res = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_joint_*kernel_share.json"))):
+        try:
+            d = json.load(open(f))
+            res[d.get("workload", os.path.basename(f))] = {"stock_torch_share_of_kernel_time": d["stock_share"], "forge_share_of_kernel_time": d["forge_share"],
+                                                           "kernel_ms_per_step": d.get("kernel_ms_per_step"), "source": os.path.basename(f)}
+        except Exception:
+            continue
+    return res or None
+
+
+def joint_configs(dev, steps=5):
+    """BASELINE configs[4] on one GPU: the joint 2D3D fine-tune iteration of kubric_train_joint.py:111-141 - FORGE with
+    PREDICTED poses (2-D + 3-D pose estimators and the pose head on stock torch kernels; encoder / rotate / fusion / heads / ray-march /
+    conv_rgb on the HIP kernels), 5 input + 5 novel views, compute_all_loss_nvs (scripts/kubric_compute_loss.py:121-172), backward through the
+    pose chain (rotate's d pose, the ray-marcher's d(R, T)), clip 10, Adam over the parameter list of kubric_train_joint.py:111-116.
+      joint_step          reference-native grids (32^3 features, 64^3 render volume)
+      joint_step_grid64   the configuration's 128^3-voxel scenes: synthetic [1,5,128,64^3] feature volumes enter the reconstruction
+                          (FORGE.forward(features_recon=...)), the pose networks keep their native inputs
+    Each entry: ms_per_step, views_per_s, `roofline` = the FLOPs libforge's matrix-core launches execute as a time floor (stock-torch FLOPs are
+    counted separately by torch's FlopCounterMode and NOT part of that floor), and `stock_torch` = the pose networks' own forward + backward
+    timed alone on the same inputs (live) beside the per-kernel-name share of a committed rocprofv3 trace."""
+    from forge_amd import train
+    from forge_amd.flopmeter import FlopMeter
+    from forge_amd.model import FORGE
+    out = []
+    cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+    cfg.loss.regu_origin_proj = 1.0                                   # config/kubric/joint_pose_2d3d.yaml:34-38 (perceptual term: no VGG weights offline)
+    ds = syn.SyntheticDataset(1.5)
+    try:
+        model = FORGE(cfg)
+        model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+        model = model.to(dev).train()
+        params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render)
+                  for p in m.parameters()]                            # kubric_train_joint.py:111-116
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
+        gen = torch.Generator(device=dev).manual_seed(79)
+        f64 = torch.randn(1, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+    except Exception as e:
+        return [{"name": "joint_step", "error": repr(e)[:300]}]
+
+    def make_step(feats):
+        call = model if feats is None else (lambda s, d, dv: model(s, d, dv, features_recon=feats))
+
+        def step():
+            loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call, {}, dev)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            opt.step()
+            return loss
+        return step
+
+    def pose_nets_only():
+        """the stock-torch part alone: both pose estimators + pose head forward and backward on the step's own (detached) inputs"""
+        with torch.no_grad():
+            clips = sample["images"][:, :T_IN]
+            feats = model.encoder_3d.get_feat3D(clips.reshape(T_IN, 3, 256, 256)).reshape(1, T_IN, 128, 32, 32, 32)
+        feats = feats.detach().requires_grad_(True)
+
+        def run():
+            _, _, pose = model.predict_poses(feats, clips, sample, ds, dev)
+            (pose["pred"].square().sum() + pose["conf"].sum()).backward()
+            for p in model.parameters():
+                p.grad = None
+            feats.grad = None
+        return run
+
+    share = joint_stock_share()
+    for name, feats, workload in (
+            ("joint_step", None, "BASELINE configs[4] step at the reference-native grids: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input + 5 novel "
+             "views 256^2 -> 10 rendered views, compute_all_loss_nvs, backward incl. the pose chain, clip 10, Adam; train-mode BatchNorm / Dropout; eager launch"),
+            ("joint_step_grid64", f64, "BASELINE configs[4] at its 128^3-voxel grid: the same step with 5 synthetic [128,64^3] feature volumes entering rotate(D=64) -> "
+             "fusion at M=262144 -> heads -> 128^3 x 17 volume -> 10 rendered views; pose networks on their native inputs; eager launch")):
+        try:
+            step = make_step(feats)
+            step()                                                    # allocator / MIOpen solver warm-up outside the meters
+            torch.cuda.synchronize()
+            from torch.utils.flop_counter import FlopCounterMode
+            with FlopMeter() as fm, FlopCounterMode(display=False) as fc:
+                step()
+            torch.cuda.synchronize()
+            ms = _timed(step, steps, warm=1)
+            ms_pose = _timed(pose_nets_only(), steps, warm=1)
+            e = {"name": name, "workload": workload, "steps": steps, "ms_per_step": ms, "views_per_s": 10 / ms * 1e3,
+                 "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches,
+                                  note="executed_gflop = libforge matrix-core launches only; the stock-torch pose networks' FLOPs are in stock_torch.gflop"),
+                 "stock_torch": {"what": "2-D + 3-D pose estimators and pose head (MIOpen / rocBLAS / ATen kernels): forward + backward timed alone on the step's inputs",
+                                 "pose_nets_fwd_bwd_ms": ms_pose, "share_of_step": ms_pose / ms, "gflop": fc.get_total_flops() / 1e9,
+                                 "rocprofv3": (share or {}).get(name)}}
+            out.append(e)
+        except Exception as e:
+            out.append({"name": name, "workload": workload, "error": repr(e)[:300]})
+        torch.cuda.empty_cache()
     return out
 
 

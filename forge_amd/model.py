@@ -83,7 +83,24 @@ class FORGE(nn.Module):
             cache[key] = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
         return cache[key]
 
-    def forward(self, sample, dataset, device):
+    def predict_poses(self, features_raw, clips, sample, dataset, device):
+        """models/model.py:60-84 - relative poses of views 1..t-1 from the 3-D pose estimator (on the per-view feature volumes) and the 2-D pose
+        estimator (on the images), joined by the pose head; quaternion normalised, toSE3, chained onto the canonical camera.
+        Returns (camPoses_cv2 [b,t,4,4], camE_cv2 [b,t,4,4], {'gt', 'pred', 'conf'})."""
+        b, t = features_raw.shape[:2]
+        pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True),            # [b(t-1),1024] each
+                               self.encoder_traj_2d(clips, return_features=True)], dim=-1)
+        pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
+        pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
+            pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
+            dataset.get_canonical_extrinsics_cv2(device=device), b, t)
+        gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
+        return camPoses_cv2, camE_cv2, {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
+
+    def forward(self, sample, dataset, device, features_recon=None):
+        """models/model.py:42-148. `features_recon` (not in the reference): per-view feature volumes [b,5,C,D,D,D] that replace the encoder's
+        in the reconstruction (rotate -> fuse -> heads -> render) while the pose estimators keep their native inputs - BASELINE configs[4]'s
+        128^3-voxel scenes need D = 64 volumes, which the encoder cannot produce from 256^2 images (models/encoder.py:49)."""
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
         b, t_all = sample["images"].shape[:2]
         clips = sample["images"][:, :self.N_INPUT]
@@ -93,14 +110,7 @@ class FORGE(nn.Module):
         features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
-            pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True),            # [b(t-1),1024] each
-                                   self.encoder_traj_2d(clips, return_features=True)], dim=-1)
-            pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
-            pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
-                pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
-                dataset.get_canonical_extrinsics_cv2(device=device), b, t)
-            gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
-            camPose_return = {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
+            camPoses_cv2, camE_cv2, camPose_return = self.predict_poses(features_raw, clips, sample, dataset, device)
         else:
             suffix = "_canonicalized" if self.config.train.canonicalize else ""
             camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t]
@@ -117,7 +127,8 @@ class FORGE(nn.Module):
         assert V == t_all, "sample must carry intrinsics for every rendered camera"
         cameras = geo_utils.camera_dict(camE_all, sample["K_cv2"])
 
-        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras)       # views ordered by distance
+        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw if features_recon is None else features_recon,
+                                                                      camPoses_cv2[:, :t], cameras)                      # views ordered by distance
         if self.config.train.use_gt_pose:
             return rendered_imgs, rendered_masks
         return rendered_imgs, rendered_masks, 2 * origin_proj / self.config.dataset.img_size, camPose_return

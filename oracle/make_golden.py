@@ -141,6 +141,37 @@ def main():
         npz("state_dict_keys_joint", keys=keys, shapes=np.array([str(shapes[k]) for k in keys]))
 
 
+class _Dataset64:
+    """SyntheticDataset handing out float64 canonical cameras (the float64 yardstick runs)."""
+
+    def __init__(self, ds):
+        self.ds = ds
+
+    def get_canonical_extrinsics_cv2(self, device="cpu"):
+        return self.ds.get_canonical_extrinsics_cv2(device).double()
+
+    def get_canonical_pose_cv2(self, device="cpu"):
+        return self.ds.get_canonical_pose_cv2(device).double()
+
+
+def to_float64(model, sample):
+    """The reference model and a sample in float64: parameters / buffers through .double(), plus the plain tensor attributes the reference keeps
+    outside the state_dict (models/rotate.py:18-35 grid_coord*, the pose transformer's positional table)."""
+    model.double()
+    for mod in model.modules():
+        for k, v in list(vars(mod).items()):
+            if torch.is_tensor(v) and v.is_floating_point():
+                setattr(mod, k, v.double())
+    return model, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sample.items()}
+
+
+def yardstick(g32, g64):
+    """(max|g32 - g64| / max|g64|, 1 - cos(g32, g64)): how far the reference's own fp32 gradient sits from its float64 evaluation."""
+    a, b = g32.double().flatten(), g64.double().flatten()
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item() if a.numel() > 1 else 1.0
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300), 1.0 - cos
+
+
 TRAIN_KEYS = ["encoder_3d.feature_extraction.0.weight", "encoder_3d.feature_extraction.7.2.bn3.weight", "encoder_3d.conv1.0.bias",
               "encoder_3d.conv1.1.weight", "encoder_3d.fusion_feature.cells.0.conv_gate.bias", "encoder_3d.fusion_feature.cells.0.out_gate.bias",
               "encoder_3d.fusion_feature.fusion_conv.4.weight", "encoder_3d.fusion_feature.fusion_norm.weight",
@@ -178,6 +209,27 @@ def train_goldens(m):
     print("  training: loss reference %.6f oracle %.6f" % (float(loss), float(lo)))
     for k in TRAIN_KEYS:
         err("grad " + k.split(".", 1)[1][-34:], named[k].grad, wo[k].grad)
+    # float64 yardstick: the SAME reference graph evaluated in double - the fixture carries the float64 gradients (rounded
+    # to fp32 for storage: 6e-8 relative) and how far the reference's own fp32 run sits from them, per key
+    m64 = m["models.model_single_pose_estimator"].FORGE_poseEstimator3D(cfg)
+    m64.load_state_dict(sdm)
+    m64.train()
+    m64, s64 = to_float64(m64, sample)
+    torch.set_default_dtype(torch.float64)          # the reference's own fp32 literals (torch.eye(4), torch.zeros(...)) become float64 for this run only
+    try:
+        i64, k64 = m64(s64, _Dataset64(ds), "cpu")
+        l64 = 5.0 * torch.nn.functional.mse_loss(i64, tgt_i.double()) + torch.nn.functional.mse_loss(k64, tgt_m.double())
+        l64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    n64 = dict(m64.named_parameters())
+    out["loss64"] = float(l64)
+    print("  training: loss float64 %.9f (fp32 reference off by %.2e)" % (float(l64), abs(float(l64) - float(loss))))
+    for k in TRAIN_KEYS:
+        e, c = yardstick(named[k].grad, n64[k].grad)
+        out["grad64__" + k] = n64[k].grad.float()
+        out["g64err__" + k], out["g64cos__" + k] = e, c
+        print("    fp32 reference vs its float64 evaluation %-52s err/max %.2e  1-cos %.2e" % (k[-52:], e, c))
     npz("train_pose3d", **out)
 
 
@@ -249,8 +301,99 @@ def joint_goldens(m):
     npz("forward_joint", **out)
 
 
+JOINT_TRAIN_KEYS = ["pose_head.1.weight", "pose_head.2.weight", "pose_head.4.weight", "pose_head.4.bias",
+                    "encoder_traj.conv3d_1.0.weight", "encoder_traj.pose_head_1.0.bias", "encoder_traj.pose_head_1.1.weight",
+                    "encoder_traj.pose_head_1.3.weight", "encoder_traj.conv3d_3.3.weight",
+                    "encoder_traj_2d.conv.9.weight", "encoder_traj_2d.conv.10.weight",
+                    "encoder_3d.feature_extraction.0.weight", "encoder_3d.feature_extraction.7.2.bn3.weight",
+                    "encoder_3d.conv1.0.weight", "encoder_3d.conv1.1.weight",
+                    "encoder_3d.fusion_feature.cells.0.conv_gate.weight", "encoder_3d.fusion_feature.cells.0.conv_gate.bias",
+                    "encoder_3d.fusion_feature.cells.0.out_gate.weight", "encoder_3d.fusion_feature.cells.0.out_gate.bias",
+                    "encoder_3d.fusion_feature.fusion_conv.4.weight", "encoder_3d.fusion_feature.fusion_norm.weight",
+                    "encoder_3d.features_head.0.weight", "encoder_3d.features_head.3.bias",
+                    "encoder_3d.density_head.3.bias", "encoder_3d.density_head.6.weight",
+                    "render.conv_rgb.0.weight", "render.conv_rgb.3.weight", "render.conv_rgb.6.weight", "render.conv_rgb.6.bias"]
+JOINT_SUB_LIMIT = 4096          # gradients with more elements are stored as a strided sample of the flattened tensor + their L2 norm / max
+
+
+def grad_sample_stride(numel):
+    """Stride of the flattened sample a large gradient is stored with (odd, so that it walks all residues of the inner dimensions)."""
+    s = max(1, numel // JOINT_SUB_LIMIT)
+    return s | 1
+
+
+def train_joint_goldens(m):
+    """BASELINE configs[4], the joint 2D3D fine-tune iteration of the REFERENCE itself: scripts/kubric_compute_loss.py:121-172
+    `compute_all_loss_nvs` (recon_rgb 5, recon_mask 1, regu_origin_proj 1: config/kubric/joint_pose_2d3d.yaml:34-38; perceptual 0 - no VGG
+    weights offline) on models/model.py:18-148 `FORGE(use_gt_pose=False, parameter='joint')`, then backward: the gradient reaches the pose
+    head and both pose estimators through toSE3 <- rotate's d(pose) and the ray-marcher's d(R, T) as well as through the pose / translation
+    MSE terms. BatchNorm on running statistics and Dropout off (two evaluations are then comparable; kubric_train_joint.py itself runs
+    .train()). Seeded sample / weights, neither stored. The fixture holds the seven loss terms, the predicted poses and the gradients of
+    parameters from every sub-network (large ones as a strided sample + norm)."""
+    import importlib
+    from easydict import EasyDict
+    kcl = importlib.import_module("scripts.kubric_compute_loss")
+    cfg = ref_import.kubric_config(use_gt_pose=False, parameter="joint")
+    cfg.loss = EasyDict({"recon_rgb": 5.0, "recon_mask": 1.0, "perceptual_img": 0.0, "regu_origin_proj": 1.0})
+    jm = m["models.model"].FORGE(cfg)
+    jm.load_state_dict(syn.seeded_state_dict(jm.state_dict(), 0))
+    jm.train()
+    for mod in jm.modules():
+        if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Dropout)):
+            mod.eval()
+    sample = syn.make_sample(1, 10, 256, 1.5, seed=12)
+    ds = syn.SyntheticDataset(1.5)
+    loss, terms, imgs, masks = kcl.compute_all_loss_nvs(cfg, 0, {k: v.clone() for k, v in sample.items()}, ds, jm, {}, "cpu", None)
+    loss.backward()
+    named = dict(jm.named_parameters())
+    print("  parameters the joint step leaves without a gradient:", sorted({k.rsplit(".", 2)[0] for k, p in named.items() if p.grad is None}))
+    out = {"sample_seed": 12, "weight_seed": 0, "loss": float(loss), "recon_rgb": 5.0, "recon_mask": 1.0, "regu_origin_proj": 1.0,
+           "imgs_sub": imgs.detach()[0, :, :, ::16, ::16], "masks_sub": masks.detach()[0, :, :, ::16, ::16], "masks_mean": masks.detach().mean(dim=(2, 3, 4))[0]}
+    for k, v in terms.items():
+        out["term__" + k] = float(v)
+    print("  joint training (reference): loss %.6f terms %s mask mean %.4f" % (float(loss), {k: round(v, 6) for k, v in terms.items()}, masks.mean().item()))
+    # float64 yardstick of the same step (see train_goldens)
+    j64 = m["models.model"].FORGE(cfg)
+    j64.load_state_dict(syn.seeded_state_dict(j64.state_dict(), 0))
+    j64.train()
+    for mod in j64.modules():
+        if isinstance(mod, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Dropout)):
+            mod.eval()
+    j64, s64 = to_float64(j64, sample)
+    torch.set_default_dtype(torch.float64)          # models/utils literals (torch.eye(4) in quat2mat, utils/geo_utils.py:115) become float64 for this run only
+    try:
+        l64, t64, _, _ = kcl.compute_all_loss_nvs(cfg, 0, s64, _Dataset64(ds), j64, {}, "cpu", None)
+        l64.backward()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    n64 = dict(j64.named_parameters())
+    out["loss64"] = float(l64)
+    for k, v in t64.items():
+        out["term64__" + k] = float(v)
+    print("  joint training: loss float64 %.9f (fp32 reference off by %.2e)" % (float(l64), abs(float(l64) - float(loss))))
+    for k in JOINT_TRAIN_KEYS:
+        g = named[k].grad
+        assert g is not None, k
+        flat, flat64 = g.flatten(), n64[k].grad.flatten()
+        out["gnorm__" + k] = float(flat.double().norm())
+        out["gmax__" + k] = float(flat.abs().max())
+        out["g64norm__" + k] = float(flat64.norm())
+        out["g64max__" + k] = float(flat64.abs().max())
+        out["g64err__" + k], out["g64cos__" + k] = yardstick(g, n64[k].grad)
+        if flat.numel() > JOINT_SUB_LIMIT:
+            st = grad_sample_stride(flat.numel())
+            out["gstride__" + k] = st
+            out["gsub__" + k], out["gsub64__" + k] = flat[::st], flat64[::st].float()
+            out["g64suberr__" + k], out["g64subcos__" + k] = yardstick(flat[::st], flat64[::st])
+        else:
+            out["grad__" + k], out["grad64__" + k] = g, n64[k].grad.float()
+        print("    grad %-66s |g|max %.3e norm %.3e %-4s fp32 vs float64: err/max %.2e 1-cos %.2e"
+              % (k, out["gmax__" + k], out["gnorm__" + k], "sub" if flat.numel() > JOINT_SUB_LIMIT else "full", out["g64err__" + k], out["g64cos__" + k]))
+    npz("train_joint", **out)
+
+
 if __name__ == "__main__":
-    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens}
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens}
     if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
         single[sys.argv[1]](ref_import.import_reference())
@@ -259,3 +402,4 @@ if __name__ == "__main__":
         loss_goldens(ref_import.import_reference())
         train_goldens(ref_import.import_reference())
         joint_goldens(ref_import.import_reference())
+        train_joint_goldens(ref_import.import_reference())

@@ -28,7 +28,7 @@ class NDCGridRaysampler(torch.nn.Module):
     def forward(self, cameras, **kwargs):
         batch_size = cameras.R.shape[0]
         device = cameras.device
-        xy_grid = self._xy_grid.to(device)[None].expand(batch_size, *self._xy_grid.shape)
+        xy_grid = self._xy_grid.to(device=device, dtype=cameras.R.dtype)[None].expand(batch_size, *self._xy_grid.shape)
         spatial = xy_grid.shape[1:-1]
         n_rays = spatial[0] * spatial[1]
         depths = torch.linspace(self._min_depth, self._max_depth, self._n_pts_per_ray,

@@ -21,6 +21,12 @@ Every expected value below is evaluated in float64 numpy / python loops from tho
   impulse           one voxel at an off-centre, all-different index of a non-cubic grid, rotated camera with fx != fy, cx != cy:
                     hit pixel = floor(OpenCV projection of the voxel centre); full opacity / feature image from the tent-product formula
   impulse_on_sample the same with a depth sample placed exactly on the voxel centre: opacity == d0 at the hit pixel
+  impulse_tall      a TALL render target (Hr = 44 > Wr = 26; every other case is wider than tall or square): NDCGridRaysampler's second
+                    non-square branch (range_y = H / W, range_x = 1) and cameras_from_opencv_projection's min(H, W) scale with H != W
+  slab_tall         a constant slab on the tall target, pixels in the corners of the long axis
+
+All cases with Hr != Wr also pin the PyTorch3D restatement used for the golden import (oracle/shims/pytorch3d: test_oracle_golden.py::
+test_pytorch3d_shim_reproduces_analytic_kats_on_non_square_targets), in both of its non-square branches.
 """
 import math
 
@@ -165,6 +171,25 @@ def cases():
     proj, ef, eo, ed = impulse_case((D, D, D), 1.0, idx, 0.6, fv, cam, 16, 24, 2, zc, zc + 0.5)
     out.append({"name": "impulse_on_sample", "dims": (D, D, D), "vol": 1.0, "dens": dens, "feat": feat, "cam": cam, "Hr": 16, "Wr": 24, "S": 2, "zmin": zc,
                 "zmax": zc + 0.5, "proj": proj, "expect_feat": ef, "expect_opacity": eo, "expect_depth": ed, "hit": (h0, w0), "hit_opacity": 0.6})
+    # -- impulse_tall / slab_tall: Hr > Wr (PyTorch3D's NDC range is 1 along the SHORT side: range_y = Hr / Wr here)
+    a, b = math.radians(-25.0), math.radians(15.0)
+    Ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    cam = _camera(Rx @ Ry, [-0.05, 0.12, 2.2], 60.0, 85.0, 11.0, 24.5)
+    dims = (10, 14, 6)
+    idx, d0, fv = (7, 3, 4), 0.9, [0.5, 1.0, -1.5, 2.5]
+    dens = np.zeros(dims)
+    dens[idx] = d0
+    feat = np.zeros((4,) + dims)
+    feat[(slice(None),) + idx] = fv
+    proj, ef, eo, ed = impulse_case(dims, 1.0, idx, d0, fv, cam, 44, 26, 120, 1.0, 3.5)
+    out.append({"name": "impulse_tall", "dims": dims, "vol": 1.0, "dens": dens, "feat": feat, "cam": cam, "Hr": 44, "Wr": 26, "S": 120, "zmin": 1.0, "zmax": 3.5,
+                "proj": proj, "expect_feat": ef, "expect_opacity": eo, "expect_depth": ed})
+    fv = [0.3, -0.6, 1.2, 0.9]
+    cam = _camera(np.eye(3), [0.0, 0.0, 1.5], 30.0, 36.0, 13.0, 22.0)
+    px = [(22, 13), (0, 0), (43, 25), (43, 0), (5, 20), (40, 12)]
+    out.append({"name": "slab_tall", "dims": (D, D, D), "vol": 1.0, "dens": np.full((D, D, D), 0.2), "feat": np.tile(np.array(fv)[:, None, None, None], (1, D, D, D)),
+                "cam": cam, "Hr": 44, "Wr": 26, "S": 48, "zmin": 0.5, "zmax": 2.5, "expect_pixels": slab_case((D, D, D), 1.0, 0.2, fv, cam, px, 48, 0.5, 2.5)})
     return out
 
 

@@ -14,6 +14,7 @@ import torch
 import forge_oracle as fo
 import kat_render
 from forge_amd import geo_utils, ops, synthetic as syn
+from test_gpu_parity import assert_forward_close
 
 pytestmark = pytest.mark.gpu
 T = lambda a: torch.from_numpy(np.asarray(a))
@@ -106,6 +107,114 @@ def test_pose3d_predicted_pose_forward_vs_reference_golden(dev, golden):
     assert (imgs.cpu().mean(dim=(1, 2, 3)) - T(g["pose3d__imgs_mean"])).abs().max().item() < 2e-4 * scale, stats
 
 
+# ------------------------------------------------------------------------------------------------------------- configs[4] training step
+def joint_training_step(dev, cfg=None, weight_seed=0, sample_seed=12):
+    """One joint 2D3D fine-tune iteration up to the gradients (kubric_train_joint.py:111-141 -> compute_all_loss_nvs -> backward): FORGE with
+    predicted poses in train mode, BatchNorm on running statistics and Dropout off as in the golden, the stock-torch pose networks pinned to
+    their deterministic backward algorithms (tests/test_gpu_ddp.py::_joint_step explains why). Returns (loss, terms, model, imgs, masks)."""
+    from forge_amd import train
+    from forge_amd.model import FORGE
+    cfg = cfg or syn.kubric_config(use_gt_pose=False, parameter="joint")
+    det = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        model = FORGE(cfg)
+        model.load_state_dict(syn.seeded_state_dict(model.state_dict(), weight_seed))
+        model = model.to(dev).train()
+        for m in model.modules():
+            if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Dropout)):
+                m.eval()
+        sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=sample_seed).items()}
+        loss, terms, imgs, masks = train.compute_all_loss_nvs(cfg, 0, sample, syn.SyntheticDataset(1.5), model, {}, dev)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        torch.use_deterministic_algorithms(False)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = det
+    return loss.detach(), terms, model, imgs.detach(), masks.detach()
+
+
+def grad_distance(got, ref):
+    """(max |got - ref| / max |ref|, 1 - cos) of two gradient tensors, in float64."""
+    a, b = got.double().flatten(), ref.double().flatten()
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item() if a.numel() > 1 else 1.0
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300), 1.0 - cos
+
+
+def check_gradients_vs_float64_golden(g, named, factor, floor=3e-4, report=None):
+    """The float64-referenced gradient bound. The fixtures carry, per key, the REFERENCE's float64 gradient (grad64__ /
+    gsub64__: the same graph evaluated in double by oracle/make_golden.py) and how far the reference's own fp32 gradient sits from it
+    (g64err__ / g64cos__, on the stored sample g64suberr__ / g64subcos__). Asserted per key:
+        err(HIP, f64) <= factor * err(ref fp32, f64) + floor          (both as max-abs / max |g64|)
+        1 - cos(HIP, f64) <= factor^2 * (1 - cos(ref fp32, f64)) + 1e-6
+    `floor`: 3e-4 of the tensor's max - bias / BatchNorm-weight gradients are sums of 1e5..1e6 fp32 terms, where a different summation order
+    alone moves the result by 1e-4 (40x below the 1e-2 band this bound replaces). Keys whose float64 gradient is exactly cancellation
+    (|g64| < 1e-6 of the largest gradient: biases in front of a train-mode BatchNorm) are skipped."""
+    keys = [k[len("g64err__"):] for k in g.files if k.startswith("g64err__")]
+    scale = max(float(np.abs(g["grad64__" + k] if "grad64__" + k in g.files else g["gsub64__" + k]).max()) for k in keys)
+    bad, rows = [], []
+    for k in keys:
+        got = named[k].grad
+        assert got is not None, k
+        flat = got.detach().flatten().cpu()
+        if "gsub64__" + k in g.files:
+            flat, ref64 = flat[::int(g["gstride__" + k])], T(g["gsub64__" + k])
+            e32, c32 = float(g["g64suberr__" + k]), float(g["g64subcos__" + k])
+        else:
+            ref64 = T(g["grad64__" + k]).flatten()
+            e32, c32 = float(g["g64err__" + k]), float(g["g64cos__" + k])
+        if float(ref64.abs().max()) < 1e-6 * scale:
+            continue
+        e, c = grad_distance(flat, ref64)
+        rows.append((k, e, c, e32, c32))
+        if not (e <= factor * e32 + floor and c <= factor * factor * c32 + 1e-6):
+            bad.append((k, e, e32, c, c32))
+    if report is not None:
+        report.extend(rows)
+    if os.environ.get("FORGE_TEST_REPORT"):
+        for k, e, c, e32, c32 in rows:
+            print("  %-64s hip/f64 %.2e (1-cos %.1e)  ref32/f64 %.2e (1-cos %.1e)  ratio %.2f" % (k[-64:], e, c, e32, c32, e / max(e32, 1e-12)))
+    assert not bad, bad
+    return len(rows)
+
+
+def test_joint_training_step_vs_reference_golden(dev, golden):
+    """BASELINE configs[4] / VERDICT r4 item 1: the joint fine-tune iteration against the REFERENCE's own run of it
+    (tests/golden/train_joint.npz = scripts/kubric_compute_loss.py:121-172 `compute_all_loss_nvs` on models/model.py:18-148 `FORGE` with predicted
+    poses + backward, made in the build container by oracle/make_golden.py::train_joint_goldens, in fp32 AND in float64): the seven loss terms,
+    the rendered maps, and the gradients of the pose head, both pose estimators (stock torch, fed by rotate's d(pose) and the ray-marcher's
+    d(R, T) through toSE3), the trunk, conv1, both GRU gates, both heads and conv_rgb.
+    Bounds: loss / terms 2e-5 relative to the float64 value (the reference's fp32 loss is 8e-7 from it); gradients against the float64
+    evaluation within 3x the distance of the reference's own fp32 run (measured <= 2.2x, most keys < 1.3x: tools/debug/train_grad_margins.py),
+    and within 2e-2 of each tensor's max of the reference's fp32 gradients (two fp32 evaluations of the pose chain sit 0.5-1.5e-2 from float64
+    each: the unscaled 4096-token attention of the 3-D pose estimator amplifies rounding)."""
+    g = golden("train_joint")
+    cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+    cfg.loss.recon_rgb, cfg.loss.recon_mask, cfg.loss.regu_origin_proj = float(g["recon_rgb"]), float(g["recon_mask"]), float(g["regu_origin_proj"])
+    loss, terms, model, imgs, masks = joint_training_step(dev, cfg, int(g["weight_seed"]), int(g["sample_seed"]))
+    assert float(T(g["masks_mean"]).mean()) > 0.1                      # the scene is in view of the predicted cameras: every stage carries gradient
+    assert abs(loss.item() - float(g["loss64"])) < 2e-5 * abs(float(g["loss64"])), (loss.item(), float(g["loss64"]), float(g["loss"]))
+    for k in ("recon_img", "recon_mask", "recon_img_nvs", "recon_mask_nvs", "pose", "trans", "regu_origin"):
+        ref = float(g["term64__" + k])
+        assert abs(terms[k] - ref) < 2e-5 * max(abs(ref), 0.1), (k, terms[k], ref, float(g["term__" + k]))
+    assert (imgs[0, :, :, ::16, ::16].cpu() - T(g["imgs_sub"])).abs().max().item() < 2e-3
+    assert (masks[0, :, :, ::16, ::16].cpu() - T(g["masks_sub"])).abs().max().item() < 2e-3
+    named = dict(model.named_parameters())
+    assert check_gradients_vs_float64_golden(g, named, factor=3.0) >= 29
+    for k in [k[len("gnorm__"):] for k in g.files if k.startswith("gnorm__")]:
+        flat = named[k].grad.detach().flatten().cpu()
+        if "grad__" + k in g.files:
+            ref = T(g["grad__" + k]).flatten()
+        else:                                                          # the whole tensor through its norm, the stored sample element-wise
+            assert abs(float(flat.double().norm()) - float(g["gnorm__" + k])) < 1e-2 * float(g["gnorm__" + k]), (k, float(flat.double().norm()), float(g["gnorm__" + k]))
+            ref, flat = T(g["gsub__" + k]), flat[::int(g["gstride__" + k])]
+        assert (flat - ref).abs().max().item() < 2e-2 * float(g["gmax__" + k]), k
+    # parameters the reference's joint step leaves without a gradient stay without one here (find_unused_parameters=True territory)
+    for k in ("encoder_traj.out.0.weight", "encoder_traj_2d.out.0.weight", "rotate.conv3d_1.weight"):
+        assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
+
+
 # ------------------------------------------------------------------------------------------------------------- configs[2]
 def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
     """BASELINE configs[2]: full HIP path, batch = 8 scenes, 64^3 render grid, 1 GPU. Scenes 2 and 5 of the batch against the CPU
@@ -125,8 +234,7 @@ def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
         with torch.no_grad():
             oi, om = fo.forward_hot_path(one["images"], one["cam_poses_cv2_canonicalized"], one["cam_extrinsics_cv2_canonicalized"],
                                          one["K_cv2"], w, cfg, order_by_distance=True)
-        assert (imgs[s] - oi).abs().max().item() < 2e-3 and fo.psnr(imgs[s], oi) > 60.0, s
-        assert (masks[s] - om).abs().max().item() < 5e-4, s
+        assert_forward_close(imgs[s], oi, masks[s], om, "configs[2] scene %d of 8" % s)
     worst = 0.0
     for s in range(8):
         one = {k: v[s:s + 1].contiguous() for k, v in sample.items()}
@@ -367,9 +475,8 @@ def test_checkpoint_round_trip_reference_layout(dev, golden, tmp_path):
     with torch.no_grad():
         imgs, masks = fresh(sample, syn.SyntheticDataset(1.5), dev)               # host sample -> staged copy; caches must have been dropped
     assert not torch.equal(imgs, stale)
-    assert (imgs.cpu()[:, :, ::4, ::4] - T(g["imgs_sub"])).abs().max().item() < 2e-3
-    assert (masks.cpu()[:, :, ::4, ::4] - T(g["masks_sub"])).abs().max().item() < 5e-4
-    assert fo.psnr(imgs.cpu()[:, :, ::4, ::4], T(g["imgs_sub"])) > 60.0
+    assert_forward_close(imgs[:, :, ::4, ::4], T(g["imgs_sub"]), masks[:, :, ::4, ::4], T(g["masks_sub"]), "resumed checkpoint vs reference golden",
+                         max_abs=4e-4, psnr=90.0, mask_abs=2e-4)
     # stage hand-over into the joint model
     joint = FORGE(syn.kubric_config()).to(dev).eval()
     ck.load_encoder_pretrained(joint, str(tmp_path), strict=True, device=dev)

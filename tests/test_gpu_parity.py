@@ -4,7 +4,7 @@ against the CPU oracle and the committed golden vectors from the reference.
 Stated fp32 tolerances (the op is trilinear interpolation / compositing of O(1) values):
   rotate fwd            max-abs 2e-5          render fwd   max-abs 2e-5 (features/opacity/depth)
   backward (vs autograd through the oracle)   max-abs 1e-4 relative to the gradient scale
-  full forward vs reference golden            PSNR > 60 dB and max-abs 2e-3 (cuts through ~70 conv layers)
+  full forward vs oracle / reference golden   max-abs 2e-4 and PSNR > 95 dB (4e-4 / 90 dB against the reference's own output); measured 4.6e-5 / 110 dB
 """
 import os
 
@@ -25,6 +25,18 @@ def dev():
     from forge_amd import _lib
     _lib.lib()          # fail loudly if libforge_hip.so is missing — no fallback
     return torch.device("cuda:0")
+
+
+def assert_forward_close(imgs, oi, masks, om, tag, max_abs=2e-4, psnr=95.0, mask_abs=1e-4):
+    """Full-forward bound against the oracle / the reference golden: ~4x what is measured (max-abs 4.6e-5, 110.5 dB on the
+    bench scene; the round-4 bound of 2e-3 / 60 dB would have let a 50 dB regression pass). Relative to the image scale when the seeded
+    conv_rgb emits intensities above 1 (its ReLU is unbounded above)."""
+    imgs, masks = imgs.detach().cpu(), masks.detach().cpu()
+    scale = max(1.0, oi.abs().max().item())
+    e_i, e_m, p = (imgs - oi).abs().max().item() / scale, (masks - om).abs().max().item(), fo.psnr(imgs / scale, oi / scale)
+    if os.environ.get("FORGE_TEST_REPORT"):
+        print("  forward %-40s max-abs %.2e (scale %.2f)  mask %.2e  PSNR %.1f dB" % (tag, e_i, scale, e_m, p))
+    assert e_i < max_abs and p > psnr and e_m < mask_abs, (tag, e_i, p, e_m)
 
 
 def _cam_pack(R, Tt, Kh):
@@ -235,9 +247,8 @@ def test_forward_pose3d_golden_and_oracle(dev, golden):
     assert torch.equal(sample["K_cv2"], K_before)
     imgs, masks = imgs.cpu(), masks.cpu()
     ref_i, ref_m = T(g["imgs_sub"]), T(g["masks_sub"])
-    assert (imgs[:, :, ::4, ::4] - ref_i).abs().max().item() < 2e-3
-    assert (masks[:, :, ::4, ::4] - ref_m).abs().max().item() < 5e-4
-    assert fo.psnr(imgs[:, :, ::4, ::4], ref_i) > 60.0
+    # against the REFERENCE's own output (the oracle sits 8.7e-5 / 1e-5 from it): 4e-4 / 90 dB
+    assert_forward_close(imgs[:, :, ::4, ::4], ref_i, masks[:, :, ::4, ::4], ref_m, "pose3d vs reference golden", max_abs=4e-4, psnr=90.0, mask_abs=2e-4)
     assert (imgs.mean(dim=(1, 2, 3)) - T(g["imgs_mean"])).abs().max().item() < 1e-4
 
 
@@ -256,8 +267,7 @@ def test_forge_gt_pose_5in5out_vs_oracle(dev):
                                      sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
                                      order_by_distance=True)
     assert imgs.shape == (5, 3, 256, 256)
-    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
-    assert (masks.cpu() - om).abs().max().item() < 5e-4
+    assert_forward_close(imgs, oi, masks, om, "FORGE 5-in / 5-out (bench scene family)")
 
 
 @pytest.mark.parametrize("t", [1, 2, 3])
@@ -277,8 +287,7 @@ def test_forge_ragged_view_counts_vs_oracle(dev, t):
                                      sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
                                      order_by_distance=True)
     assert imgs.shape == (t, 3, 256, 256)
-    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
-    assert (masks.cpu() - om).abs().max().item() < 5e-4
+    assert_forward_close(imgs, oi, masks, om, "FORGE t = %d input views" % t)
 
 
 def test_forge_non_default_render_config_vs_oracle(dev):
@@ -298,8 +307,7 @@ def test_forge_non_default_render_config_vs_oracle(dev):
                                      sample["cam_extrinsics_cv2_canonicalized"], sample["K_cv2"], w, cfg,
                                      order_by_distance=True)
     assert imgs.shape == (4, 3, 256, 256)
-    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
-    assert (masks.cpu() - om).abs().max().item() < 5e-4
+    assert_forward_close(imgs, oi, masks, om, "FORGE non-default render config")
 
 
 def test_fuse_groups_shared_inputs_equals_separate_fusions(dev):
@@ -433,6 +441,36 @@ def test_training_gradients_vs_reference_golden(dev, golden):
         if ref.numel() > 1 and ref.abs().max().item() > 1e-3 * gscale:
             cos = torch.nn.functional.cosine_similarity(named[k].grad.cpu().double().flatten(), ref.double().flatten(), dim=0).item()
             assert cos > 0.99995, (k, cos)
+
+
+@pytest.mark.parametrize("path,factor", [("winograd", 4.0), ("direct", 1.5)])
+def test_training_gradients_vs_float64_reference(dev, golden, path, factor):
+    """the GT-pose training step against the REFERENCE's float64 evaluation of the same graph (train_pose3d.npz grad64__*,
+    oracle/make_golden.py::train_goldens), per golden key, relative to how far the reference's own fp32 run sits from that float64 result
+    (0.8-4e-3 of max on the trunk, 1e-4 .. 1e-3 elsewhere):
+        direct    (convops.winograd(False): implicit-GEMM launches only)   err(HIP, f64) <= 1.5 x err(ref fp32, f64) + 3e-4   measured <= 1.37x
+                  on the trunk, <= 1.7x elsewhere where the floor does not carry it
+        winograd  (the default path: F(2x2,3x3) point GEMMs in the fusion, conv1 and layer3/4 forward, data and weight gradients)   <= 4 x ... + 3e-4
+                  measured 1.5-3.2x: the transforms' rounding amplification, the price of 2.25x fewer multiplies (profiles/r05_train_grad_margins.txt)
+    The reference's own GPU runs are cuDNN TF32 (kubric_train_pose_3D.py:119-124, torch 1.10 defaults): 10-bit mantissas, two orders noisier."""
+    from forge_amd import convops as co
+    from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    from test_gpu_configs import check_gradients_vs_float64_golden
+    gold = golden("train_pose3d")
+    cfg = syn.kubric_config()
+    with co.winograd(path == "winograd"):
+        model = FORGE_poseEstimator3D(cfg)
+        model.load_state_dict(syn.seeded_state_dict(model.state_dict(), int(gold["weight_seed"])))
+        model = model.to(dev).train()
+        sample = syn.make_sample(1, 5, 256, 1.5, seed=int(gold["sample_seed"]))
+        tgt_i = sample["images"][0].repeat(2, 1, 1, 1).to(dev)
+        tgt_m = sample["fg_probabilities"][0].repeat(2, 1, 1, 1).to(dev)
+        imgs, masks = model(sample, syn.SyntheticDataset(1.5), dev)
+        loss = 5.0 * torch.nn.functional.mse_loss(imgs, tgt_i) + torch.nn.functional.mse_loss(masks, tgt_m)
+        loss.backward()
+        torch.cuda.synchronize()
+    assert abs(loss.item() - float(gold["loss64"])) < 2e-6 * abs(float(gold["loss64"])), (loss.item(), float(gold["loss64"]))
+    assert check_gradients_vs_float64_golden(gold, dict(model.named_parameters()), factor=factor) >= 16
 
 
 def test_training_step_runs(dev):
@@ -1172,8 +1210,7 @@ def test_forge_two_scenes_10_views_vs_oracle(dev):
                                      order_by_distance=True, render_extrinsics=sample["cam_extrinsics_cv2_canonicalized"],
                                      render_K=sample["K_cv2"])
     assert imgs.shape == (20, 3, 256, 256) and masks.shape == (20, 1, 256, 256)
-    assert (imgs.cpu() - oi).abs().max().item() < 2e-3 and fo.psnr(imgs.cpu(), oi) > 60.0
-    assert (masks.cpu() - om).abs().max().item() < 5e-4
+    assert_forward_close(imgs, oi, masks, om, "FORGE 2 scenes x 10 views")
 
 
 def test_forge_joint_mode_forward_backward(dev):

@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/forge_oracle.py) against the golden vectors produced by the reference's
 own module code (oracle/make_golden.py) and against the known answers embedded in the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -187,6 +189,37 @@ def test_render_analytic_kats():
         kat_render.check(case, raw[0])
 
 
+def test_pytorch3d_shim_reproduces_analytic_kats_on_non_square_targets():
+    """the PyTorch3D restatement the golden import runs on (oracle/shims/pytorch3d: cameras_from_opencv_projection ->
+    NDCGridRaysampler -> VolumeSampler -> EmissionAbsorptionRaymarcher, wired exactly as models/volume_render.py:18-24,53-63 wires them) against
+    the analytic float64 known answers of tests/kat_render.py - every case, of which the wide ones (Hr < Wr: range_x = W / H) and the tall ones
+    (Hr > Wr: range_y = H / W) take the two non-square branches of the raysampler (oracle/shims/pytorch3d/renderer/__init__.py:15-18) that no
+    golden fixture touches (all goldens render square targets). The shim shares no code with the oracle's closed form or the C restatement."""
+    import sys
+    import kat_render
+    shims = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims")
+    sys.path.insert(0, shims)
+    try:
+        from pytorch3d.renderer import EmissionAbsorptionRaymarcher, NDCGridRaysampler, VolumeRenderer
+        from pytorch3d.structures import Volumes
+        from pytorch3d.utils.camera_conversions import cameras_from_opencv_projection
+    finally:
+        sys.path.remove(shims)
+    seen = set()
+    for case in kat_render.cases():
+        D, H, W = case["dims"]
+        feat, dens, R, Tt, K = _kat_inputs(case)
+        Hr, Wr = case["Hr"], case["Wr"]
+        cams = cameras_from_opencv_projection(R=R, tvec=Tt, camera_matrix=K, image_size=torch.tensor([[Hr, Wr]]))
+        renderer = VolumeRenderer(raysampler=NDCGridRaysampler(image_width=Wr, image_height=Hr, n_pts_per_ray=case["S"], min_depth=case["zmin"],
+                                                               max_depth=case["zmax"]), raymarcher=EmissionAbsorptionRaymarcher())
+        with torch.no_grad():
+            got = renderer(cameras=cams, volumes=Volumes(densities=dens, features=feat, voxel_size=case["vol"] / D), render_depth=True)[0][0]
+        kat_render.check(case, got.numpy())
+        seen.add("wide" if Wr > Hr else "tall" if Hr > Wr else "square")
+    assert {"wide", "tall"} <= seen, seen
+
+
 def test_pose_estimators_reproduce_reference_predictions(golden):
     """forge_amd/pose_estimator_{2d,3d}.py + pose_head + geo_utils (stock torch, CPU here) on the oracle's encoder features reproduce
     the pose vectors / confidences the REFERENCE's FORGE (use_gt_pose=False) and FORGE_poseEstimator3D(use_gt_pose=False) predicted on
@@ -225,3 +258,27 @@ def test_pose_estimators_reproduce_reference_predictions(golden):
             assert (gt - T(g["joint__pose_gt"])).abs().max().item() < 1e-5
         else:
             assert (oproj - ref_o[:5]).abs().max().item() < 2e-3 and (oproj - ref_o[5:]).abs().max().item() < 2e-3, tag
+
+
+def test_joint_training_fixture_is_consistent_with_the_forward_fixture(golden):
+    """tests/golden/train_joint.npz (the reference's compute_all_loss_nvs + backward, oracle/make_golden.py::train_joint_goldens) against
+    tests/golden/forward_joint.npz (the reference's eval forward on the same seeds): total = sum of the seven terms; the pose / translation
+    terms are the MSEs of the stored predicted and GT pose vectors (scripts/kubric_compute_loss.py:150-156); every stored gradient is finite,
+    non-zero and its sample / norm / max triple is coherent."""
+    import numpy as np
+    g, f = golden("train_joint"), golden("forward_joint")
+    assert int(g["sample_seed"]) == int(f["sample_seed"]) and int(g["weight_seed"]) == int(f["weight_seed"])
+    terms = {k[len("term__"):]: float(g[k]) for k in g.files if k.startswith("term__")}
+    assert sorted(terms) == ["pose", "recon_img", "recon_img_nvs", "recon_mask", "recon_mask_nvs", "regu_origin", "trans"]
+    assert abs(sum(terms.values()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    pred, gt = f["joint__pose_pred"], f["joint__pose_gt"]
+    assert abs(float(np.mean((pred[:, :4] - gt[:, :4]) ** 2)) - terms["pose"]) < 1e-5
+    assert abs(float(np.mean((pred[:, 4:] - gt[:, 4:]) ** 2)) - terms["trans"]) < 1e-5
+    oproj = f["joint__origin_proj"]
+    assert abs(float(g["regu_origin_proj"]) * float(np.mean((oproj - 0.5) ** 2)) - terms["regu_origin"]) < 1e-5
+    keys = [k[len("gnorm__"):] for k in g.files if k.startswith("gnorm__")]
+    assert len(keys) == 29 and any(k.startswith("encoder_traj_2d.") for k in keys) and any(k.startswith("pose_head.") for k in keys)
+    for k in keys:
+        arr = g["grad__" + k] if "grad__" + k in g.files else g["gsub__" + k]
+        assert np.isfinite(arr).all() and np.abs(arr).max() > 0, k
+        assert np.abs(arr).max() <= float(g["gmax__" + k]) * (1 + 1e-6) and np.linalg.norm(arr.astype(np.float64)) <= float(g["gnorm__" + k]) * (1 + 1e-6), k

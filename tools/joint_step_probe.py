@@ -1,33 +1,42 @@
 #!/usr/bin/env python
-"""Time one joint-mode training step (BASELINE configs[4] code path: FORGE with predicted poses - 2-D + 3-D pose estimators and the
-pose head in stock torch, reconstruction on the HIP kernels - fwd + bwd + Adam) and list the slowest kernels of the last step."""
+"""Time the joint 2D3D fine-tune iteration (BASELINE configs[4]; kubric_train_joint.py:111-141) exactly as bench.py's extra_configs
+`joint_step` / `joint_step_grid64` run it (bench.joint_configs), for rocprofv3 passes:
+
+    JOINT_GRID=32|64  JOINT_STEPS=n   python tools/joint_step_probe.py
+
+FORGE with predicted poses (2-D + 3-D pose estimators and the pose head on stock torch kernels; everything else on libforge_hip.so),
+compute_all_loss_nvs, backward, clip 10, Adam over the reference's parameter list."""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
-import torch.nn.functional as F  # noqa: E402
 
-from forge_amd import synthetic as syn  # noqa: E402
+from forge_amd import synthetic as syn, train  # noqa: E402
 from forge_amd.model import FORGE  # noqa: E402
 
-b = int(os.environ.get("JOINT_SCENES", "1"))
+grid = int(os.environ.get("JOINT_GRID", "32"))
 steps = int(os.environ.get("JOINT_STEPS", "4"))
 dev = torch.device("cuda:0")
 cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+cfg.loss.regu_origin_proj = 1.0
 model = FORGE(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).train()
-opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
-sample = {k: v.to(dev) for k, v in syn.make_sample(b, 10, 256, 1.5, seed=12).items()}
+params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render) for p in m.parameters()]
+opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
 ds = syn.SyntheticDataset(1.5)
+call = model
+if grid == 64:
+    gen = torch.Generator(device=dev).manual_seed(79)
+    f64 = torch.randn(1, 5, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+    call = lambda s, d, dv: model(s, d, dv, features_recon=f64)      # noqa: E731
 
 
 def step():
-    imgs, masks, origin_proj, pose = model(sample, ds, dev)
-    loss = F.mse_loss(imgs, sample["images"].reshape(-1, 3, 256, 256)) + F.mse_loss(masks, sample["fg_probabilities"].reshape(-1, 1, 256, 256)) \
-        + F.mse_loss(pose["pred"], pose["gt"]) + 0.1 * F.mse_loss(origin_proj, torch.full_like(origin_proj, 0.5))
+    loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call, {}, dev)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
@@ -43,5 +52,5 @@ for _ in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("joint train step b=%d: %.1f ms/step (fwd+bwd+Adam, 10 rendered views/scene), loss %.5f, peak mem %.1f GB"
-      % (b, dt * 1e3, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30))
+print("joint step grid %d: %.1f ms/step (fwd+bwd+clip+Adam, 10 rendered views), loss %.5f, peak mem %.1f GB, steps timed %d (+2 warm-up)"
+      % (grid, dt * 1e3, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30, steps))

@@ -687,17 +687,21 @@ class _ConvTapsRows(torch.autograd.Function):
                 conv_igemm(dy, Cout, Cout, None, 0, 0, wd, None, None, None, 1.0, None, None, None, dx, None, (n, D, H, W), (D, H, W), Cin, Cin,
                            [(-a, -b, -c) for a, b, c in taps], epilogue=EPI_BIAS)
             else:
-                assert istride == 2 and D == 1 and Di == 1 and Hi == 2 * H and Wi == 2 * W and all(t[0] == 0 for t in taps)
-                dx = torch.zeros(n, 1, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
-                for ph_y in (0, 1):
-                    for ph_x in (0, 1):
-                        sel = [i for i, (_, ty, tx) in enumerate(taps) if (ty - ph_y) % 2 == 0 and (tx - ph_x) % 2 == 0]
-                        if not sel:
-                            continue                                                 # no tap reaches this pixel parity: gradient stays 0
-                        ptaps = [(0, (ph_y - taps[i][1]) // 2, (ph_x - taps[i][2]) // 2) for i in sel]
-                        conv_igemm(dy, Cout, Cout, None, 0, 0, torch.stack([wd[i] for i in sel]), None, None, None, 1.0, None, None, None, dx, None,
-                                   (n, 1, H, W), (1, H, W), Cin, Cin, ptaps, out_grid=(1, Hi, Wi), ostride=2, phase=(0, ph_y, ph_x),
-                                   epilogue=EPI_BIAS)
+                # stride 2: a transposed convolution - one phase GEMM per input-voxel parity over the taps of that parity (2-D: D = Di = 1, four
+                # phases; 3-D: eight). Parities no tap reaches keep a zero gradient.
+                flat = D == 1 and Di == 1 and all(t[0] == 0 for t in taps)
+                assert istride == 2 and Hi == 2 * H and Wi == 2 * W and (flat or Di == 2 * D), (istride, (D, H, W), (Di, Hi, Wi))
+                dx = torch.zeros(n, Di, Hi, Wi, Cin, dtype=torch.float32, device=dy.device)
+                for ph_z in ((0,) if flat else (0, 1)):
+                    for ph_y in (0, 1):
+                        for ph_x in (0, 1):
+                            sel = [i for i, (tz, ty, tx) in enumerate(taps) if (flat or (tz - ph_z) % 2 == 0) and (ty - ph_y) % 2 == 0 and (tx - ph_x) % 2 == 0]
+                            if not sel:
+                                continue
+                            ptaps = [(0 if flat else (ph_z - taps[i][0]) // 2, (ph_y - taps[i][1]) // 2, (ph_x - taps[i][2]) // 2) for i in sel]
+                            conv_igemm(dy, Cout, Cout, None, 0, 0, torch.stack([wd[i] for i in sel]), None, None, None, 1.0, None, None, None, dx, None,
+                                       (n, D, H, W), (D, H, W), Cin, Cin, ptaps, out_grid=(Di, Hi, Wi), ostride=2, phase=(ph_z, ph_y, ph_x),
+                                       epilogue=EPI_BIAS)
             dx1 = dx[..., :C1] if ctx.needs_input_grad[0] else None
             dx2 = dx[..., C1:] if (x2 is not None and ctx.needs_input_grad[1]) else None
         if ctx.needs_input_grad[2]:
@@ -794,6 +798,21 @@ def conv2d_rows(x, weight, bias, stride=1, want_stats=False):
     if want_stats:
         return y[0].reshape(N, Ho, Wo, co_), y[1]
     return y.reshape(N, Ho, Wo, co_)
+
+
+def conv3d_rows(x, weight, bias, stride=1, want_stats=False):
+    """Conv3d(k = 3, padding = 1, stride 1 or 2) on channels-last rows [n,D,H,W,C] with autograd (the 3-D pose estimator's convolutions,
+    models/pose_estimator_3d.py:24-60); Cin and Cout multiples of 32, even input extents for stride 2. Stride 1 is conv3x3x3_rows (Winograd
+    where it applies); stride 2 gathers rows 2 o + t through the same GEMM, its data gradient runs as eight parity-phase GEMMs."""
+    co_, ci_ = weight.shape[:2]
+    n, D, H, W, C = x.shape
+    if tuple(weight.shape[2:]) != (3, 3, 3) or C != ci_ or stride not in (1, 2):
+        raise ValueError("conv3d_rows: weight %s / input channels %d / stride %d" % (tuple(weight.shape), C, stride))
+    if stride == 1:
+        return conv_taps_rows(x, None, _pack3d(weight), bias, TAPS_3x3x3, want_stats=want_stats)
+    if D % 2 or H % 2 or W % 2:
+        raise ValueError("conv3d_rows: stride 2 needs even input extents, got %s" % ((D, H, W),))
+    return conv_taps_rows(x, None, _pack3d(weight), bias, TAPS_3x3x3, 2, (D // 2, H // 2, W // 2), want_stats)
 
 
 class _ConvDirectRows(torch.autograd.Function):

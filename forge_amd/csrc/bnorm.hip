@@ -57,7 +57,7 @@ __device__ __forceinline__ void bn_block_sum(double (&a)[8], int c, int rg, int 
     for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = a[k];
     __syncthreads();
     if (c >= 0 && rg == 0) {
-        const int CQ = BN_THREADS / RG;
+        const int C4 = C >> 2, CQ = C4 < BN_THREADS ? C4 : BN_THREADS;     // as bn_coords (BN_THREADS / RG only when C / 4 divides 256)
         for (int g = 1; g < RG; ++g)
 #pragma unroll
             for (int k = 0; k < 8; ++k) a[k] += red[threadIdx.x + g * CQ][k];

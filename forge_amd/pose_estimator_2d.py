@@ -191,6 +191,19 @@ class PoseEstimator2D(nn.Module):
         # float64 parameter, as in the reference (numpy float64 embedding wrapped in nn.Parameter, :50-51)
         self.pos_emb = nn.Parameter(0.05 * torch.from_numpy(sincos_pos_embed_2d(256, 16))[None])
 
+    def _conv_rows(self, rows):
+        """`self.conv` (four Conv2d(k = 3, stride 2) + BatchNorm2d + LeakyReLU, models/pose_estimator_2d.py:36-48) on NHWC rows [n,h,w,256] - what the
+        attention blocks produce anyway - through libforge_hip.so (convops.conv2d_rows, bn_act_rows): MIOpen ran these on its naive fp32 kernels."""
+        from . import convops as co
+        from .fusion import bn_act_rows
+        mods = list(self.conv)
+        for i in range(0, len(mods), 3):
+            conv, bn, act = mods[i:i + 3]
+            if rows.shape[1] % 2 or rows.shape[2] % 2:
+                raise RuntimeError("forge_amd: PoseEstimator2D.conv needs even feature-map extents at every stride-2 convolution, got %s" % (tuple(rows.shape[1:3]),))
+            rows = bn_act_rows(bn, co.conv2d_rows(rows.contiguous(), conv.weight, conv.bias, stride=conv.stride[0]), act.negative_slope)
+        return rows
+
     def forward(self, x, return_features=False):
         """x [B,T,3,H,W] -> pose features [B(T-1),1024] or 7-D pose"""
         B, T, C, H, W = x.shape
@@ -202,6 +215,9 @@ class PoseEstimator2D(nn.Module):
         feat = (feat[:, 1:] + pos.unsqueeze(1)).to(feat.dtype).reshape(B, (T - 1) * h2 * w2, 256)
         for cross, selfa in zip(self.cross_attn_blks, self.self_attn_blks):
             feat = selfa(cross(x_q=feat, x_k=feat_canonical, x_v=feat_canonical, residual=feat))
-        feat = feat.reshape(B * (T - 1), h2, w2, 256).permute(0, 3, 1, 2)
-        feat = self.conv(feat).squeeze()
+        if feat.is_cuda and feat.dtype == torch.float32 and not getattr(self, "force_stock_torch", False):
+            feat = self._conv_rows(feat.reshape(B * (T - 1), h2, w2, 256)).reshape(B * (T - 1), -1).squeeze()
+        else:
+            feat = feat.reshape(B * (T - 1), h2, w2, 256).permute(0, 3, 1, 2)
+            feat = self.conv(feat).squeeze()
         return feat if return_features else self.out(feat)

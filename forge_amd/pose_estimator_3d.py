@@ -1,9 +1,11 @@
-"""3-D pose estimator (cross-attention over feature volumes) — NOT on the accelerated hot path
-("pose heads stay stock PyTorch-ROCm"). It exists so that
-`FORGE_poseEstimator3D` / `FORGE` keep the reference's attribute surface (`encoder_traj`,
-`.toSE3`, `.pose_dim`, `return_features=`) and state_dict keys (`encoder_traj.*`, 26.65 M
-parameters). Architecture re-expressed from models/pose_estimator_3d.py:9-144 and the
-Block/Attention/Mlp/positional-embedding helpers of models/model_utils.py:59-256."""
+"""3-D pose estimator (cross-attention over feature volumes): the reference's attribute surface (`encoder_traj`, `.toSE3`, `.pose_dim`,
+`return_features=`) and state_dict keys (`encoder_traj.*`, 26.65 M parameters); architecture re-expressed from
+models/pose_estimator_3d.py:9-144 and the Block/Attention/Mlp/positional-embedding helpers of models/model_utils.py:59-256.
+
+On the MI355X its eight 3x3x3 convolutions (stride 1 and 2) + BatchNorm + LeakyReLU run on libforge_hip.so (convops.conv3d_rows, bn_act_rows on
+channels-last rows; round 5): in the joint fine-tune step (BASELINE configs[4]) MIOpen served them with its `naive_conv_*` fp32 kernels - 164 ms
+of a 256 ms step (profiles/r05_joint_grid32_kernel_share_before.txt). The attention block (1x1 projections, 4096-token softmax, MLP) stays
+stock torch (rocBLAS GEMMs). CPU tensors run the same modules on torch's own kernels (the architecture pin of tests/test_oracle_golden.py)."""
 import math
 
 import torch
@@ -146,17 +148,63 @@ class PoseEstimator3D(nn.Module):
         self.out = nn.Sequential(nn.Linear(1024, 256), nn.BatchNorm1d(256), nn.LeakyReLU(),
                                  nn.Linear(256, self.pose_dim + 1))
 
+    @staticmethod
+    def _block_rows(seq, rows):
+        """An nn.Sequential of Conv3d(k = 3, padding = 1, stride 1 | 2) / BatchNorm3d / LeakyReLU on channels-last rows [n,D,H,W,C]: convolutions
+        forward, data and weight gradient on the MFMA implicit-GEMM / wgrad kernels, BatchNorm + the activation behind it as one HIP pass."""
+        from . import convops as co
+        from .fusion import bn_act_rows
+        mods, i = list(seq), 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv3d):
+                if m.kernel_size != (3, 3, 3) or m.padding != (1, 1, 1) or m.stride[0] not in (1, 2) or len(set(m.stride)) != 1:
+                    raise RuntimeError("forge_amd: PoseEstimator3D expects Conv3d(k=3, padding=1, stride 1|2), got %r" % (m,))
+                rows = co.conv3d_rows(rows, m.weight, m.bias, stride=m.stride[0])
+            elif isinstance(m, nn.modules.batchnorm._BatchNorm):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, nn.LeakyReLU):
+                    rows, i = bn_act_rows(m, rows, nxt.negative_slope), i + 1
+                else:
+                    rows = bn_act_rows(m, rows)
+            elif isinstance(m, nn.LeakyReLU):
+                rows = torch.nn.functional.leaky_relu(rows, m.negative_slope)
+            else:
+                raise TypeError("unexpected layer in PoseEstimator3D block: %r" % (m,))
+            i += 1
+        return rows
+
+    def _forward_features_hip(self, features):
+        """features [b,t,128,D,H,W] (any strides) on the MI355X -> [b(t-1),1024] through the HIP convolution kernels."""
+        b, t, C1, D1, H1, W1 = features.shape
+        rows = features.reshape(b * t, C1, D1, H1, W1).permute(0, 2, 3, 4, 1)
+        rows = rows if rows.is_contiguous() else rows.contiguous()
+        x = self._block_rows(self.conv3d_1, rows)                                   # [bt,D,H,W,64]
+        _, D, H, W, C = x.shape
+        x = x.reshape(b, t, D * H * W, C).permute(0, 1, 3, 2)                       # [b,t,C,N] view of the rows
+        ref = x[:, 0:1].expand(b, t - 1, C, D * H * W).reshape(b * (t - 1), C, -1)
+        cur = x[:, 1:].reshape(b * (t - 1), C, -1)
+        x = self.pose_transformer(q=ref, k=cur)                                     # [b(t-1),64,N]
+        rows = x.reshape(b * (t - 1), self.coord_dim, D, H, W).permute(0, 2, 3, 4, 1).contiguous()
+        rows = self._block_rows(self.pose_head_1, self._block_rows(self.conv3d_3, self._block_rows(self.conv3d_2, rows)))
+        if rows.shape[1:4] != (1, 1, 1):                                            # the reference squeezes [n,1024,1,1,1]; other grids have no meaning here
+            raise RuntimeError("forge_amd: PoseEstimator3D needs 32^3 feature volumes (pose_head_1 ends at %s)" % (tuple(rows.shape[1:4]),))
+        return rows.reshape(b * (t - 1), -1).squeeze()
+
     def forward(self, features, return_features=False):
         """features [b,t,128,D,H,W] -> (pose [b(t-1),pose_dim], conf [b(t-1),1]) or the 1024-d features"""
         b, t, C1, D1, H1, W1 = features.shape
-        x = self.conv3d_1(features.reshape(b * t, C1, D1, H1, W1))
-        _, C, D, H, W = x.shape
-        x = x.reshape(b, t, C, D * H * W)
-        ref = x[:, 0:1].repeat(1, t - 1, 1, 1).reshape(b * (t - 1), C, -1)
-        cur = x[:, 1:].reshape(b * (t - 1), C, -1)
-        x = self.pose_transformer(q=ref, k=cur).reshape(b * (t - 1), self.coord_dim, D, H, W)
-        x = self.conv3d_3(self.conv3d_2(x))
-        x = self.pose_head_2(self.pose_head_1(x).squeeze())
+        if features.is_cuda and features.dtype == torch.float32 and not getattr(self, "force_stock_torch", False):
+            x = self.pose_head_2(self._forward_features_hip(features))
+        else:
+            x = self.conv3d_1(features.reshape(b * t, C1, D1, H1, W1))
+            _, C, D, H, W = x.shape
+            x = x.reshape(b, t, C, D * H * W)
+            ref = x[:, 0:1].repeat(1, t - 1, 1, 1).reshape(b * (t - 1), C, -1)
+            cur = x[:, 1:].reshape(b * (t - 1), C, -1)
+            x = self.pose_transformer(q=ref, k=cur).reshape(b * (t - 1), self.coord_dim, D, H, W)
+            x = self.conv3d_3(self.conv3d_2(x))
+            x = self.pose_head_2(self.pose_head_1(x).squeeze())
         if return_features:
             return x
         x = self.out(x)

@@ -8,7 +8,8 @@ import torch.nn as nn
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("shape,slope", [((2, 4, 6, 8, 128), 0.01), ((3, 16, 20, 8), 0.0), ((1, 3, 5, 7, 2048), 1.0), ((5, 9, 11, 24), 0.01)])
+@pytest.mark.parametrize("shape,slope", [((2, 4, 6, 8, 128), 0.01), ((3, 16, 20, 8), 0.0), ((1, 3, 5, 7, 2048), 1.0), ((5, 9, 11, 24), 0.01),
+                                         ((2, 6, 7, 9, 96), 0.01), ((3, 10, 12, 160), 0.0)])      # C / 4 does not divide 256 (round 5: the block reduction assumed it did)
 def test_bn_train_forward_backward_and_running_stats(shape, slope):
     from forge_amd.fusion import bn_act_rows
     dev = torch.device("cuda:0")
@@ -57,7 +58,7 @@ def test_bn_eval_keeps_the_torch_module_and_single_process_syncbn_runs_hip():
     assert torch.equal(sync.running_var, plain.running_var)
 
 
-@pytest.mark.parametrize("M,C,ld", [(32768, 128, 128), (5120, 2048, 2048), (1000, 32, 64), (7, 8, 8), (262144, 16, 16), (2621440, 3, 3), (100001, 1, 1),
+@pytest.mark.parametrize("M,C,ld", [(32768, 128, 128), (5120, 2048, 2048), (1000, 32, 64), (144, 96, 96), (3001, 160, 192), (7, 8, 8), (262144, 16, 16), (2621440, 3, 3), (100001, 1, 1),
                                     (999, 7, 7), (5, 3, 3), (40000, 3, 5)])      # C % 4 != 0: the flat walk (conv_rgb's 3-channel bias gradient, the density head's 1)
 def test_colsum_kernel_vs_float64(M, C, ld):
     """forge_colsum (the bias gradients of the training path; float64 partial sums, fixed order) against a float64 torch sum: 2e-7 of the

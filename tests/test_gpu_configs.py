@@ -215,6 +215,61 @@ def test_joint_training_step_vs_reference_golden(dev, golden):
         assert named[k].grad is None or float(named[k].grad.abs().max()) == 0.0, k
 
 
+def test_pose_estimators_hip_convolutions_vs_float64_and_stock_torch(dev):
+    """Round 5: on the MI355X the 3-D pose estimator's eight 3x3x3 convolutions (+ BatchNorm + LeakyReLU) and the 2-D pose estimator's four stride-2
+    convolutions run on libforge_hip.so instead of MIOpen's naive fp32 kernels (164 + 21 ms of the 256 ms joint step). Both modules, train mode
+    (BatchNorm batch statistics) and eval mode, forward features + gradients of the input and of a parameter from every block, against the SAME
+    module evaluated in float64 on the CPU - and, as the yardstick, the stock-torch path on the GPU against the same float64 result
+    (`force_stock_torch`): the HIP path has to stay within 3x the stock path's distance (+ 2e-5 of max)."""
+    import copy
+    from forge_amd.pose_estimator_2d import PoseEstimator2D
+    from forge_amd.pose_estimator_3d import PoseEstimator3D
+    torch.manual_seed(3)
+    rel = lambda got, want: (got.detach().double().cpu() - want.detach()).abs().max().item() / max(want.detach().abs().max().item(), 1e-30)
+
+    def run(mod, x, keys):
+        x = x.clone().requires_grad_(True)
+        out = mod(x, return_features=True)
+        out.square().sum().backward()
+        named = dict(mod.named_parameters())
+        res = [out.detach(), x.grad] + [named[k].grad for k in keys]
+        for p in mod.parameters():
+            p.grad = None
+        return res
+
+    cases = [
+        (PoseEstimator3D(syn.kubric_config()), (torch.randn(1, 3, 128, 32, 32, 32) * 0.5),
+         ["conv3d_1.0.weight", "conv3d_1.3.bias", "conv3d_2.3.weight", "conv3d_3.1.weight", "conv3d_3.3.weight", "pose_head_1.0.weight", "pose_head_1.3.weight",
+          "pose_transformer.self_transformer.mlp.fc1.weight"]),
+        (PoseEstimator2D(), torch.rand(1, 3, 3, 256, 256), ["conv.0.weight", "conv.1.weight", "conv.3.weight", "conv.6.bias", "conv.9.weight",
+                                                            "self_attn_blks.2.mlp.mlp.1.weight", "backbone.layer4.0.0.conv2.weight"]),
+    ]
+    for mod, x, keys in cases:
+        sd = syn.seeded_state_dict({"m." + k: v for k, v in mod.state_dict().items()}, 11)
+        mod.load_state_dict({k[2:]: v for k, v in sd.items()})
+        for train in (True, False):
+            mod.train(train)
+            for m in mod.modules():                                        # Dropout off: three evaluations must be comparable
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+            ref_mod = copy.deepcopy(mod).double()
+            for m in ref_mod.modules():
+                for k, v in list(vars(m).items()):
+                    if torch.is_tensor(v) and v.is_floating_point():
+                        setattr(m, k, v.double())
+            ref = run(ref_mod, x.double(), keys)
+            g = copy.deepcopy(mod).to(dev)
+            hip = run(g, x.to(dev), keys)
+            g2 = copy.deepcopy(mod).to(dev)
+            g2.force_stock_torch = True
+            stock = run(g2, x.to(dev), keys)
+            for name, a, b_, r in zip(["features", "d input"] + keys, hip, stock, ref):
+                eh, es = rel(a, r), rel(b_, r)
+                if os.environ.get("FORGE_TEST_REPORT"):
+                    print("  %-16s %-5s %-52s hip/f64 %.2e  stock/f64 %.2e" % (type(mod).__name__, "train" if train else "eval", name, eh, es))
+                assert eh <= 3.0 * es + 2e-5, (type(mod).__name__, train, name, eh, es)
+
+
 # ------------------------------------------------------------------------------------------------------------- configs[2]
 def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
     """BASELINE configs[2]: full HIP path, batch = 8 scenes, 64^3 render grid, 1 GPU. Scenes 2 and 5 of the batch against the CPU

@@ -1138,6 +1138,34 @@ def test_conv2d_rows_strided_autograd_vs_torch(dev):
         assert (wd.grad.cpu() - wa.grad).abs().max().item() < 1e-4 * wa.grad.abs().max().item(), tag
 
 
+def test_conv3d_rows_strided_autograd_vs_torch_float64(dev):
+    """convops.conv3d_rows (the 3-D pose estimator's convolutions, models/pose_estimator_3d.py:24-60): Conv3d(k = 3, padding = 1) with stride 1 and
+    stride 2, bias, on channels-last rows - forward, data gradient (stride 2: eight parity-phase GEMMs of the transposed convolution), weight
+    gradient (strided gather) and bias gradient against torch's float64 CPU convolution; shapes from the estimator's tail (8^3 -> 4^3 -> 2^3 -> 1^3)
+    and a ragged one."""
+    from forge_amd import convops as co
+    g = torch.Generator().manual_seed(29)
+    for stride, Cin, Cout, dims, n in ((2, 64, 96, (8, 12, 6), 2), (2, 128, 64, (2, 2, 2), 3), (1, 64, 32, (5, 4, 6), 2), (2, 32, 64, (4, 4, 4), 1)):
+        x = torch.randn(n, Cin, *dims, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g, dtype=torch.float64) / (27 * Cin) ** 0.5
+        b = torch.randn(Cout, generator=g, dtype=torch.float64)
+        xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ref = torch.nn.functional.conv3d(xa, wa, ba, stride=stride, padding=1)
+        gy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+        ref.backward(gy)
+        xd = x.float().permute(0, 2, 3, 4, 1).contiguous().to(dev).requires_grad_(True)
+        wd, bd = w.float().to(dev).requires_grad_(True), b.float().to(dev).requires_grad_(True)
+        out = co.conv3d_rows(xd, wd, bd, stride=stride)
+        out.backward(gy.float().permute(0, 2, 3, 4, 1).contiguous().to(dev))
+        tag = "s%d %s" % (stride, dims)
+        rel = lambda got, want: (got.double().cpu() - want).abs().max().item() / want.abs().max().item()
+        assert out.shape[1:4] == ref.shape[2:], tag
+        assert rel(out.detach().permute(0, 4, 1, 2, 3), ref.detach()) < 2e-5, tag
+        assert rel(xd.grad.permute(0, 4, 1, 2, 3), xa.grad) < 5e-5, tag
+        assert rel(wd.grad, wa.grad) < 5e-5, tag
+        assert rel(bd.grad, ba.grad) < 2e-5, tag
+
+
 def test_conv2d_rows_winograd_2d_training_path_vs_float64(dev):
     """The bottleneck conv2 of ResNet layer3 / layer4 in TRAINING (3x3, stride 1, 256 / 512 channels at 32 x 32): forward, data gradient and
     weight gradient take the 2-D Winograd launches (one depth tap, convops.wino_applies) - against torch's float64 convolution, and against

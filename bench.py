@@ -875,8 +875,8 @@ def joint_stock_share():
 
 def joint_configs(dev, steps=5):
     """BASELINE configs[4] on one GPU: the joint 2D3D fine-tune iteration of kubric_train_joint.py:111-141 - FORGE with
-    PREDICTED poses (2-D + 3-D pose estimators and the pose head on stock torch kernels; encoder / rotate / fusion / heads / ray-march /
-    conv_rgb on the HIP kernels), 5 input + 5 novel views, compute_all_loss_nvs (scripts/kubric_compute_loss.py:121-172), backward through the
+    PREDICTED poses (attention blocks of the 2-D / 3-D pose estimators and the pose head on stock torch kernels; encoder / rotate / fusion / heads / ray-march /
+    conv_rgb and, since round 5, every convolution + BatchNorm of the two pose estimators on the HIP kernels), 5 input + 5 novel views, compute_all_loss_nvs (scripts/kubric_compute_loss.py:121-172), backward through the
     pose chain (rotate's d pose, the ray-marcher's d(R, T)), clip 10, Adam over the parameter list of kubric_train_joint.py:111-116.
       joint_step          reference-native grids (32^3 features, 64^3 render volume)
       joint_step_grid64   the configuration's 128^3-voxel scenes: synthetic [1,5,128,64^3] feature volumes enter the reconstruction
@@ -917,7 +917,7 @@ def joint_configs(dev, steps=5):
         return step
 
     def pose_nets_only():
-        """the stock-torch part alone: both pose estimators + pose head forward and backward on the step's own (detached) inputs"""
+        """both pose estimators + pose head alone: forward and backward on the step's own (detached) inputs"""
         with torch.no_grad():
             clips = sample["images"][:, :T_IN]
             feats = model.encoder_3d.get_feat3D(clips.reshape(T_IN, 3, 256, 256)).reshape(1, T_IN, 128, 32, 32, 32)
@@ -930,6 +930,9 @@ def joint_configs(dev, steps=5):
                 p.grad = None
             feats.grad = None
         return run
+
+    def stock(on):
+        model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = bool(on)
 
     share = joint_stock_share()
     for name, feats, workload in (
@@ -949,10 +952,47 @@ def joint_configs(dev, steps=5):
             ms_pose = _timed(pose_nets_only(), steps, warm=1)
             e = {"name": name, "workload": workload, "steps": steps, "ms_per_step": ms, "views_per_s": 10 / ms * 1e3,
                  "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches,
-                                  note="executed_gflop = libforge matrix-core launches only; the stock-torch pose networks' FLOPs are in stock_torch.gflop"),
-                 "stock_torch": {"what": "2-D + 3-D pose estimators and pose head (MIOpen / rocBLAS / ATen kernels): forward + backward timed alone on the step's inputs",
-                                 "pose_nets_fwd_bwd_ms": ms_pose, "share_of_step": ms_pose / ms, "gflop": fc.get_total_flops() / 1e9,
-                                 "rocprofv3": (share or {}).get(name)}}
+                                  note="executed_gflop = libforge matrix-core launches (the pose estimators' convolutions included since round 5); the attention "
+                                       "blocks' rocBLAS GEMMs are in stock_torch.gflop"),
+                 "pose_networks": {"what": "2-D + 3-D pose estimators and pose head alone, forward + backward on the step's inputs (convolutions + BatchNorm on libforge, "
+                                           "attention blocks on rocBLAS / ATen)", "fwd_bwd_ms": ms_pose, "share_of_step": ms_pose / ms},
+                 "stock_torch": {"what": "kernels that are not libforge's (rocBLAS attention GEMMs, ATen element-wise / softmax / LayerNorm / optimizer): FLOPs "
+                                         "counted by torch's FlopCounterMode; share of kernel time by kernel NAME from the committed rocprofv3 trace",
+                                 "gflop": fc.get_total_flops() / 1e9, "rocprofv3": (share or {}).get(name)}}
+            # the same step as ONE hipGraph (forge_amd.graph.GraphedStep: forward, loss, backward, clip, capturable Adam): the eager step is host-bound
+            # (~3000 launches from Python); reported beside the eager number, which is what a DDP wrapper runs
+            try:
+                from forge_amd.graph import GraphedStep
+                opt_g = torch.optim.Adam(params, lr=1e-4, capturable=True)
+                call_g = model if feats is None else (lambda s, d, dv: model(s, d, dv, features_recon=feats))
+
+                def graph_fn():
+                    loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call_g, {}, dev)
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+                    opt_g.step()
+                    return loss.detach()
+                gs = GraphedStep(graph_fn, opt_g, warmup=2)
+                msg = _timed(gs, steps, warm=1)
+                e["hipgraph_replay"] = dict(floor_of(fm.gflop, msg), ms_per_step=msg, views_per_s=10 / msg * 1e3)
+                del gs, opt_g
+            except Exception as ex:
+                e["hipgraph_replay"] = {"error": repr(ex)[:300]}
+            for p_ in model.parameters():
+                p_.grad = None
+            torch.cuda.empty_cache()
+            if feats is None:
+                # the round-4 state for comparison: the same step with both pose estimators on stock torch kernels (MIOpen picks its solvers per process:
+                # asm Winograd in one, `naive_conv_*` fp32 in the next - 216 ms of a 256 ms step in BENCH-style runs of round 5's first build)
+                try:
+                    stock(True)
+                    step()
+                    torch.cuda.synchronize()
+                    e["pose_networks_on_stock_torch"] = {"ms_per_step": _timed(step, steps, warm=1), "pose_nets_fwd_bwd_ms": _timed(pose_nets_only(), steps, warm=1)}
+                except Exception as ex:
+                    e["pose_networks_on_stock_torch"] = {"error": repr(ex)[:200]}
+                finally:
+                    stock(False)
             out.append(e)
         except Exception as e:
             out.append({"name": name, "workload": workload, "error": repr(e)[:300]})

@@ -91,6 +91,43 @@ def load_imagenet_trunk(feature_extraction, state_dict, strict=True):
     return feature_extraction.load_state_dict(out, strict=strict)
 
 
+@_lib.on_tensor_device
+def resnet_rows_autograd(conv0, bn0, pool, stages, img, slope=0.0):
+    """A torchvision-style bottleneck ResNet (stem conv0 / bn0 / pool + `stages` = sequences of blocks with conv1..3, bn1..3, downsample) with
+    an autograd graph on the HIP kernels, activations as NHWC rows; returns the output rows of every stage. `slope`: 0 = ReLU (the encoder's
+    trunk, models/encoder.py:71-78), 0.01 = the LeakyReLU bottlenecks of the 2-D pose estimator's FPN (models/pose_estimator_2d.py:237-275).
+    Stem: patch gather + one-tap GEMM (the image needs no gradient), max-pool by torch; bottlenecks: 1x1 / 3x3 (stride 1 or 2) / 1x1
+    convolutions through convops.conv2d_rows, every BatchNorm's batch statistics from its convolution's GEMM epilogue."""
+    N, Ci, Hi, Wi = img.shape
+    kh, kw = conv0.kernel_size
+    s0, p0 = conv0.stride[0], conv0.padding[0]
+    Kp = ((kh * kw * Ci + 31) // 32) * 32
+    Hc, Wc = (Hi + 2 * p0 - kh) // s0 + 1, (Wi + 2 * p0 - kw) // s0 + 1
+    patches = torch.empty(N, 1, Hc, Wc, Kp, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.lib().forge_im2col_nchw(_lib.ptr(img.detach().contiguous()), _lib.ptr(patches), N, Ci, Hi, Wi, kh, kw, s0, p0, Kp,
+                                            _lib.current_stream()), "forge_im2col_nchw")
+    w0 = torch.nn.functional.pad(conv0.weight.permute(0, 2, 3, 1).reshape(conv0.out_channels, -1), (0, Kp - kh * kw * Ci))[None]
+    x, st0 = co.conv_taps_rows(patches, None, w0, None, [(0, 0, 0)], want_stats=True)
+    x = bn_act_rows(bn0, x.reshape(N, Hc, Wc, conv0.out_channels), slope, stats=st0)
+    x = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    outs = []
+    for stage in stages:
+        for blk in stage:
+            # conv1 hands its input through: the gradients of the identity / downsample path are added inside conv1's data-gradient GEMM
+            y1, idn, st1 = co.conv1x1_rows_skip(x, blk.conv1.weight)
+            out = bn_act_rows(blk.bn1, y1, slope, stats=st1)              # the statistics of every BatchNorm below come from its convolution's GEMM epilogue
+            y2, st2 = co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0], want_stats=True)
+            out = bn_act_rows(blk.bn2, y2, slope, stats=st2)
+            if blk.downsample is not None:
+                yd, std = co.conv2d_rows(idn, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0], want_stats=True)
+                idn = bn_act_rows(blk.downsample[1], yd, 1.0, stats=std)
+            # act(bn3(conv3) + identity) in bn3's apply pass (and its mask / d identity in bn3's backward apply pass)
+            y3, st3 = co.conv2d_rows(out, blk.conv3.weight, None, want_stats=True)
+            x = bn_act_rows(blk.bn3, y3, slope, residual=idn, stats=st3)
+        outs.append(x)
+    return outs
+
+
 class _HeadsFrozen(torch.autograd.Function):
     """Both heads (models/encoder.py:16-34) for frozen weights under autograd (pose refinement): forward = the fused inference launches
     of Encoder3D._heads_hip (merged transposed convolutions, BatchNorm / activations in the epilogues) keeping the two intermediate
@@ -237,38 +274,10 @@ class Encoder3D(co.PackedModule):
     def _bn2d_rows(bn, rows, relu=True):
         return bn_act_rows(bn, rows, 0.0 if relu else 1.0)
 
-    @_lib.on_tensor_device
     def _trunk_autograd_hip(self, img):
-        """ResNet-50 trunk with an autograd graph on the HIP kernels. Stem: patch gather + one-tap GEMM (the image needs no
-        gradient), max-pool by torch; bottlenecks: 1x1 / 3x3 (stride 1 or 2) / 1x1 convolutions through convops.conv2d_rows."""
+        """ResNet-50 trunk with an autograd graph on the HIP kernels (resnet_rows_autograd)."""
         fe = self.feature_extraction
-        conv0, bn0, pool = fe[0], fe[1], fe[3]
-        N, Ci, Hi, Wi = img.shape
-        kh, kw = conv0.kernel_size
-        s0, p0 = conv0.stride[0], conv0.padding[0]
-        Kp = ((kh * kw * Ci + 31) // 32) * 32
-        Hc, Wc = (Hi + 2 * p0 - kh) // s0 + 1, (Wi + 2 * p0 - kw) // s0 + 1
-        patches = torch.empty(N, 1, Hc, Wc, Kp, dtype=torch.float32, device=img.device)
-        _lib.check(_lib.lib().forge_im2col_nchw(_lib.ptr(img.detach().contiguous()), _lib.ptr(patches), N, Ci, Hi, Wi, kh, kw, s0, p0, Kp,
-                                                _lib.current_stream()), "forge_im2col_nchw")
-        w0 = torch.nn.functional.pad(conv0.weight.permute(0, 2, 3, 1).reshape(conv0.out_channels, -1), (0, Kp - kh * kw * Ci))[None]
-        x, st0 = co.conv_taps_rows(patches, None, w0, None, [(0, 0, 0)], want_stats=True)
-        x = bn_act_rows(bn0, x.reshape(N, Hc, Wc, conv0.out_channels), 0.0, stats=st0)
-        x = pool(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
-        for li in (4, 5, 6, 7):
-            for blk in fe[li]:
-                # conv1 hands its input through: the gradients of the identity / downsample path are added inside conv1's data-gradient GEMM
-                y1, idn, st1 = co.conv1x1_rows_skip(x, blk.conv1.weight)
-                out = bn_act_rows(blk.bn1, y1, 0.0, stats=st1)            # the statistics of every BatchNorm below come from its convolution's GEMM epilogue
-                y2, st2 = co.conv2d_rows(out, blk.conv2.weight, None, stride=blk.conv2.stride[0], want_stats=True)
-                out = bn_act_rows(blk.bn2, y2, 0.0, stats=st2)
-                if blk.downsample is not None:
-                    yd, std = co.conv2d_rows(idn, blk.downsample[0].weight, None, stride=blk.downsample[0].stride[0], want_stats=True)
-                    idn = bn_act_rows(blk.downsample[1], yd, 1.0, stats=std)
-                # relu(bn3(conv3) + identity) in bn3's apply pass (and its mask / d identity in bn3's backward apply pass)
-                y3, st3 = co.conv2d_rows(out, blk.conv3.weight, None, want_stats=True)
-                x = bn_act_rows(blk.bn3, y3, 0.0, residual=idn, stats=st3)
-        return x
+        return resnet_rows_autograd(fe[0], fe[1], fe[3], [fe[4], fe[5], fe[6], fe[7]], img, slope=0.0)[-1]
 
     def _head_autograd_hip(self, head, z):
         """A head (nn.Sequential of ConvTranspose3d / Conv3d / BatchNorm3d / LeakyReLU / ReLU, models/encoder.py:16-34) with an

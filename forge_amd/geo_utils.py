@@ -137,6 +137,18 @@ def predicted_camera_chain(pose_vec, to_se3, canonical_pose, canonical_extrinsic
     return pose_vec, poses, extrinsics
 
 
+def canonical_cameras(owner, dataset, device):
+    """(canonical pose, canonical extrinsics) of `dataset` on `device` (models/model.py:74-75), fetched ONCE per (dataset, device) and kept on
+    the model `owner`: the dataset hands out host tensors, and a pageable host->device copy per forward synchronises the stream and cannot be
+    captured into a hipGraph."""
+    cache = owner.__dict__.setdefault("_canon", {})
+    key = (id(dataset), str(device))
+    if key not in cache:
+        cache.clear()                                                   # one dataset at a time; the entry keeps the dataset alive, so its id stays unique
+        cache[key] = (dataset.get_canonical_pose_cv2(device=device).to(torch.float32), dataset.get_canonical_extrinsics_cv2(device=device).to(torch.float32), dataset)
+    return cache[key][:2]
+
+
 def camera_dict(extrinsics, K):
     """The {'R','T','K'} dict VolRender.forward takes (models/volume_render.py:40-48) from [..,4,4] extrinsics and [..,3,3] intrinsics."""
     E = extrinsics.reshape(-1, 4, 4)

@@ -91,9 +91,7 @@ class FORGE(nn.Module):
         pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True),            # [b(t-1),1024] each
                                self.encoder_traj_2d(clips, return_features=True)], dim=-1)
         pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
-        pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
-            pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
-            dataset.get_canonical_extrinsics_cv2(device=device), b, t)
+        pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(pose_vec, self.encoder_traj.toSE3, *geo_utils.canonical_cameras(self, dataset, device), b, t)
         gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
         return camPoses_cv2, camE_cv2, {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
 

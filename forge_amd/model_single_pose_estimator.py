@@ -76,8 +76,7 @@ class FORGE_poseEstimator3D(nn.Module):
         if not self.config.train.use_gt_pose:
             pose_vec, conf = self.encoder_traj(features_raw)                           # :45
             pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(
-                pose_vec, self.encoder_traj.toSE3, dataset.get_canonical_pose_cv2(device=device),
-                dataset.get_canonical_extrinsics_cv2(device=device), b, t)
+                pose_vec, self.encoder_traj.toSE3, *geo_utils.canonical_cameras(self, dataset, device), b, t)
             gt_rel = sample["cam_poses_rel_cv2"][:, 1:].reshape(b * (t - 1), 4, 4)
             camPose_return = {"gt": geo_utils.mat2quat(gt_rel), "pred": pose_vec, "conf": conf}
         else:

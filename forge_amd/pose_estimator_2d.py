@@ -1,8 +1,10 @@
-"""2-D pose estimator (ResNet-50 FPN + cross/self-attention) — NOT on the accelerated hot path
-(SURVEY.md §2.1 row 7). Present so that `FORGE` keeps the reference's attribute surface
-(`encoder_traj_2d`) and state_dict keys (`encoder_traj_2d.*`, 40.19 M parameters).
-Architecture re-expressed in stock PyTorch from models/pose_estimator_2d.py:10-275 and the
-Perceiver-style attention blocks of models/model_utils.py:258-427; einops is not required."""
+"""2-D pose estimator (ResNet-50 FPN + cross/self-attention): the reference's attribute surface (`encoder_traj_2d`) and state_dict keys
+(`encoder_traj_2d.*`, 40.19 M parameters); architecture re-expressed from models/pose_estimator_2d.py:10-275 and the Perceiver-style attention
+blocks of models/model_utils.py:258-427 (einops is not required).
+
+On the MI355X every convolution of the module - the FPN's LeakyReLU ResNet-50, its lateral / top / smoothing layers and the four stride-2
+convolutions of `conv` - runs on libforge_hip.so with HIP BatchNorm (round 5; FPN.forward_rows, PoseEstimator2D._conv_rows); the six attention
+blocks stay stock torch (rocBLAS GEMMs, softmax, LayerNorm). CPU tensors run the same modules on torch's own kernels."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -171,6 +173,21 @@ class FPN(nn.Module):
         p4 = F.interpolate(self.toplayer(c5), size=lat.shape[-2:], mode="bilinear", align_corners=False) + lat
         return self.smooth1(p4)
 
+    def forward_rows(self, x):
+        """The same pyramid level as NHWC rows [n,h,w,256] on libforge_hip.so: the LeakyReLU ResNet-50 through encoder.resnet_rows_autograd (MFMA
+        implicit-GEMM convolutions forward / data / weight gradient, HIP BatchNorm), the lateral / top / smoothing convolutions through
+        convops.conv2d_rows; only the 8x8 -> 16x16 bilinear up-sampling and the max-pool are torch ops. (On MIOpen these convolutions took whatever
+        solver its find step landed on in that process - asm Winograd in one run, `naive_conv_*` in the next.)"""
+        from . import convops as co
+        from .encoder import resnet_rows_autograd
+        l0 = self.layer0
+        _, _, c4, c5 = resnet_rows_autograd(l0[0], l0[1], l0[3], [self.layer1[0], self.layer2[0], self.layer3[0], self.layer4[0]], x,
+                                            slope=l0[2].negative_slope)
+        lat = co.conv2d_rows(c4, self.latlayer1.weight, self.latlayer1.bias)
+        top = co.conv2d_rows(c5, self.toplayer.weight, self.toplayer.bias)
+        up = F.interpolate(top.permute(0, 3, 1, 2), size=lat.shape[1:3], mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+        return co.conv2d_rows((up + lat).contiguous(), self.smooth1.weight, self.smooth1.bias)
+
 
 class PoseEstimator2D(nn.Module):
     """models/pose_estimator_2d.py:10-86"""
@@ -207,15 +224,21 @@ class PoseEstimator2D(nn.Module):
     def forward(self, x, return_features=False):
         """x [B,T,3,H,W] -> pose features [B(T-1),1024] or 7-D pose"""
         B, T, C, H, W = x.shape
-        feat = self.backbone(x.reshape(B * T, C, H, W))                   # [B*T,256,h,w]
-        h2, w2 = feat.shape[-2:]
-        feat = feat.reshape(B, T, 256, h2 * w2).permute(0, 1, 3, 2)       # [B,T,N,256]
+        hip = x.is_cuda and x.dtype == torch.float32 and not getattr(self, "force_stock_torch", False)
+        if hip:
+            feat = self.backbone.forward_rows(x.reshape(B * T, C, H, W))  # [B*T,h,w,256] NHWC rows
+            h2, w2 = feat.shape[1:3]
+            feat = feat.reshape(B, T, h2 * w2, 256)                       # [B,T,N,256]
+        else:
+            feat = self.backbone(x.reshape(B * T, C, H, W))               # [B*T,256,h,w]
+            h2, w2 = feat.shape[-2:]
+            feat = feat.reshape(B, T, 256, h2 * w2).permute(0, 1, 3, 2)   # [B,T,N,256]
         pos = self.pos_emb.to(feat.device)
         feat_canonical = (feat[:, 0] + pos).to(feat.dtype)                # [B,N,256]
         feat = (feat[:, 1:] + pos.unsqueeze(1)).to(feat.dtype).reshape(B, (T - 1) * h2 * w2, 256)
         for cross, selfa in zip(self.cross_attn_blks, self.self_attn_blks):
             feat = selfa(cross(x_q=feat, x_k=feat_canonical, x_v=feat_canonical, residual=feat))
-        if feat.is_cuda and feat.dtype == torch.float32 and not getattr(self, "force_stock_torch", False):
+        if hip:
             feat = self._conv_rows(feat.reshape(B * (T - 1), h2, w2, 256)).reshape(B * (T - 1), -1).squeeze()
         else:
             feat = feat.reshape(B * (T - 1), h2, w2, 256).permute(0, 3, 1, 2)

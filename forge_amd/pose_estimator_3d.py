@@ -116,8 +116,17 @@ class PoseTransformer(nn.Module):
         # plain attribute (not a buffer) as in the reference: absent from the state_dict
         self.pos_embed_3d_coord = (sincos_pos_embed_3d(coord_dim, inp_res, inp_res) * 0.1).reshape(1, -1, coord_dim)
 
+    def _pos_embed(self, like):
+        """The positional table on `like`'s device / dtype, copied there ONCE per (device, dtype) - the reference copies the host tensor in every
+        forward (models/pose_estimator_3d.py:137), a pageable host->device copy that synchronises and cannot be captured into a hipGraph."""
+        cache = self.__dict__.setdefault("_pe_cache", {})
+        key = (str(like.device), like.dtype)
+        if key not in cache:
+            cache[key] = self.pos_embed_3d_coord.to(like)
+        return cache[key]
+
     def forward(self, q, k, q_pe=None, k_pe=None):
-        pe = self.pos_embed_3d_coord.to(q)
+        pe = self._pos_embed(q)
         attn = self.cross_transformer.get_attn(query=q, key=k)          # [B,N,N]
         coord = torch.matmul(attn, pe).permute(0, 2, 1)                  # [B,C,N]
         return self.self_transformer(query=coord, key=coord)

@@ -19,7 +19,12 @@ def _publish(losses, terms):
     if terms:
         from . import dist as fdist
         vec = fdist.all_reduce_mean_(torch.stack([v.detach() for v in terms.values()]))
-        losses.update(dict(zip(terms.keys(), vec.cpu().tolist())))
+        if vec.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture (forge_amd.graph.GraphedStep) a device->host copy is illegal: the terms stay device scalars, views of ONE
+            # static tensor the replay overwrites - read them after a replay with .tolist()
+            losses.update(dict(zip(terms.keys(), vec.unbind(0))))
+        else:
+            losses.update(dict(zip(terms.keys(), vec.cpu().tolist())))
     return losses
 
 

@@ -2,7 +2,7 @@
 """Time the joint 2D3D fine-tune iteration (BASELINE configs[4]; kubric_train_joint.py:111-141) exactly as bench.py's extra_configs
 `joint_step` / `joint_step_grid64` run it (bench.joint_configs), for rocprofv3 passes:
 
-    JOINT_GRID=32|64  JOINT_STEPS=n   python tools/joint_step_probe.py
+    JOINT_GRID=32|64  JOINT_STEPS=n  [JOINT_STOCK=1]   python tools/joint_step_probe.py
 
 FORGE with predicted poses (2-D + 3-D pose estimators and the pose head on stock torch kernels; everything else on libforge_hip.so),
 compute_all_loss_nvs, backward, clip 10, Adam over the reference's parameter list."""
@@ -24,6 +24,8 @@ cfg.loss.regu_origin_proj = 1.0
 model = FORGE(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).train()
+if os.environ.get("JOINT_STOCK") == "1":       # the round-4 state: both pose estimators entirely on stock torch kernels (MIOpen / rocBLAS)
+    model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = True
 params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render) for p in m.parameters()]
 opt = torch.optim.Adam(params, lr=1e-4, fused=True)
 sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
@@ -47,10 +49,13 @@ def step():
 for _ in range(2):
     l = step()
 torch.cuda.synchronize()
+torch.cuda._sleep(1000)                    # marker kernel (`spin_kernel`) for tools/joint_kernel_share.py: the timed steps start here
 t0 = time.perf_counter()
 for _ in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+torch.cuda._sleep(1000)                    # ... and end here
+torch.cuda.synchronize()
 print("joint step grid %d: %.1f ms/step (fwd+bwd+clip+Adam, 10 rendered views), loss %.5f, peak mem %.1f GB, steps timed %d (+2 warm-up)"
       % (grid, dt * 1e3, l.item(), torch.cuda.max_memory_allocated() / 2 ** 30, steps))

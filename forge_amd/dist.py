@@ -19,9 +19,11 @@ def env_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend=None):
+def init(backend=None, allow_shared_gpus=False, timeout_s=None):
     """Initialise the default process group from the torchrun environment (no-op for world size 1).
-    Returns (rank, local_rank, world_size)."""
+    Returns (rank, local_rank, world_size). With fewer visible GPUs than ranks RCCL cannot run (it refuses two ranks on one device): that
+    is an ERROR unless the caller asks for a functional rehearsal with `allow_shared_gpus=True` (ranks share devices, collectives on gloo) -
+    a scaling number from shared devices would be meaningless, so nothing drops to gloo silently. An explicit `backend` is taken as is."""
     rank, local_rank, world = env_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -29,13 +31,19 @@ def init(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
             if backend == "nccl" and torch.cuda.device_count() < world:
-                # more ranks than GPUs (a multi-rank dry run on a 1-GPU box): RCCL refuses two ranks on one device, gloo does not
-                print("forge_amd.dist: %d ranks on %d GPU(s) - falling back to gloo, ranks share devices"
+                if not allow_shared_gpus:
+                    raise RuntimeError("forge_amd.dist.init: %d ranks but only %d GPU(s) visible - one process per MI355X is the deployment; pass "
+                                       "allow_shared_gpus=True for a functional rehearsal on shared devices (collectives on gloo)" % (world, torch.cuda.device_count()))
+                print("forge_amd.dist: %d ranks on %d GPU(s) - rehearsal on shared devices, collectives on gloo"
                       % (world, torch.cuda.device_count()), file=sys.stderr)
                 backend = "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+        kw = {}
+        if timeout_s:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -190,13 +198,12 @@ class _RenderRaysSharded(torch.autograd.Function):
             res.append(torch.zeros_like(t) if (n and g is None) else g)
         ctx.local = None
         if world > 1 and reduce == "all":
-            views = [(_dense_view(g), g) for g in res if g is not None]
-            work = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v, _ in views]
+            views = [None if g is None else _dense_view(g) for g in res]
+            work = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in views if v is not None]
             for w in work:
                 w.wait()
-            for v, g in views:
-                if v.data_ptr() != g.data_ptr():
-                    g.copy_(v)                                   # _dense_view had to copy (same shape): write the sum back
+            # _dense_view had to copy (a gradient that is neither contiguous nor channels-last, e.g. an expanded one): the copy - same shape - IS the sum
+            res = [g if (g is None or v.data_ptr() == g.data_ptr()) else v for g, v in zip(res, views)]
         return res[0], res[1], res[2], None, None, None, None, None
 
 

@@ -100,6 +100,8 @@ class FORGE(nn.Module):
         in the reconstruction (rotate -> fuse -> heads -> render) while the pose estimators keep their native inputs - BASELINE configs[4]'s
         128^3-voxel scenes need D = 64 volumes, which the encoder cannot produce from 256^2 images (models/encoder.py:49)."""
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
+        if features_recon is None:
+            features_recon = sample.get("features_recon")             # ... or handed over with the sample (what a wrapped model - DDP - can be given)
         b, t_all = sample["images"].shape[:2]
         clips = sample["images"][:, :self.N_INPUT]
         b, t, c, h, w = clips.shape

@@ -65,13 +65,21 @@ class FORGE_poseEstimator3D(nn.Module):
         view2vol = per_scene.reshape(b * 2 * t).contiguous()
         return self.render(cameras, features, densities, return_origin_proj=True, view2vol=view2vol)
 
-    def forward(self, sample, dataset, device):
+    def forward(self, sample, dataset, device, features_recon=None):
+        """models/model_single_pose_estimator.py:26-138. `features_recon` (not in the reference): per-view feature volumes [b,t,C,D,D,D] that
+        replace the encoder's in the reconstruction - BASELINE configs[3]'s 128^3-voxel scenes need D = 64 volumes, which the encoder cannot
+        produce from 256^2 images (models/encoder.py:49). With GT poses the encoder is then not run at all (nothing consumes its output)."""
         sample = stage_sample(sample, device)                         # ONE pinned host->device copy for host-resident samples (f4)
+        if features_recon is None:
+            features_recon = sample.get("features_recon")             # ... or handed over with the sample (what a wrapped model - DDP - can be given)
         clips = sample["images"]
         b, t, c, h, w = clips.shape
-        features_raw = self.encoder_3d.get_feat3D(clips.reshape(b * t, c, h, w))      # [b*t,C,D,H,W]
-        _, C, D, H, W = features_raw.shape
-        features_raw = features_raw.reshape(b, t, C, D, H, W)
+        if features_recon is not None and self.config.train.use_gt_pose:
+            features_raw = features_recon
+        else:
+            features_raw = self.encoder_3d.get_feat3D(clips.reshape(b * t, c, h, w))      # [b*t,C,D,H,W]
+            _, C, D, H, W = features_raw.shape
+            features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
             pose_vec, conf = self.encoder_traj(features_raw)                           # :45
@@ -92,7 +100,7 @@ class FORGE_poseEstimator3D(nn.Module):
             origin_proj = self.render.proj_origin(cameras, device)
             return camPose_return, 2 * origin_proj / self.config.dataset.img_size
 
-        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw, camPoses_cv2[:, :t], cameras)
+        rendered_imgs, rendered_masks, origin_proj = self.reconstruct(features_raw if features_recon is None else features_recon, camPoses_cv2[:, :t], cameras)
         if self.config.train.use_gt_pose:
             return rendered_imgs, rendered_masks
         return rendered_imgs, rendered_masks, 2 * origin_proj / self.config.dataset.img_size, camPose_return

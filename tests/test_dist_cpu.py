@@ -128,6 +128,18 @@ def test_bench_entry_launches_its_own_ranks_dry_run():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["dry_run"] is True and d["views_counted"] == 8 * 2 * 5 * 3 and d["steps"] == 3
     assert d["ranks_ok"] == 8 and d["error"] is None
+    # the sub-record skeleton of the real multi-rank line (bench.multi_rank_records), rehearsed with token workloads: a DDP step
+    # with and without no_sync(), a record that fails on ONE rank (reported, the line and the other records survive), the ray-sharded render op
+    m = d["multi_rank"]
+    assert m["ddp_train"]["ranks_ok"] == 8 and m["ddp_train"]["ms_per_step"] > 0 and m["ddp_train"]["ms_per_step_no_sync"] > 0
+    assert m["failing_record"]["ranks_ok"] == 7 and len(m["failing_record"]["errors"]) == 1 and "rank 7" in m["failing_record"]["errors"][0]
+    assert m["ray_sharded_joint"]["ranks_ok"] == 8 and m["ray_sharded_joint"]["rows"] == 16 and m["ray_sharded_joint"]["d_feat"] == m["ray_sharded_joint"]["expected_d_feat"]
+    # a sub-record that never comes back: the watchdog prints the MAIN line and every rank leaves with exit code 0
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run", "--rehearse-hang"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, FORGE_BENCH_SUBRECORD_DEADLINE_S="3"), cwd=ROOT)
+    assert w.returncode == 0, w.stderr[-2000:]
+    dw = json.loads([l for l in w.stdout.splitlines() if l.startswith("{")][0])
+    assert dw["n_gpus"] == 2 and "did not finish" in dw["multi_rank"]["error"]
     # --train rehearsal: the same entry wraps a model in DistributedDataParallel over the 8 ranks (gloo here, RCCL on the node), steps it, and
     # the replicas end up identical on every rank
     t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "4", "--dry-run", "--train"],

@@ -59,7 +59,7 @@ def _worker(rank, world, port, q, sync_bn=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd
-    fd.init()                                       # 2 ranks on 1 GPU -> gloo, both on cuda:0
+    fd.init(allow_shared_gpus=True)                 # 2 ranks on 1 GPU -> gloo, both on cuda:0
     dev = torch.device("cuda", torch.cuda.current_device())
     _, model = _build(dev, batch_stats=sync_bn)
     calls = [0]
@@ -132,7 +132,7 @@ def _ray_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd, ops, synthetic as syn
-    fd.init()
+    fd.init(allow_shared_gpus=True)
     dev = torch.device("cuda", torch.cuda.current_device())
     D, C, V, Hr, S = 64, 16, 3, 128, 64
     feat, dens = syn.blob_volumes(1, D, C, seed=5)
@@ -204,6 +204,18 @@ def test_bench_entry_two_ranks_on_the_shared_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d and d["ranks_ok"] == 2 and not d["errors"]
     assert d["strong_scaling"]["total_scenes"] == 8 and d["strong_scaling"]["scenes_per_gpu"] == 4 and d["strong_scaling"]["ranks_ok"] == 2
     assert abs(d["value"] - 2 * 5 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]          # whole-job views / max-over-ranks time
+    # the SAME line carries the sub-records whose collectives matter on a real node - DDP + SyncBatchNorm training (configs[3]) with
+    # and without the gradient all-reduce, and the ray-sharded joint step (configs[4]) at both grids with the sharded render op in both reduce modes
+    m = d["multi_rank"]
+    t = m["ddp_train"]
+    assert t["ranks_ok"] == 2 and not t["errors"] and t["global_batch"] == 8 and t["ms_per_step"] > 0 and t["ms_per_step_no_sync"] > 0
+    assert t["gradient_bytes_all_reduced_per_step"] > 200e6 and t["syncbn_layers"] > 50 and t["process_group"]["world_size"] == 2
+    for name, vol in (("ray_sharded_joint", 17 * 64 ** 3 * 4), ("ray_sharded_joint_grid64", 17 * 128 ** 3 * 4)):
+        j = m[name]
+        assert j["ranks_ok"] == 2 and not j["errors"] and j["band_rows"] == 64 and j["ms_per_step"] > 0 and j["unsharded_ms_per_step"] > 0, (name, j)
+        assert j["all_reduce_bytes_per_step"] >= vol and j["all_gather_bytes_per_step"] == 10 * 17 * 128 * 128 * 4
+    op = m["ray_sharded_joint"]["sharded_render_op"]
+    assert all(op["volume_%d_reduce_%s_fwd_bwd_ms" % (D, mode)] > 0 for D in (64, 128) for mode in ("all", "none"))
 
 
 def _spawn2(target, args=(), timeout=420):
@@ -271,7 +283,7 @@ def _ray_bwd_worker(rank, world, port, q, D=64, reduce="all"):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd
-    fd.init()
+    fd.init(allow_shared_gpus=True)
     dev = torch.device("cuda", torch.cuda.current_device())
     loss, g, rgb = _ray_bwd_case(dev, True, D, reduce)
     if D > 64:                                      # 128^3: the volume gradients are 134 + 8 MB per rank - ship a strided sample and float64 checksums
@@ -377,7 +389,7 @@ def _joint_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
     from forge_amd import dist as fd
-    fd.init()
+    fd.init(allow_shared_gpus=True)
     dev = torch.device("cuda", torch.cuda.current_device())
     q.put((rank, _joint_step(dev, True)))
     dist.barrier()
@@ -414,7 +426,7 @@ def _syncbn_worker(rank, world, port, q):
     import torch.distributed as dist
     from forge_amd import dist as fd
     from forge_amd.fusion import bn_act_rows
-    fd.init()
+    fd.init(allow_shared_gpus=True)
     dev = torch.device("cuda", torch.cuda.current_device())
     x, dy, w, b = _syncbn_case()
     rows = slice(0, 5) if rank == 0 else slice(5, 8)                       # UNEQUAL shards: 5 and 3 of the 8 batch elements
@@ -477,6 +489,12 @@ def test_bench_train_mode_two_ranks_and_n1_paths_agree():
     assert tr.returncode == 0, tr.stderr[-3000:]
     d = json.loads([l for l in tr.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["ranks_ok"] == 2 and not d["errors"] and d["value"] > 0 and d["config"]["global_batch"] == 2
+    # configs[3]'s real per-GPU shape through the same entry: --grid 64 (128^3-voxel render grid from synthetic 64^3 feature volumes in the sample)
+    t64 = subprocess.run([sys.executable, bench, "--gpus", "2", "--train", "--grid", "64", "--steps", "1", "--warmup", "1", "--repeats", "1"], capture_output=True,
+                         text=True, timeout=1200, env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=ROOT)
+    assert t64.returncode == 0, t64.stderr[-3000:]
+    d64 = json.loads([l for l in t64.stdout.splitlines() if l.startswith("{")][0])
+    assert d64["n_gpus"] == 2 and d64["ranks_ok"] == 2 and not d64["errors"] and d64["value"] > 0 and d64["config"]["feature_grid"] == 64 and "128^3" in d64["metric"]
     quick = ["--steps", "3", "--warmup", "1", "--no-microbench", "--no-cpu-baseline", "--no-extra"]
     plain = subprocess.run([sys.executable, bench, "--gpus", "1"] + quick, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-2000:]

@@ -161,6 +161,31 @@ def pmc_traffic(prefix):
     return None
 
 
+KLOOP_CEILING_TF = {"64x64": 130.0, "64x128": 137.0, "128x128": 141.0}     # LDS -> MFMA loop alone (no global -> LDS staging), direct gates launch K = 6912:
+                                                                            # debug builds of tools/debug/gemm_ceiling.py, profiles/TUNING_LOG.md "K-loop ceiling"
+
+
+def rocprof_conv_time():
+    """Per-step kernel time of the dominant kernel from the committed `rocprofv3 --kernel-trace --stats` run of this command with ONE step in flight
+    (profiles/r*_rocprofv3_kernel_stats.csv + its .meta.json: steps traced): sum of TotalDurationNs over every conv_igemm_kernel<...> instantiation /
+    steps - pure kernel durations (no launch gaps), what the eager HIP-event pairs of `frac` cannot give. None when no profile is committed."""
+    import csv
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprofv3_kernel_stats.csv")), reverse=True):
+        meta = f[:-4] + ".meta.json"
+        if "grid64" in f or "in_flight" in f or not os.path.exists(meta):
+            continue
+        try:
+            m = json.load(open(meta))
+            rows = [r for r in csv.DictReader(open(f)) if "conv_igemm_kernel<" in r["Name"]]
+            ns = sum(float(r["TotalDurationNs"]) for r in rows)
+            return {"ms_per_step": ns / 1e6 / m["steps_traced"], "launches_per_step": sum(int(r["Calls"]) for r in rows) / m["steps_traced"],
+                    "source": os.path.basename(f), "steps_traced": m["steps_traced"]}
+        except Exception:
+            continue
+    return None
+
+
 def time_kernel(fn, iters=20, warm=3):
     """Average duration (ms) of one launch of `fn`, HIP events on the current stream."""
     for _ in range(warm):
@@ -699,6 +724,7 @@ def extra_configs(dev, steps=5):
     from forge_amd.graph import GraphedCall, GraphedForward, PipelinedForward
     from forge_amd.model import FORGE
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    from forge_amd import train
     from forge_amd.train import grouped_mse
     out = []
     holder = {}
@@ -823,7 +849,7 @@ def extra_configs(dev, steps=5):
         loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+        train.clip_grad_norm_(m3.parameters(), 10.0)
         opt.step()
     entry("train_step", "GT-pose training step (kubric_train_pose_3D.py; scripts/kubric_trainer.py:47-59): FORGE_poseEstimator3D, 1 scene x 5 views, "
           "3 fusions, 10 rendered views, fused MSE, backward, clip 10, Adam; train-mode BatchNorm on the HIP kernels; eager launch", 10, train_step, train_step)
@@ -838,7 +864,7 @@ def extra_configs(dev, steps=5):
             loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+            train.clip_grad_norm_(m3.parameters(), 10.0)
             opt.step()
         entry("train_step_4_scenes", "the same training step at configs[3]'s per-GPU batch: 4 scenes x 5 views -> 40 rendered views per step; eager launch",
               40, train_step4, train_step4, n=steps)
@@ -862,7 +888,7 @@ def extra_configs(dev, steps=5):
             loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+            train.clip_grad_norm_(m3.parameters(), 10.0)
             opt.step()
         entry("train_step_4_scenes_grid64", "BASELINE configs[3] per-GPU shape: GT-pose training step, 4 scenes x 5 synthetic [128,64^3] feature volumes "
               "(128^3-voxel render grid) -> rotate(D=64) -> 3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
@@ -884,7 +910,7 @@ def extra_configs(dev, steps=5):
             mm = grouped_mse(masks.reshape(1, 10, 1, 256, 256), s1["fg_probabilities"][:, :T_IN], T_IN)
             loss = 5.0 * (mi[0] + mi[1]) + mm[0] + mm[1]
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(m3.parameters(), 10.0)
+            train.clip_grad_norm_(m3.parameters(), 10.0)
             opt_g.step()
             return loss.detach()
         gs = GraphedStep(graph_fn, opt_g, warmup=2)
@@ -954,7 +980,7 @@ def joint_configs(dev, steps=5):
             loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call, {}, dev)
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+            train.clip_grad_norm_(model.parameters(), 10.0)
             opt.step()
             return loss
         return step
@@ -1012,7 +1038,7 @@ def joint_configs(dev, steps=5):
                 def graph_fn():
                     loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call_g, {}, dev)
                     loss.backward()
-                    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+                    train.clip_grad_norm_(model.parameters(), 10.0)
                     opt_g.step()
                     return loss.detach()
                 gs = GraphedStep(graph_fn, opt_g, warmup=2)
@@ -1294,6 +1320,9 @@ def main():
                          "1 = one stream, back to back")
     ap.add_argument("--dump-conv", action="store_true", help="print every conv launch of one step (shape, ms, TFLOP/s) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="with --no-cpu-baseline: also skip the one CPU oracle forward the last output is checked against")
+    ap.add_argument("--min-psnr-db", type=float, default=None, help="exit non-zero unless the last output of the timed region is at least this close to the oracle "
+                                                                    "(soak runs: --steps 3000 --no-cpu-baseline --no-extra --min-psnr-db 100)")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs / strong_scaling (the other BASELINE configurations)")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo rehearsal of the multi-rank launch path (no HIP work)")
@@ -1513,18 +1542,32 @@ def main():
                 "gflop_per_step": v["gflop"], "share_of_step": v["total_ms"] / step_ms}
             for k, v in sorted(convs.items(), key=lambda kv: -kv[1]["total_ms"])}
     fl = floor_of(tot_gf + n16_gf, step_ms)
+    tr = pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128")
+    rp = rocprof_conv_time() if (args.grid == 32 and B == 1) else None
+    ceil_tf = KLOOP_CEILING_TF["64x128"]                              # the tile that carries ~80 % of the step's FLOPs
     roofline = {"kernel": "conv_igemm_kernel<BM, BN, waves> (fp32 MFMA implicit-GEMM conv; all %d launches of one step, %d tile instantiations)"
                           % (n_launch, len(convs)),
                 "bound": "mfma", "achieved": tot_gf / tot_ms, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tot_gf / tot_ms / FP32_MFMA_PEAK_TF,
-                "traffic": pmc_traffic("winograd gates" if wino_rec else "conv_igemm_kernel<128"), "avg_launch_ms": tot_ms / n_launch,
+                # flat keys: HBM-side bytes of the dominant launch from the PMC counters, per launch, next to its algorithmic bytes
+                "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_algorithmic_bytes": tr["algorithmic_bytes"] if tr else None,
+                "traffic_launch": tr["launch"] if tr else None, "traffic_source": ("profiles/" + tr["source"]) if tr else None,
+                # (5b) the same fraction from pure kernel durations: rocprofv3 --kernel-trace --stats of this command, one step in flight
+                "frac_rocprof": (tot_gf / rp["ms_per_step"] / FP32_MFMA_PEAK_TF) if rp else None, "rocprof_kernel_ms_per_step": rp["ms_per_step"] if rp else None,
+                "rocprof_source": ("profiles/" + rp["source"]) if rp else None,
+                # (5c) what the kernel's own LDS -> MFMA loop can do with staging removed (measured on debug builds): the exact-fp32 ceiling of this design
+                "ceiling": {"kloop_without_staging_tflops": KLOOP_CEILING_TF, "frac_of_peak": ceil_tf / FP32_MFMA_PEAK_TF,
+                            "source": "profiles/TUNING_LOG.md 'K-loop ceiling' (tools/debug/gemm_ceiling.py on FORGE_EXP_* debug builds, direct gates launch K = 6912)"},
+                "frac_of_ceiling": (tot_gf / (rp["ms_per_step"] if rp else tot_ms)) / ceil_tf,
+                "avg_launch_ms": tot_ms / n_launch,
                 "executed_gflop": fl["executed_gflop"], "executed_frac": fl["executed_frac"], "floor_ms": fl["floor_ms"], "step_over_floor": fl["step_over_floor"],
                 "kernel_ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms, "instantiations": inst,
                 "note": "frac = FLOPs the dominant kernel's launches EXECUTE / their HIP-event time / peak (a statement about the kernel; eager pass, each "
-                        "event pair includes the host launch gap and, for split-K launches, the reduction). executed_frac = floor_ms / ms_per_step = the "
+                        "event pair includes the host launch gap and, for split-K launches, the reduction); frac_rocprof = the same FLOPs / the kernels' own "
+                        "durations in the committed rocprofv3 trace of this command. executed_frac = floor_ms / ms_per_step = the "
                         "WHOLE step (all kernels, hipGraph replay) against the time its executed matrix-core FLOPs need at peak (a statement about the "
                         "step). In SURVEY.md 8(d)'s direct-convolution FLOPs the same launches are %.0f GF (the Winograd launches execute 2.25x fewer "
                         "multiplies than the convolutions they replace), so a fraction in those units can exceed 1 and is not reported as one; "
-                        "traffic = PMC pass of the fusion's point-GEMM launch" % alg_gf}
+                        "traffic = PMC pass of the fusion's point-GEMM launch (L2 -> fabric bytes, Infinity-Cache hits included)" % alg_gf}
     if args.grid == 32:
         metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
         workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
@@ -1563,11 +1606,19 @@ def main():
     if multi is not None:
         result["multi_rank"] = multi
     ref = None
-    if world == 1 and not args.no_cpu_baseline and args.grid == 32:
-        cb, ref = cpu_baseline(sample_cpu, weights, cfg)
-        result["cpu_baseline"] = cb
+    if world == 1 and args.grid == 32 and not (args.no_cpu_baseline and args.no_oracle_check):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import forge_oracle as fo
+        if not args.no_cpu_baseline:
+            cb, ref = cpu_baseline(sample_cpu, weights, cfg)
+            result["cpu_baseline"] = cb
+        else:
+            # no timing of the CPU path, but the LAST output of the timed region is still checked against the oracle (one CPU forward of scene 0):
+            # a soak run must look at what it produced ("a soak that never looks at its output proves only that nothing crashed")
+            one = {k: v[:1] for k, v in sample_cpu.items()}
+            with torch.no_grad():
+                ref = fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN], one["cam_extrinsics_cv2_canonicalized"][:, :T_IN],
+                                          one["K_cv2"][:, :T_IN], weights, cfg, order_by_distance=True)
         img0 = out[0][:V_OUT].cpu()
         result["psnr_vs_oracle_db"] = fo.psnr(img0, ref[0])
         result["oracle_note"] = ("oracle = oracle/forge_oracle.py, pinned by golden vectors from the reference's own module code; its ray-marcher restates "
@@ -1578,12 +1629,17 @@ def main():
         tgt = sample_cpu["images"][0, :V_OUT]
         p_build, p_oracle = fo.psnr(img0, tgt), fo.psnr(ref[0], tgt)
         result["psnr_to_target_db"] = {"build": p_build, "oracle": p_oracle, "abs_diff": abs(p_build - p_oracle)}
-        result["speedup_vs_cpu_baseline"] = result["value"] / cb["value"]
+        if "cpu_baseline" in result:
+            result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
     if world == 1 and not args.no_extra and args.grid == 32:
         del graphed, step
         torch.cuda.empty_cache()
         result["extra_configs"] = extra_configs(dev, steps=10)
     print(json.dumps(result), flush=True)
+    if args.min_psnr_db is not None:
+        got = result.get("psnr_vs_oracle_db")
+        if got is None or not got >= args.min_psnr_db:
+            raise SystemExit("bench.py: the last output of the timed region is %s dB from the oracle, below --min-psnr-db %.1f" % (got, args.min_psnr_db))
     return result
 
 

@@ -165,11 +165,17 @@ class _ZeroArena:
         self.want = self.used
         self.buf, self.off, self.used, self.task = None, 0, 0, -1
 
+    # the arena needs two private autograd hooks (the id of the running backward pass, an end-of-pass callback); a torch build without them
+    # gets plain torch.zeros for every request (feature-detected, not assumed)
+    HAVE_HOOKS = hasattr(torch._C, "_current_graph_task_id") and hasattr(getattr(torch.autograd.Variable, "_execution_engine", None), "queue_callback")
+
     def zeros(self, shape, device):
         n = 1
         for d in shape:
             n *= int(d)
         nbytes = (n * 4 + 255) // 256 * 256
+        if not self.HAVE_HOOKS:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
         task = torch._C._current_graph_task_id()                  # -1 outside a backward pass
         if task < 0:
             return torch.zeros(shape, dtype=torch.float32, device=device)
@@ -198,8 +204,12 @@ class _ZeroArena:
 GRAD_ZEROS = _ZeroArena()
 
 
-def grad_zeros(shape, device):
-    """A zero-filled float32 tensor for a weight gradient (see _ZeroArena): inside a backward pass a slice of the pass's arena, else torch.zeros."""
+def grad_zeros(shape, device, scratch=False):
+    """A zero-filled float32 tensor for a weight gradient (see _ZeroArena): inside a backward pass a slice of the pass's arena, else torch.zeros.
+    scratch = True: a transient the caller does NOT hand to autograd as a gradient (Winograd-domain dU accumulators) - its own allocation, so that
+    parameter gradients (which AccumulateGrad keeps as views of the arena) do not pin transients for as long as they live."""
+    if scratch:
+        return torch.zeros(tuple(shape), dtype=torch.float32, device=device)
     return GRAD_ZEROS.zeros(tuple(shape), device)
 
 
@@ -436,7 +446,7 @@ def conv3_wgrad(dy, x1, C1, x2, C2, dwp, grid, Cout, bs1=0, taps=None, dM=None):
     if dM is None:                                             # (the caller may hold A dy A^T already: wino_input_dy)
         dM = torch.empty(16, R, Cout, dtype=torch.float32, device=dev)
         _lib.check(L.forge_wino_dy(_lib.ptr(dy), dy.shape[-1], _lib.ptr(dM), n, D, H, W, Cout, st), "forge_wino_dy")
-    dU = grad_zeros((16, kd, Cout, C1 + C2), dev)
+    dU = grad_zeros((16, kd, Cout, C1 + C2), dev, scratch=True)
     _lib.check(L.forge_wino_wgrad(_lib.ptr(dM), _lib.ptr(V1), C1, 0, 0, _lib.ptr(V2), C2, 0, 0, _lib.ptr(dU), n, D, Ht, Wt, Cout, kd, st), "forge_wino_wgrad")
     _lib.check(L.forge_wino_dw(_lib.ptr(dU), _lib.ptr(dwp), Cout, C1 + C2, kd, st), "forge_wino_dw")
     return dwp

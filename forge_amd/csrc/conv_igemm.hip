@@ -968,6 +968,11 @@ extern "C" int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1
                                              pl.ksplit <= a.tpp * ((C1 + C2) / BK)), FORGE_EINVAL,
                           "forge_conv_igemm: ksplit=%d needs epilogue 0/1 without phases, Cout, ldo %% 4 == 0 and a workspace of ksplit M Cout floats", pl.ksplit);
         }
+        // the statistics by-product is written by the GEMM epilogue in 32-row blocks of the PLANNED tile: a caller that asks for it must know the
+        // tile (to size `stats` and to tell forge_bn_train_fwd how many blocks to read) and must not land on a split-K plan, whose launches skip
+        // the epilogue - so it has to hand the plan over (forge_conv_igemm_plan) instead of leaving it to this call
+        FORGE_REQUIRE(stats == nullptr || (tile != 0 && pl.ksplit == 1), FORGE_EINVAL,
+                      "forge_conv_igemm: output statistics need an explicit tile ('A'..'E' from forge_conv_igemm_plan) and a plan without split-K");
         if (pl.ksplit > 1) { a.ksplit = pl.ksplit; a.ws = splitk_ws; }
         if (int rc = launch_conv_tile(a, pl.tile, st)) return rc;
         if (a.ksplit > 1) {

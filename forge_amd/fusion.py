@@ -62,6 +62,11 @@ def bn_rows_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, slope,
         if stats.dim() != 3 or stats.shape[1:] != (2, C) or stats.dtype != torch.float64:
             raise ValueError("bn_rows_fwd: stats must be float64 [blocks][2][%d], got %s %s" % (C, stats.dtype, tuple(stats.shape)))
         pre = stats.shape[0]
+        # the producing GEMM wrote whole workgroup tiles of 64 or 128 rows in 32-row blocks (convops.stats_blocks): a stats tensor of another
+        # convolution's output (other M) cannot have a block count in that window - refuse it instead of normalising with foreign sums
+        lo, hi = (M + 63) // 64 * 2, (M + 127) // 128 * 4
+        if not (min(lo, hi) <= pre <= max(lo, hi)):
+            raise ValueError("bn_rows_fwd: %d statistics blocks do not belong to an output of %d rows (expected %d or %d)" % (pre, M, lo, hi))
     if group is None:
         ws = stats if pre else torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=dev)
         _lib.check(L.forge_bn_train_fwd(p(x), x.stride(0), p(gamma), p(beta), float(eps), float(slope), p(y), C, p(mean), p(invstd), p(running_mean),
@@ -565,7 +570,7 @@ class _FuseGroupsTrain(torch.autograd.Function):
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         newV = lambda rows, c: torch.empty(16, rows, c, dtype=torch.float32, device=dev)
         UT = {k: co.wino_pack_packed(v, transpose=True) for k, v in packs.items()}     # Winograd-domain data-gradient weights [16][3][Cin][Cout]
-        dU = {k: co.grad_zeros((16, 3, v.shape[1], v.shape[2]), dev) for k, v in packs.items()}
+        dU = {k: co.grad_zeros((16, 3, v.shape[1], v.shape[2]), dev, scratch=True) for k, v in packs.items()}
         Mm = newV(R, 2 * C)
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
 
@@ -995,7 +1000,8 @@ class ConvGRU_3D(co.PackedModule):
         bns = (fc[1], fc[4], self.fusion_norm)
         rows_probe = x.permute(0, 1, 3, 4, 5, 2)
         if (co.wino_enabled() and co.wino_fits(b, D, H, W, 2 * C, views=t) and co.wino_wgrad_applies(b, D, H, W, C, 0, C)
-                and all(bn_hip_train(m, rows_probe) and m.weight is not None for m in bns) and isinstance(fc[2], nn.LeakyReLU)):
+                and all(bn_hip_train(m, rows_probe) and m.weight is not None for m in bns)
+                and all(isinstance(a, nn.LeakyReLU) and a.negative_slope == 0.01 for a in (fc[2], fc[5]))):       # the node's kernels are launched with slope 0.01 for BOTH activations
             # the training step proper (every BatchNorm on batch statistics): one hand-scheduled autograd node for all groups
             outs = _FuseGroupsTrain.apply(x, cell.conv_gate.weight, cell.conv_gate.bias, cell.out_gate.weight, cell.out_gate.bias,
                                           fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[3].weight, fc[3].bias, fc[4].weight, fc[4].bias,

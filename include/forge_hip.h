@@ -209,6 +209,8 @@ int forge_resize_bilinear_bwd(const float* g, float* din, int P, int Hi, int Wi,
  *            every block is written, blocks past M with partial / zero sums) - the
  *            batch statistics of the BatchNorm behind the convolution as a by-product of the epilogue (fixed order, no atomics):
  *            forge_bn_train_fwd / forge_bn_sync_stats take them as their partial sums (nblk_pre) instead of re-reading the activation.
+ *            The block count depends on the tile, and a split-K plan skips the epilogue: a call with stats != NULL must pass an explicit
+ *            `tile` ('A'..'E', forge_conv_igemm_plan's answer) and ksplit <= 1 - tile = 0 (planned inside) is refused with FORGE_EINVAL.
  *   M = n D H W must be < 2^31.
  */
 int forge_conv_igemm(const float* in1, int C1, int ld1, long long bs1, const float* in2, int C2, int ld2, long long bs2,

@@ -98,7 +98,9 @@ def test_module_surface_names():
     assert list(inspect.signature(m.render.forward).parameters)[:5] == [
         "camera_params", "feature_3d", "density_3d", "render_depth", "return_origin_proj"]
     assert list(inspect.signature(m.rotate.forward).parameters)[:3] == ["voxels", "camPoses_cv2", "grid_size"]     # + optional `order` extension
-    assert list(inspect.signature(m.forward).parameters) == ["sample", "dataset", "device"]
+    # the reference's three arguments first; `features_recon` is this package's optional extension (128^3-voxel scenes: feature volumes the encoder cannot produce)
+    assert list(inspect.signature(m.forward).parameters) == ["sample", "dataset", "device", "features_recon"]
+    assert inspect.signature(m.forward).parameters["features_recon"].default is None
 
 
 def test_reference_import_aliases():

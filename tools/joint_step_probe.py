@@ -41,7 +41,7 @@ def step():
     loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call, {}, dev)
     opt.zero_grad(set_to_none=True)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    train.clip_grad_norm_(model.parameters(), 10.0)
     opt.step()
     return loss
 

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
-from forge_amd import synthetic as syn  # noqa: E402
+from forge_amd import synthetic as syn, train  # noqa: E402
 from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D  # noqa: E402
 
 b = int(os.environ.get("TRAIN_SCENES", "1"))
@@ -47,7 +47,7 @@ def step():
     loss = loss_of(imgs, masks)
     opt.zero_grad(set_to_none=True)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+    train.clip_grad_norm_(model.parameters(), 10.0)
     opt.step()
     return loss
 
@@ -59,7 +59,7 @@ if use_graph:
         imgs, masks = run_model()
         loss = loss_of(imgs, masks)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        train.clip_grad_norm_(model.parameters(), 10.0)
         opt.step()
         return loss.detach()
     step = GraphedStep(graph_fn, opt, warmup=2)

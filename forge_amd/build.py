@@ -73,5 +73,36 @@ def build(force=False, verbose=True):
     return LIB
 
 
+LIB_ASAN = os.path.join(HERE, "libforge_hip_asan.so")
+
+
+def build_sanitized(verbose=False):
+    """libforge_hip_asan.so: the same sources with the HOST side (argument checks, launch-plan code, kernel-argument marshalling of the 51 entry
+    points) under AddressSanitizer + UndefinedBehaviorSanitizer (-fsanitize=address,undefined -fno-gpu-sanitize: device code is compiled as in the
+    product). Test infrastructure (SURVEY.md section 5's sanitizer plan; tests/test_gpu_c_host.py runs the plain-C host program against it)."""
+    deps = _deps()
+    if os.path.exists(LIB_ASAN) and all(os.path.getmtime(p) <= os.path.getmtime(LIB_ASAN) for p in deps):
+        return LIB_ASAN
+    objdir = os.path.join(HERE, "csrc", "_obj_asan")
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+    flags = ["--offload-arch=" + ARCH, "-O1", "-g", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-DNDEBUG", "-fsanitize=address,undefined",
+             "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-shared-libsan"]
+    procs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        procs.append((src, subprocess.Popen([cc] + flags + ["-x", "hip", "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc (sanitized) failed on %s:\n%s" % (src, out))
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-o", LIB_ASAN] + objs
+    if verbose:
+        print("[forge_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_ASAN
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build_sanitized(verbose=True) if "--asan" in sys.argv else build(force="--force" in sys.argv))

@@ -155,6 +155,10 @@ int main(void) {
         EXPECT(tile >= 'A' && tile <= 'E' && ks == 1, "the plan query must name a tile A..E and no split-K without a workspace");
         EXPECT(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL, 1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc,
                                 taps, 1, 1, 0, 0, 0, 4, 8, 8, 0, 0, 'Z', 1, NULL, 0, NULL, (forge_stream_t)st) == FORGE_EINVAL, "an unknown tile letter must be refused");
+        /* output statistics need the caller's explicit plan: tile = 0 with stats != NULL is refused before any launch */
+        EXPECT(forge_conv_igemm(d_x, Cc, Cc, 0, NULL, 0, 0, 0, d_w, d_b, NULL, NULL, 1.0f, NULL, NULL, NULL, d_y, NULL, NULL, 1, 4, 8, 8, 1, 4, 8, 8, Cc, Cc,
+                                taps, 1, 1, 0, 0, 0, 4, 8, 8, 0, 0, 0, 1, NULL, 0, (double*)d_y, (forge_stream_t)st) == FORGE_EINVAL,
+               "stats without an explicit tile must be refused");
     }
     /* ---------------- bilinear x2 of a constant plane and of a column ramp (align_corners = False: interior values are the 0.25 / 0.75 blends) */
     {

@@ -48,8 +48,8 @@ wino = {"wino_input_kernel": ("wino_input_kernel (h -> V_h, 32^3 x 128 channels)
 Vb, Hb, Sb, Cb, Db = 10, 128, 64, 16, 64
 rbwd = {"render_bwd_rays_kernel<4, false>": ("render_bwd_rays_kernel<4, false> (10 views x 128^2 rays x 64 samples of one 64^3 volume: march + per-sample scalars)",
                                               4.0 * (17 * Db ** 3 + Vb * Hb * Hb * (Cb + 1) + 2 * Vb * Hb * Hb * Sb)),
-        "render_bwd_rays_kernel<4, true>": ("render_bwd_rays_kernel<4, true> (the same + camera gradients)",
-                                             4.0 * (17 * Db ** 3 + Vb * Hb * Hb * (Cb + 1) + 2 * Vb * Hb * Hb * Sb)),
+        "render_bwd_rays_kernel<4, true>": ("render_bwd_rays_kernel<4, true> (the same + camera gradients: six position-gradient scalars per sample parked by pass A, read by pass C)",
+                                             4.0 * (17 * Db ** 3 + Vb * Hb * Hb * (Cb + 1) + 2 * Vb * Hb * Hb * Sb + 2 * 6 * Vb * Hb * Hb * Sb)),
         "render_bwd_voxels_kernel": ("render_bwd_voxels_kernel<4> (voxel-parallel gather of 10 views into one 64^3 x 17 gradient volume)",
                                      4.0 * (2 * Vb * Hb * Hb * Sb + Vb * Hb * Hb * Cb + 17 * Db ** 3))}
 jobs = ([(sub, label, alg[sub], F, W, S) for sub, label in names.items()] + [(sub, lab, ab, WF, WW, WS) for sub, (lab, ab) in wino.items()]

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Every matrix-core launch of ONE GT-pose training step (TRAIN_SCENES scenes, default 4) with HIP events around it: entry point, shape
+"""Every matrix-core launch of ONE GT-pose training step (TRAIN_SCENES scenes, default 4; TRAIN_MODE=joint: the joint 2D3D fine-tune step of
+BASELINE configs[4], 1 scene) with HIP events around it: entry point, shape
 (rows, Cout, Cin, taps / kd), ms, TFLOP/s of the FLOPs it executes - grouped by shape, sorted by time. Shows which GEMM shapes sit
 furthest below the 157.3 TF pipe."""
 import collections
@@ -24,7 +25,29 @@ sample = {k: v.to(dev) for k, v in syn.make_sample(b, 5, 256, 1.5, seed=3).items
 ds = syn.SyntheticDataset(1.5)
 
 
+mode = os.environ.get("TRAIN_MODE", "gt_pose")
+if mode == "joint":
+    from forge_amd import train
+    from forge_amd.model import FORGE
+    b = 1
+    cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+    cfg.loss.regu_origin_proj = 1.0
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).train()
+    opt = torch.optim.Adam([p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render)
+                            for p in m.parameters()], lr=1e-4, fused=True)
+    sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
+
+
 def step():
+    if mode == "joint":
+        loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, model, {}, dev)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        train.clip_grad_norm_(model.parameters(), 10.0)
+        opt.step()
+        return
     imgs, masks = model(sample, ds, dev)
     mi = grouped_mse(imgs.reshape(b, 10, 3, 256, 256), sample["images"], 5)
     mm = grouped_mse(masks.reshape(b, 10, 1, 256, 256), sample["fg_probabilities"], 5)

@@ -1144,7 +1144,7 @@ def ray_sharded_joint_record(rank, world, dev, steps, grid=32):
     torch.manual_seed(1234)                                            # every rank draws the same Dropout masks: the replicas must predict the same poses
     model = FORGE(cfg)
     model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
-    model = model.to(dev).train()
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.to(dev).train())                                        # kubric_train_joint.py:136 (HIP SyncBatchNorm: one all-reduce per layer and direction)
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)         # kubric_train_joint.py:141
     params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render) for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)

@@ -392,8 +392,32 @@ def train_joint_goldens(m):
     npz("train_joint", **out)
 
 
+def geo_goldens(m):
+    """utils/geo_utils.py of the REFERENCE on seeded inputs: the four pose parameterisations -> SE(3) (`PoseEstimator3D.toSE3` dispatches on
+    config.network.rot_representation, models/pose_estimator_3d.py:104-113; the shipped configs use 'quat'), mat2quat incl. all four branches of the
+    torchgeometry algorithm, get_relative_pose and canonicalize_poses. Pins forge_amd/geo_utils.py (CPU test, no GPU involved)."""
+    gu = m["utils.geo_utils"]
+    g = torch.Generator().manual_seed(4242)
+    out = {}
+    x7, x6, x9, x12 = (torch.randn(16, n, generator=g) for n in (7, 6, 9, 12))
+    out.update(quat_in=x7, quat_out=gu.quat2mat(x7), euler_in=x6, euler_out=gu.euler2mat(x6), rot6d_in=x9, rot6d_out=gu.rot6d2mat(x9),
+               rot9d_in=x12, rot9d_out=gu.rot9d2mat(x12))
+    # rotations that reach every branch of mat2quat_transform: trace-dominant, and each diagonal element dominant in turn
+    qs = torch.tensor([[1.0, 0.05, 0.02, -0.03], [0.05, 1.0, 0.02, 0.03], [0.03, -0.02, 1.0, 0.05], [0.02, 0.03, -0.05, 1.0], [0.5, 0.5, 0.5, 0.5],
+                       [0.1, -0.7, 0.7, 0.1], [0.0, 0.0, 1.0, 0.0], [0.3, 0.2, -0.9, 0.1]])
+    P = gu.quat2mat(torch.cat([qs, torch.randn(8, 3, generator=g)], dim=1))
+    out.update(mat_in=P, mat2quat_out=gu.mat2quat(P))
+    A, Bm = gu.quat2mat(torch.randn(5, 7, generator=g)), gu.quat2mat(torch.randn(5, 7, generator=g))
+    out.update(rel_a=A, rel_b=Bm, rel_out=gu.get_relative_pose(A, Bm), rel_out_single=gu.get_relative_pose(A[0], Bm),
+               canon_out=gu.canonicalize_poses(A[0], Bm))
+    for k in ("quat_out", "euler_out", "rot6d_out", "rot9d_out"):
+        R = out[k][:, :3, :3]
+        assert (R @ R.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-5 and (torch.det(R) - 1).abs().max() < 1e-5, k
+    npz("geo_utils", **out)
+
+
 if __name__ == "__main__":
-    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens}
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens}
     if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
         single[sys.argv[1]](ref_import.import_reference())
@@ -403,3 +427,4 @@ if __name__ == "__main__":
         train_goldens(ref_import.import_reference())
         joint_goldens(ref_import.import_reference())
         train_joint_goldens(ref_import.import_reference())
+        geo_goldens(ref_import.import_reference())

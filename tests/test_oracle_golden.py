@@ -282,3 +282,23 @@ def test_joint_training_fixture_is_consistent_with_the_forward_fixture(golden):
         arr = g["grad__" + k] if "grad__" + k in g.files else g["gsub__" + k]
         assert np.isfinite(arr).all() and np.abs(arr).max() > 0, k
         assert np.abs(arr).max() <= float(g["gmax__" + k]) * (1 + 1e-6) and np.linalg.norm(arr.astype(np.float64)) <= float(g["gnorm__" + k]) * (1 + 1e-6), k
+
+
+def test_geo_utils_match_the_reference_functions(golden):
+    """forge_amd/geo_utils.py against utils/geo_utils.py of the REFERENCE on seeded inputs (tests/golden/geo_utils.npz, oracle/make_golden.py::
+    geo_goldens): all four pose parameterisations of `toSE3` (quat - the shipped configs -, euler, 6D, 9D: config.network.rot_representation),
+    mat2quat through every branch of the torchgeometry algorithm, relative / canonicalised poses, and the closed-form affine inverse that
+    replaces torch.inverse in the predicted-camera chain."""
+    from forge_amd import geo_utils as gu
+    g = golden("geo_utils")
+    close = lambda a, b, tol=2e-6: (a - T(b)).abs().max().item() < tol
+    assert close(gu.quat2mat(T(g["quat_in"])), g["quat_out"])
+    assert close(gu.euler2mat(T(g["euler_in"])), g["euler_out"])
+    assert close(gu.rot6d2mat(T(g["rot6d_in"])), g["rot6d_out"])
+    assert close(gu.rot9d2mat(T(g["rot9d_in"])), g["rot9d_out"], 1e-5)          # SVD: sign / order conventions are fixed by the determinant correction
+    assert close(gu.mat2quat(T(g["mat_in"])), g["mat2quat_out"])
+    assert close(gu.get_relative_pose(T(g["rel_a"]), T(g["rel_b"])), g["rel_out"], 1e-5)
+    assert close(gu.get_relative_pose(T(g["rel_a"])[0], T(g["rel_b"])), g["rel_out_single"], 1e-5)
+    assert close(gu.canonicalize_poses(T(g["rel_a"])[0], T(g["rel_b"])), g["canon_out"], 1e-5)
+    P = T(g["rel_a"])
+    assert (gu.inverse_affine(P) - torch.inverse(P)).abs().max().item() < 1e-5

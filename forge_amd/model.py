@@ -83,13 +83,36 @@ class FORGE(nn.Module):
             cache[key] = torch.arange(b, device=device, dtype=torch.int32)[:, None].expand(b, V).reshape(b * V).contiguous()
         return cache[key]
 
-    def predict_poses(self, features_raw, clips, sample, dataset, device):
+    # The 2-D pose estimator needs only the images: on the MI355X it is launched on a side HIP stream BEFORE the encoder, so that its ~60 small ResNet
+    # launches (5 images: 320-1280 workgroups each) share the chip with the encoder trunk's equally under-filled ones - forward, and backward too
+    # (autograd replays each node on its forward stream). False = one stream.
+    pose2d_side_stream = True
+
+    def _pose2d_features(self, clips):
+        """encoder_traj_2d(clips, return_features=True), launched on the side stream when enabled; returns (features, join) - call join() on the
+        consumer's stream before the features are used."""
+        if not (self.pose2d_side_stream and clips.is_cuda):
+            return self.encoder_traj_2d(clips, return_features=True), (lambda: None)
+        cur = torch.cuda.current_stream(clips.device)
+        side = self.__dict__.setdefault("_side_streams", {}).setdefault(str(clips.device), None) or torch.cuda.Stream(device=clips.device)
+        self.__dict__["_side_streams"][str(clips.device)] = side
+        side.wait_stream(cur)                                           # the images (and the parameters' last update) are complete
+        with torch.cuda.stream(side):
+            feat = self.encoder_traj_2d(clips, return_features=True)
+
+        def join():
+            cur.wait_stream(side)
+            feat.record_stream(cur)                                     # allocated on the side stream, consumed (and later freed) on this one
+        return feat, join
+
+    def predict_poses(self, features_raw, clips, sample, dataset, device, pose_feat_2d=None):
         """models/model.py:60-84 - relative poses of views 1..t-1 from the 3-D pose estimator (on the per-view feature volumes) and the 2-D pose
         estimator (on the images), joined by the pose head; quaternion normalised, toSE3, chained onto the canonical camera.
         Returns (camPoses_cv2 [b,t,4,4], camE_cv2 [b,t,4,4], {'gt', 'pred', 'conf'})."""
         b, t = features_raw.shape[:2]
-        pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True),            # [b(t-1),1024] each
-                               self.encoder_traj_2d(clips, return_features=True)], dim=-1)
+        if pose_feat_2d is None:
+            pose_feat_2d = self.encoder_traj_2d(clips, return_features=True)
+        pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True), pose_feat_2d], dim=-1)      # [b(t-1),1024] each
         pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
         pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(pose_vec, self.encoder_traj.toSE3, *geo_utils.canonical_cameras(self, dataset, device), b, t)
         gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
@@ -105,12 +128,14 @@ class FORGE(nn.Module):
         b, t_all = sample["images"].shape[:2]
         clips = sample["images"][:, :self.N_INPUT]
         b, t, c, h, w = clips.shape
+        f2d, join2d = (None, None) if self.config.train.use_gt_pose else self._pose2d_features(clips)
         features_raw = self.encoder_3d.get_feat3D(clips.reshape(b * t, c, h, w))
         _, C, D, H, W = features_raw.shape
         features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
-            camPoses_cv2, camE_cv2, camPose_return = self.predict_poses(features_raw, clips, sample, dataset, device)
+            join2d()
+            camPoses_cv2, camE_cv2, camPose_return = self.predict_poses(features_raw, clips, sample, dataset, device, pose_feat_2d=f2d)
         else:
             suffix = "_canonicalized" if self.config.train.canonicalize else ""
             camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t]

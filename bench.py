@@ -973,11 +973,12 @@ def joint_configs(dev, steps=5):
     except Exception as e:
         return [{"name": "joint_step", "error": repr(e)[:300]}]
 
-    def make_step(feats):
+    def make_step(feats, smp=None):
         call = model if feats is None else (lambda s, d, dv: model(s, d, dv, features_recon=feats))
+        smp = sample if smp is None else smp
 
         def step():
-            loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, call, {}, dev)
+            loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, smp, ds, call, {}, dev)
             opt.zero_grad(set_to_none=True)
             loss.backward()
             train.clip_grad_norm_(model.parameters(), 10.0)
@@ -1066,6 +1067,25 @@ def joint_configs(dev, steps=5):
         except Exception as e:
             out.append({"name": name, "workload": workload, "error": repr(e)[:300]})
         torch.cuda.empty_cache()
+    # the reference's joint configuration trains 4 scenes per GPU (config/kubric/joint_pose_2d3d.yaml: batch_size 4): the GPU-bound regime of the same step
+    try:
+        s4 = {k: v.to(dev) for k, v in syn.make_sample(4, 10, 256, 1.5, seed=13).items()}
+        step4 = make_step(None, s4)
+        step4()
+        torch.cuda.synchronize()
+        with FlopMeter() as fm4:
+            step4()
+        torch.cuda.synchronize()
+        ms4 = _timed(step4, max(2, steps // 2), warm=1)
+        out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> 40 rendered views per step); eager launch",
+                    "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3,
+                    "roofline": dict(floor_of(fm4.gflop, ms4), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm4.gflop / ms4, launches=fm4.launches)})
+        del s4
+    except Exception as e:
+        out.append({"name": "joint_step_4_scenes", "error": repr(e)[:300]})
+    for p_ in model.parameters():
+        p_.grad = None
+    torch.cuda.empty_cache()
     return out
 
 

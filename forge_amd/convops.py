@@ -159,7 +159,7 @@ class _ZeroArena:
     as long as anything (a parameter's .grad) references them; the next pass gets a fresh arena."""
 
     def __init__(self):
-        self.buf, self.off, self.used, self.want, self.task, self.device = None, 0, 0, 0, -1, None
+        self.buf, self.off, self.used, self.want, self.task, self.device, self.stream = None, 0, 0, 0, -1, None, None
 
     def _end(self):
         self.want = self.used
@@ -187,8 +187,12 @@ class _ZeroArena:
             self.task, self.device, self.off, self.used = task, device, 0, 0
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of(task))
             self.buf = torch.zeros(self.want // 4 + 64, dtype=torch.float32, device=device) if self.want else None
+            self.stream = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None     # the stream the fill was queued on
         self.used += nbytes
-        if self.buf is None or device != self.device or self.off + nbytes > self.buf.numel() * 4:
+        # a request from ANOTHER stream (a branch of the model that ran on a side stream, e.g. FORGE's 2-D pose estimator: autograd replays its nodes
+        # there) must not accumulate into the arena - nothing orders it behind the fill - and gets its own zero-fill on its own stream
+        foreign = self.stream is not None and torch.cuda.current_stream(device) != self.stream
+        if self.buf is None or device != self.device or foreign or self.off + nbytes > self.buf.numel() * 4:
             return torch.zeros(shape, dtype=torch.float32, device=device)
         out = self.buf[self.off // 4:self.off // 4 + n].view(shape)
         self.off += nbytes

@@ -392,6 +392,85 @@ def train_joint_goldens(m):
     npz("train_joint", **out)
 
 
+STAGE_KEYS = {
+    # joint_pose_3d.yaml (kubric_train_pose_3D.py:95-96): FORGE_poseEstimator3D with PREDICTED poses, compute_all_loss over its 2t rendered views + pose terms
+    "pose3d_joint": ["encoder_traj.conv3d_1.0.weight", "encoder_traj.pose_head_1.1.weight", "encoder_traj.out.0.weight", "encoder_traj.out.3.weight", "encoder_traj.out.3.bias",
+                     "encoder_3d.feature_extraction.7.2.bn3.weight", "encoder_3d.conv1.1.weight", "encoder_3d.fusion_feature.cells.0.conv_gate.bias",
+                     "encoder_3d.fusion_feature.cells.0.out_gate.weight", "encoder_3d.fusion_feature.fusion_norm.weight", "encoder_3d.features_head.3.bias",
+                     "encoder_3d.density_head.6.weight", "render.conv_rgb.3.weight", "render.conv_rgb.6.bias"],
+    # pred_pose_3d.yaml (kubric_train_pose_3D.py:89-90): the same model in parameter = 'pose' mode, compute_pose_loss (pose + translation MSE only)
+    "pose3d_pose": ["encoder_traj.conv3d_1.0.weight", "encoder_traj.conv3d_3.3.weight", "encoder_traj.pose_head_1.1.weight", "encoder_traj.out.0.weight", "encoder_traj.out.3.weight",
+                    "encoder_3d.feature_extraction.0.weight", "encoder_3d.feature_extraction.7.2.bn3.weight", "encoder_3d.conv1.0.weight", "encoder_3d.conv1.1.weight"],
+    # pred_pose_2d3d.yaml / pretrain_pose_2d3d.yaml (kubric_train_joint.py:89-110): FORGE in parameter = 'pose' mode, compute_pose_loss
+    "joint_pose": ["pose_head.1.weight", "pose_head.4.weight", "pose_head.4.bias", "encoder_traj.pose_head_1.3.weight", "encoder_traj.conv3d_2.3.weight",
+                   "encoder_traj_2d.conv.9.weight", "encoder_traj_2d.conv.10.weight", "encoder_traj_2d.backbone.layer4.0.0.conv2.weight",
+                   "encoder_traj_2d.self_attn_blks.2.mlp.mlp.1.weight", "encoder_3d.conv1.1.weight", "encoder_3d.feature_extraction.7.2.bn3.weight"],
+}
+
+
+def stage_goldens(m):
+    """The REMAINING training stages of the reference (the GT-pose stage is train_pose3d.npz, the joint 2D3D stage train_joint.npz), each = the reference's own
+    loss function on its own model class + backward, in fp32 and in float64 (BatchNorm on running statistics, Dropout off; seeded sample / weights):
+      pose3d_joint   scripts/kubric_compute_loss.py:71-118 compute_all_loss   on FORGE_poseEstimator3D(use_gt_pose=False, parameter='joint')   joint_pose_3d.yaml
+      pose3d_pose    scripts/kubric_compute_loss.py:45-68  compute_pose_loss  on FORGE_poseEstimator3D(use_gt_pose=False, parameter='pose')    pred_pose_3d.yaml
+      joint_pose     compute_pose_loss on FORGE(use_gt_pose=False, parameter='pose')                                       pred_pose_2d3d.yaml / pretrain_pose_2d3d.yaml
+    One fixture, keys prefixed by the stage: loss terms, gradients (large ones as a strided sample + norm) and the float64 yardstick of each."""
+    import importlib
+    from easydict import EasyDict
+    kcl = importlib.import_module("scripts.kubric_compute_loss")
+    ds = syn.SyntheticDataset(1.5)
+    out = {"sample_seed": 12, "recon_rgb": 5.0, "recon_mask": 1.0, "regu_origin_proj": 1.0, "pose3d_weight_seed": 3, "joint_weight_seed": 0}
+    full = syn.make_sample(1, 10, 256, 1.5, seed=12)
+    s5 = {k: v[:, :5].clone() for k, v in full.items()}
+    stages = (("pose3d_joint", "models.model_single_pose_estimator", "FORGE_poseEstimator3D", "joint", kcl.compute_all_loss, s5, 3),
+              ("pose3d_pose", "models.model_single_pose_estimator", "FORGE_poseEstimator3D", "pose", kcl.compute_pose_loss, s5, 3),
+              ("joint_pose", "models.model", "FORGE", "pose", kcl.compute_pose_loss, full, 0))
+    for stage, mod, cls, parameter, loss_fn, sample, wseed in stages:
+        cfg = ref_import.kubric_config(use_gt_pose=False, parameter=parameter)
+        cfg.loss = EasyDict({"recon_rgb": 5.0, "recon_mask": 1.0, "perceptual_img": 0.0, "regu_origin_proj": 1.0})
+        res = []
+        for double in (False, True):
+            model = getattr(m[mod], cls)(cfg)
+            model.load_state_dict(syn.seeded_state_dict(model.state_dict(), wseed))
+            model.train()
+            for sub in model.modules():
+                if isinstance(sub, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Dropout)):
+                    sub.eval()
+            smp, dset = {k: v.clone() for k, v in sample.items()}, ds
+            if double:
+                model, smp = to_float64(model, smp)
+                dset = _Dataset64(ds)
+                torch.set_default_dtype(torch.float64)
+            try:
+                loss, terms, _, _ = loss_fn(cfg, 0, smp, dset, model, {}, "cpu", None)
+                loss.backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
+            res.append((float(loss), dict(terms), dict(model.named_parameters())))
+        (l32, t32, n32), (l64, t64, n64) = res
+        out[stage + "__loss"], out[stage + "__loss64"] = l32, l64
+        for k, v in t32.items():
+            out["%s__term__%s" % (stage, k)] = float(v)
+            out["%s__term64__%s" % (stage, k)] = float(t64[k])
+        print("  %s (reference): loss %.6f (float64 %.9f) terms %s" % (stage, l32, l64, {k: round(v, 6) for k, v in t32.items()}))
+        for k in STAGE_KEYS[stage]:
+            g, g64 = n32[k].grad, n64[k].grad
+            assert g is not None, (stage, k)
+            flat, flat64 = g.flatten(), g64.flatten()
+            pre = "%s__" % stage
+            out[pre + "gnorm__" + k], out[pre + "gmax__" + k] = float(flat.double().norm()), float(flat.abs().max())
+            out[pre + "g64err__" + k], out[pre + "g64cos__" + k] = yardstick(g, g64)
+            if flat.numel() > JOINT_SUB_LIMIT:
+                st = grad_sample_stride(flat.numel())
+                out[pre + "gstride__" + k] = st
+                out[pre + "gsub__" + k], out[pre + "gsub64__" + k] = flat[::st], flat64[::st].float()
+                out[pre + "g64suberr__" + k], out[pre + "g64subcos__" + k] = yardstick(flat[::st], flat64[::st])
+            else:
+                out[pre + "grad__" + k], out[pre + "grad64__" + k] = g, g64.float()
+            print("    %-13s %-62s |g|max %.3e  fp32 vs float64: err/max %.2e 1-cos %.2e" % (stage, k[-62:], out[pre + "gmax__" + k], out[pre + "g64err__" + k], out[pre + "g64cos__" + k]))
+    npz("train_stages", **out)
+
+
 def geo_goldens(m):
     """utils/geo_utils.py of the REFERENCE on seeded inputs: the four pose parameterisations -> SE(3) (`PoseEstimator3D.toSE3` dispatches on
     config.network.rot_representation, models/pose_estimator_3d.py:104-113; the shipped configs use 'quat'), mat2quat incl. all four branches of the
@@ -417,7 +496,7 @@ def geo_goldens(m):
 
 
 if __name__ == "__main__":
-    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens}
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens, "stages": stage_goldens}
     if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
         single[sys.argv[1]](ref_import.import_reference())
@@ -428,3 +507,4 @@ if __name__ == "__main__":
         joint_goldens(ref_import.import_reference())
         train_joint_goldens(ref_import.import_reference())
         geo_goldens(ref_import.import_reference())
+        stage_goldens(ref_import.import_reference())

@@ -302,3 +302,17 @@ def test_geo_utils_match_the_reference_functions(golden):
     assert close(gu.canonicalize_poses(T(g["rel_a"])[0], T(g["rel_b"])), g["canon_out"], 1e-5)
     P = T(g["rel_a"])
     assert (gu.inverse_affine(P) - torch.inverse(P)).abs().max().item() < 1e-5
+
+
+def test_training_stage_fixture_is_consistent(golden):
+    """tests/golden/train_stages.npz (the reference's compute_all_loss / compute_pose_loss stages): per stage, total = sum of its terms in fp32 and in float64, the
+    two pose-only stages of one model family report the pose terms the rendering stage reports too (same weights, same sample), and the joint model's pose terms equal
+    those of train_joint.npz (same weights, same sample, eval-mode estimators)."""
+    g, j = golden("train_stages"), golden("train_joint")
+    for stage in ("pose3d_joint", "pose3d_pose", "joint_pose"):
+        for tag, tot in (("term__", "loss"), ("term64__", "loss64")):
+            terms = [float(g[k]) for k in g.files if k.startswith("%s__%s" % (stage, tag))]
+            assert terms and abs(sum(terms) - float(g["%s__%s" % (stage, tot)])) < 1e-5 * float(g["%s__%s" % (stage, tot)]), (stage, tag)
+    for k in ("pose", "trans"):
+        assert abs(float(g["pose3d_joint__term__" + k]) - float(g["pose3d_pose__term__" + k])) < 1e-6
+        assert abs(float(g["joint_pose__term__" + k]) - float(j["term__" + k])) < 1e-6

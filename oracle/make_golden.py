@@ -471,6 +471,55 @@ def stage_goldens(m):
     npz("train_stages", **out)
 
 
+def refine_goldens(m):
+    """f2: the REFERENCE's pose-refinement loop itself - kubric_eval.py:412-530 `do_refinement` (iter_num = 2: three Adam steps, lr 1e-3 / 5e-4) on the reference
+    FORGE model (eval, seeded weights), the encoder's feature volumes of a seeded 5-view scene, initial poses = GT + a perturbation, targets = the input views.
+    The optimiser's step is wrapped for the duration of the call to record what the reference hands it: the gradients of the refinement loss w.r.t. the rotation
+    (quaternion) and translation parameters at every iteration, and the parameters after the last step. Also kept: the camera poses of the last iteration
+    (the function's 4th return value) and its first return value (the optimised pose vectors, quaternion NOT re-normalised: the leaves alias the tensor that is written
+    back). fp32 only (the loop builds its cameras with fp32 literals)."""
+    import types
+    ke = ref_import.import_reference_eval()
+    cfg = ref_import.kubric_config(use_gt_pose=False, parameter="joint")
+    ke.config.dataset.img_size = 256
+    ke.config.loss.recon_rgb, ke.config.loss.recon_mask, ke.config.loss.regu_origin_proj = 5.0, 1.0, 0.0
+    model = m["models.model"].FORGE(cfg).eval()
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    ds = syn.SyntheticDataset(1.5)
+    sample = {k: v[:, :5].contiguous() for k, v in syn.make_sample(1, 10, 256, 1.5, seed=21).items()}
+    clips, masks = sample["images"], sample["fg_probabilities"]
+    with torch.no_grad():
+        feats = model.encoder_3d.get_feat3D(clips[0]).reshape(1, 5, 128, 32, 32, 32)
+    gt_rel = sample["cam_poses_rel_cv2"]                                                     # [1,5,4,4]
+    g = torch.Generator().manual_seed(99)
+    init = m["utils.geo_utils"].mat2quat(gt_rel[0, 1:5]).clone()
+    init[:, :4] += 0.03 * torch.randn(4, 4, generator=g)
+    init[:, 4:] += 0.02 * torch.randn(4, 3, generator=g)
+    rec = {"grads": [], "params": None}
+    orig_step = torch.optim.Adam.step
+
+    def spy_step(self, *a, **kw):
+        rec["grads"].append([p.grad.detach().clone() for grp in self.param_groups for p in grp["params"]])
+        r = orig_step(self, *a, **kw)
+        rec["params"] = [p.detach().clone() for grp in self.param_groups for p in grp["params"]]
+        return r
+    torch.optim.Adam.step = spy_step
+    try:
+        ret, rot_err, trans_err, cam_poses = ke.do_refinement(0, types.SimpleNamespace(module=model), sample, ds, init.clone(), feats, gt_rel, clips, masks, "cpu", 0,
+                                                              chosen_idx=[0, 1, 2, 3, 4], iter_num=2)
+    finally:
+        torch.optim.Adam.step = orig_step
+    assert len(rec["grads"]) == 3
+    out = {"sample_seed": 21, "weight_seed": 0, "init": init, "returned_poses": ret, "cam_poses_last_iteration": cam_poses.detach(), "rot_error": float(rot_err),
+           "trans_error": float(trans_err), "rot_after": rec["params"][0], "trans_after": rec["params"][1], "recon_rgb": 5.0, "recon_mask": 1.0}
+    for i, (gr, gt_) in enumerate(rec["grads"]):
+        out["grad_rot_%d" % i], out["grad_trans_%d" % i] = gr, gt_
+        print("  refinement (reference) iteration %d: |d rot|max %.3e |d trans|max %.3e" % (i, gr.abs().max().item(), gt_.abs().max().item()))
+    assert torch.equal(ret[:, :4], rec["params"][0]) and torch.equal(ret[:, 4:], rec["params"][1])      # the returned vector IS the optimised parameters
+    print("  refinement: rot error after 3 steps %.3f deg, trans error %.4f" % (rot_err, trans_err))
+    npz("refine_steps", **out)
+
+
 def geo_goldens(m):
     """utils/geo_utils.py of the REFERENCE on seeded inputs: the four pose parameterisations -> SE(3) (`PoseEstimator3D.toSE3` dispatches on
     config.network.rot_representation, models/pose_estimator_3d.py:104-113; the shipped configs use 'quat'), mat2quat incl. all four branches of the
@@ -496,7 +545,7 @@ def geo_goldens(m):
 
 
 if __name__ == "__main__":
-    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens, "stages": stage_goldens}
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens, "stages": stage_goldens, "refine": refine_goldens}
     if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
         single[sys.argv[1]](ref_import.import_reference())
@@ -508,3 +557,4 @@ if __name__ == "__main__":
         train_joint_goldens(ref_import.import_reference())
         geo_goldens(ref_import.import_reference())
         stage_goldens(ref_import.import_reference())
+        refine_goldens(ref_import.import_reference())

@@ -55,3 +55,49 @@ def kubric_config(img_size=256, volume_size=1.0, n_pts_per_ray=64, min_depth=0.5
                    "max_depth": max_depth, "camera_z": 1.5, "k_size": 5},
         "train": {"use_gt_pose": use_gt_pose, "canonicalize": True, "parameter": parameter},
     })
+
+
+def import_reference_eval():
+    """kubric_eval.py of the reference (do_refinement, kubric_eval.py:412-530) importable in this container: its plotting / metric / dataset imports
+    (skimage, cv2, imageio, lpips; dataset.kubric / dataset.gso pull torchvision.transforms.functional) are not installed and not needed by the
+    refinement loop - they are replaced by inert stand-in modules for the duration of the import. Returns the module."""
+    import importlib.abc
+    import importlib.machinery
+    import types
+    import_reference()
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            s_ = _Stub(self.__name__ + "." + k)
+            setattr(self, k, s_)
+            return s_
+
+        def __call__(self, *a, **kw):
+            return _Stub("call")
+
+    class _AutoStub(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in ("skimage", "lpips", "cv2", "imageio", "matplotlib"):
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            mod = _Stub(spec.name)
+            mod.__path__ = []
+            return mod
+
+        def exec_module(self, module):
+            pass
+    finder = _AutoStub()
+    sys.meta_path.append(finder)
+    for name, cls in (("dataset.kubric", "Kubric"), ("dataset.gso", "GSO")):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            setattr(mod, cls, type(cls, (), {}))
+            sys.modules[name] = mod
+    try:
+        return importlib.import_module("kubric_eval")
+    finally:
+        sys.meta_path.remove(finder)

@@ -316,3 +316,18 @@ def test_training_stage_fixture_is_consistent(golden):
     for k in ("pose", "trans"):
         assert abs(float(g["pose3d_joint__term__" + k]) - float(g["pose3d_pose__term__" + k])) < 1e-6
         assert abs(float(g["joint_pose__term__" + k]) - float(j["term__" + k])) < 1e-6
+
+
+def test_refinement_fixture_is_the_reference_optimiser_trace(golden):
+    """tests/golden/refine_steps.npz (kubric_eval.py:412-530 `do_refinement`, three Adam steps; oracle/make_golden.py::refine_goldens): replaying torch's Adam
+    (lr 1e-3 on the quaternions, 5e-4 on the translations, kubric_eval.py:440-449) on the recorded gradients from the recorded initial poses reproduces the recorded
+    parameters bit for bit, and the function's returned pose vectors are those parameters (quaternions not re-normalised)."""
+    g = golden("refine_steps")
+    rot, tr = T(g["init"])[:, :4].clone().requires_grad_(True), T(g["init"])[:, 4:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": rot, "lr": 1e-3}, {"params": tr, "lr": 5e-4}], lr=1e-3)
+    for i in range(3):
+        rot.grad, tr.grad = T(g["grad_rot_%d" % i]).clone(), T(g["grad_trans_%d" % i]).clone()
+        opt.step()
+    assert torch.equal(rot.detach(), T(g["rot_after"])) and torch.equal(tr.detach(), T(g["trans_after"]))
+    assert torch.equal(T(g["returned_poses"]), torch.cat([T(g["rot_after"]), T(g["trans_after"])], dim=1))
+    assert T(g["cam_poses_last_iteration"]).shape == (1, 5, 4, 4)

@@ -520,6 +520,37 @@ def refine_goldens(m):
     npz("refine_steps", **out)
 
 
+def nvs_goldens(m):
+    """f3: the REFERENCE's own 360-degree novel-view synthesis - kubric_eval.py:166-232 `visualize_360` (28 cameras from look_at_view_transform handed to render() as if
+    they were OpenCV extrinsics, densities clamped to <= 1, depth channel on) on the reference FORGE model (eval, seeded weights) from the encoder's feature volumes of a
+    seeded 5-view scene and its GT relative poses. `vis_utils.vis_NVS` (the function's only sink: it writes image files) is replaced for the call by a recorder of the
+    tensors it is handed. Stored sub-sampled (every 8th pixel) + per-view means."""
+    import types
+    ke = ref_import.import_reference_eval()
+    cfg = ref_import.kubric_config(use_gt_pose=False, parameter="joint")
+    ke.config.render.camera_z = 1.5
+    model = m["models.model"].FORGE(cfg).eval()
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    ds = syn.SyntheticDataset(1.5)
+    sample = {k: v[:, :5].contiguous() for k, v in syn.make_sample(1, 10, 256, 1.5, seed=21).items()}
+    with torch.no_grad():
+        feats = model.encoder_3d.get_feat3D(sample["images"][0]).reshape(1, 5, 128, 32, 32, 32)
+    poses = m["utils.geo_utils"].mat2quat(sample["cam_poses_rel_cv2"][0, 1:5])
+    got = {}
+    orig = ke.vis_utils.vis_NVS
+    ke.vis_utils.vis_NVS = lambda imgs, masks, img_name, output_dir, subfolder, depths=None: got.update(imgs=imgs, masks=masks, depths=depths)
+    try:
+        with torch.no_grad():
+            ke.visualize_360(types.SimpleNamespace(module=model), sample, ds, poses, feats, 0, "golden", "/tmp", "cpu")
+    finally:
+        ke.vis_utils.vis_NVS = orig
+    imgs, masks, depths = got["imgs"], got["masks"], got["depths"]
+    assert imgs.shape == (28, 3, 256, 256) and masks.shape == (28, 1, 256, 256) and depths.shape == (28, 1, 256, 256)
+    print("  360 NVS (reference): mask mean %.4f, image max %.3f, depth max %.3f" % (masks.mean().item(), imgs.max().item(), depths.max().item()))
+    npz("nvs_360", sample_seed=21, weight_seed=0, camera_z=1.5, poses=poses, imgs_sub=imgs[:, :, ::8, ::8], masks_sub=masks[:, :, ::8, ::8], depths_sub=depths[:, :, ::8, ::8],
+        imgs_mean=imgs.mean(dim=(1, 2, 3)), masks_mean=masks.mean(dim=(1, 2, 3)), depths_mean=depths.mean(dim=(1, 2, 3)))
+
+
 def geo_goldens(m):
     """utils/geo_utils.py of the REFERENCE on seeded inputs: the four pose parameterisations -> SE(3) (`PoseEstimator3D.toSE3` dispatches on
     config.network.rot_representation, models/pose_estimator_3d.py:104-113; the shipped configs use 'quat'), mat2quat incl. all four branches of the
@@ -545,7 +576,7 @@ def geo_goldens(m):
 
 
 if __name__ == "__main__":
-    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens, "stages": stage_goldens, "refine": refine_goldens}
+    single = {"loss": loss_goldens, "train": train_goldens, "joint": joint_goldens, "train_joint": train_joint_goldens, "geo": geo_goldens, "stages": stage_goldens, "refine": refine_goldens, "nvs": nvs_goldens}
     if len(sys.argv) > 1 and sys.argv[1] in single:   # only that fixture (the others are unchanged)
         os.makedirs(OUT, exist_ok=True)
         single[sys.argv[1]](ref_import.import_reference())
@@ -558,3 +589,4 @@ if __name__ == "__main__":
         geo_goldens(ref_import.import_reference())
         stage_goldens(ref_import.import_reference())
         refine_goldens(ref_import.import_reference())
+        nvs_goldens(ref_import.import_reference())

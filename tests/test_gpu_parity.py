@@ -1039,6 +1039,36 @@ def test_render_360_vs_oracle(dev):
         assert (depths[s].cpu() - ref[2]).abs().max().item() < 2e-5
 
 
+def test_render_360_vs_the_reference_visualize_360(dev, golden):
+    """Row f3 against the REFERENCE's own 360-degree NVS: tests/golden/nvs_360.npz = kubric_eval.py:166-232 `visualize_360` on the reference FORGE model
+    (oracle/make_golden.py::nvs_goldens; the function's image-writing sink replaced by a recorder) - camera chain from the GT relative poses, rotate, view ordering,
+    ConvGRU fusion, both heads, 28 look_at_view_transform cameras used as if they were OpenCV extrinsics, densities clamped to <= 1, depth channel. Here: the same
+    stages on the MI355X, the 28 views as ONE ray-marcher launch (forge_amd.nvs.render_360). Tolerances as the full-forward tests against the reference's output:
+    max-abs 4e-4 of the image scale, PSNR > 90 dB, masks / depths 2e-4."""
+    from forge_amd import geo_utils, nvs
+    from forge_amd.model import FORGE
+    g = golden("nvs_360")
+    cfg = syn.kubric_config(use_gt_pose=False, parameter="joint")
+    model = FORGE(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), int(g["weight_seed"])))
+    model = model.to(dev).eval()
+    ds = syn.SyntheticDataset(1.5)
+    sample = {k: v[:, :5].contiguous().to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=int(g["sample_seed"])).items()}
+    with torch.no_grad():
+        feats = model.encoder_3d.get_feat3D(sample["images"][0]).reshape(1, 5, 128, 32, 32, 32)
+        _, poses, _ = geo_utils.predicted_camera_chain(T(g["poses"]).to(dev), model.encoder_traj.toSE3, ds.get_canonical_pose_cv2(device=dev),
+                                                       ds.get_canonical_extrinsics_cv2(device=dev), 1, 5)
+        fused = model.encoder_3d.fuse(model.rotate(voxels=feats, camPoses_cv2=poses, grid_size=32, order="distance"))
+        feat_mv, dens_mv = model.encoder_3d.heads(fused)
+        imgs, masks, depths = nvs.render_360(model, feat_mv, dens_mv, sample["K_cv2"][0, 0], float(g["camera_z"]), n_views=28, render_depth=True)
+    imgs, masks, depths = imgs[0].cpu(), masks[0].cpu(), depths[0].cpu()
+    assert imgs.shape == (28, 3, 256, 256) and float(T(g["masks_mean"]).mean()) > 0.3            # the object is in view all around the orbit
+    assert_forward_close(imgs[:, :, ::8, ::8], T(g["imgs_sub"]), masks[:, :, ::8, ::8], T(g["masks_sub"]), "360 NVS vs reference visualize_360", max_abs=4e-4, psnr=90.0, mask_abs=2e-4)
+    assert (depths[:, :, ::8, ::8] - T(g["depths_sub"])).abs().max().item() < 2e-4
+    assert (imgs.mean(dim=(1, 2, 3)) - T(g["imgs_mean"])).abs().max().item() < 1e-4
+    assert (depths.mean(dim=(1, 2, 3)) - T(g["depths_mean"])).abs().max().item() < 1e-4
+
+
 def test_conv3x3x3_rows_autograd_vs_torch(dev):
     """forward, data gradient (same GEMM, negated taps, transposed weights) and the wgrad kernel vs torch autograd on CPU."""
     from forge_amd import convops as co

@@ -1078,7 +1078,7 @@ def joint_configs(dev, steps=5):
         torch.cuda.synchronize()
         ms4 = _timed(step4, max(2, steps // 2), warm=1)
         out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> 40 rendered views per step); eager launch",
-                    "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3,
+                    "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3, "stock_torch": {"rocprofv3": (share or {}).get("joint_step_4_scenes")},
                     "roofline": dict(floor_of(fm4.gflop, ms4), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm4.gflop / ms4, launches=fm4.launches)})
         del s4
     except Exception as e:

@@ -537,3 +537,37 @@ dist.destroy_process_group()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_multi_rank_bench_records_run_on_rccl_with_one_rank():
+    """The sub-records of `bench.py --gpus N` (bench.ddp_train_record, bench.ray_sharded_joint_record) on the REAL backend: the test box has one GPU, so the
+    2-rank tests above run their collectives over gloo; here the same two functions run in a subprocess whose default process group is RCCL (backend "nccl",
+    world size 1) - DistributedDataParallel's reducer (bucketed all-reduce of this package's gradients, find_unused_parameters, no_sync), SyncBatchNorm-converted
+    modules, `train.train_step`'s sample broadcast and loss all-reduce, and `multi_rank_records`' own gathers all go through the RCCL communicator."""
+    import json
+    import subprocess
+    code = r'''
+import json, os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+import bench
+dev = torch.device("cuda", 0)
+args = types.SimpleNamespace(steps=2)
+rec = bench.multi_rank_records(args, 0, 1, dev, {"metric": "rehearsal"}, records=(
+    ("ddp_train", lambda: bench.ddp_train_record(0, 1, dev, 2, scenes=1, grid=32)),
+    ("ray_sharded_joint", lambda: bench.ray_sharded_joint_record(0, 1, dev, 2, grid=32))))
+torch.cuda.synchronize()
+print("RECORDS " + json.dumps(rec))
+dist.destroy_process_group()
+''' % (ROOT, str(_free_port()))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("RECORDS ")][0][len("RECORDS "):])
+    for name in ("ddp_train", "ray_sharded_joint"):
+        assert rec[name]["ranks_ok"] == 1 and not rec[name]["errors"] and rec[name]["process_group"]["backend"] == "nccl", rec[name]
+    assert rec["ddp_train"]["ms_per_step"] > 0 and rec["ddp_train"]["ms_per_step_no_sync"] > 0 and rec["ddp_train"]["gradient_bytes_all_reduced_per_step"] > 200e6
+    assert rec["ray_sharded_joint"]["unsharded_ms_per_step"] > 0 and rec["ray_sharded_joint"]["ms_per_step"] > 0

@@ -838,6 +838,28 @@ def extra_configs(dev, steps=5):
     entry("pose3d_inference", "FORGE_poseEstimator3D inference (GT poses): 1 scene x 5 views -> 3 fusions (shared input halves) -> 10 rendered views "
           "(hipGraph replay)", 10, eager3, timed3, make_pipe=pipe3)
     holder.clear()
+    # --- FORGE with PREDICTED poses in inference (kubric_eval.py:371-410 predict_initial / demo.py): both pose estimators + pose head -> cameras -> reconstruction -> 10 views
+    try:
+        mj = FORGE(syn.kubric_config(use_gt_pose=False, parameter="joint"))
+        mj.load_state_dict(syn.seeded_state_dict(mj.state_dict(), 0))
+        mj = mj.to(dev).eval()
+        s10 = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
+
+        def eagerj():
+            with torch.no_grad():
+                mj(s10, ds, dev)
+
+        def timedj():
+            if "g" not in holder:
+                holder["g"] = GraphedForward(mj, s10, ds, dev)
+            holder["g"](s10)
+        entry("joint_inference", "FORGE inference with PREDICTED poses (2-D + 3-D pose estimators + pose head -> cameras): 1 scene x 5 input views -> 10 rendered views "
+              "(5 predicted + 5 given novel cameras); the 2-D estimator on a side HIP stream beside the encoder (hipGraph replay)", 10, eagerj, timedj)
+        holder.clear()
+        del mj, s10
+    except Exception as e:
+        out.append({"name": "joint_inference", "error": repr(e)[:300]})
+    torch.cuda.empty_cache()
     # --- one GT-pose training step (configs[3] per-GPU step at the reference-native 32^3 / 64^3 grids): forward + backward + clip + Adam, eager
     m3 = m3.train()
     opt = torch.optim.Adam([p for p in m3.parameters() if p.requires_grad], lr=1e-4, fused=True)     # torch's multi-tensor Adam: same update, one launch chain

@@ -3,12 +3,15 @@
 blocks of models/model_utils.py:258-427 (einops is not required).
 
 On the MI355X every convolution of the module - the FPN's LeakyReLU ResNet-50, its lateral / top / smoothing layers and the four stride-2
-convolutions of `conv` - runs on libforge_hip.so with HIP BatchNorm (round 5; FPN.forward_rows, PoseEstimator2D._conv_rows); the six attention
+convolutions of `conv` - runs on libforge_hip.so with HIP BatchNorm (round 5; FPN.forward_rows, PoseEstimator2D._conv_rows; in eval mode without
+an autograd graph as the inference schedule of forge_amd/frozen.py: one launch per convolution, BatchNorm folded); the six attention
 blocks stay stock torch (rocBLAS GEMMs, softmax, LayerNorm). CPU tensors run the same modules on torch's own kernels."""
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .convops import PackCache as _PackCache, PackedModule as _PackedModule
 
 
 def sincos_pos_embed_2d(embed_dim, grid_size):
@@ -141,13 +144,14 @@ def _res_layer(inplanes, planes, blocks, stride):
                          *[_BottleneckLReLU(planes * 4, planes) for _ in range(1, blocks)])
 
 
-class FPN(nn.Module):
+class FPN(_PackedModule):
     """models/pose_estimator_2d.py:91-136: ResNet-50 (LeakyReLU) bottom-up, only the stride-16 level
     p4 = smooth1(upsample(toplayer(c5)) + latlayer1(c4)) is used; smooth2/3, latlayer2/3 exist unused.
     The ImageNet weights the reference downloads arrive via load_state_dict."""
 
     def __init__(self):
         super().__init__()
+        self._res_cache, self._head_cache = _PackCache(), _PackCache()      # inference launch arguments (forge_amd/frozen.py)
         self.toplayer = nn.Conv2d(2048, 256, 1)
         self.layer0 = nn.Sequential(nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
                                     nn.LeakyReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1))
@@ -179,8 +183,21 @@ class FPN(nn.Module):
         convops.conv2d_rows; only the 8x8 -> 16x16 bilinear up-sampling and the max-pool are torch ops. (On MIOpen these convolutions took whatever
         solver its find step landed on in that process - asm Winograd in one run, `naive_conv_*` in the next.)"""
         from . import convops as co
+        from . import frozen as fz
         from .encoder import resnet_rows_autograd
         l0 = self.layer0
+        if fz.frozen_ok(x, self):
+            # inference: every convolution ONE launch with bias / folded BatchNorm / residual / LeakyReLU in its epilogue; the lateral convolution
+            # takes the up-sampled top level as its residual (p4 = upsample(toplayer(c5)) + latlayer1(c4))
+            stages = [self.layer1[0], self.layer2[0], self.layer3[0], self.layer4[0]]
+            P = fz.pack_resnet(self._res_cache, l0[0], l0[1], stages, l0[2].negative_slope)
+            _, _, c4, c5 = fz.run_resnet(P, l0[0], l0[3], x, l0[2].negative_slope)                 # rows [N,1,h,w,C]
+            heads = (self.latlayer1, self.toplayer, self.smooth1)
+            lat, top, smooth = self._head_cache.get([t for m in heads for t in (m.weight, m.bias)],
+                                                    lambda: [fz.pack_layer(m, None, 1.0, force_affine=(m is self.latlayer1)) for m in heads])
+            t = fz.run_layer(top, c5)[:, 0]
+            up = F.interpolate(t.permute(0, 3, 1, 2), size=c4.shape[2:4], mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+            return fz.run_layer(smooth, fz.run_layer(lat, c4, residual=up.contiguous()[:, None]))[:, 0]
         _, _, c4, c5 = resnet_rows_autograd(l0[0], l0[1], l0[3], [self.layer1[0], self.layer2[0], self.layer3[0], self.layer4[0]], x,
                                             slope=l0[2].negative_slope)
         lat = co.conv2d_rows(c4, self.latlayer1.weight, self.latlayer1.bias)
@@ -189,11 +206,12 @@ class FPN(nn.Module):
         return co.conv2d_rows((up + lat).contiguous(), self.smooth1.weight, self.smooth1.bias)
 
 
-class PoseEstimator2D(nn.Module):
+class PoseEstimator2D(_PackedModule):
     """models/pose_estimator_2d.py:10-86"""
 
     def __init__(self):
         super().__init__()
+        self._conv_cache = _PackCache()               # inference launch arguments of `conv` (forge_amd/frozen.py)
         self.backbone = FPN()
         self.cross_attn_layers = 3
         self.self_attn_layers = 3
@@ -212,8 +230,11 @@ class PoseEstimator2D(nn.Module):
         """`self.conv` (four Conv2d(k = 3, stride 2) + BatchNorm2d + LeakyReLU, models/pose_estimator_2d.py:36-48) on NHWC rows [n,h,w,256] - what the
         attention blocks produce anyway - through libforge_hip.so (convops.conv2d_rows, bn_act_rows): MIOpen ran these on its naive fp32 kernels."""
         from . import convops as co
+        from . import frozen as fz
         from .fusion import bn_act_rows
         mods = list(self.conv)
+        if fz.frozen_ok(rows, self.conv) and not any(v % (1 << (len(mods) // 3)) for v in rows.shape[1:3]):
+            return fz.run_chain(fz.pack_chain(self._conv_cache, fz.chain_specs(self.conv)), rows[:, None])[:, 0]
         for i in range(0, len(mods), 3):
             conv, bn, act = mods[i:i + 3]
             if rows.shape[1] % 2 or rows.shape[2] % 2:

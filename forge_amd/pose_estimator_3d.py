@@ -11,6 +11,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import convops as co
 from . import geo_utils
 
 _ROT_DIMS = {"euler": 3, "quat": 4, "6D": 6, "9D": 9}
@@ -132,11 +133,12 @@ class PoseTransformer(nn.Module):
         return self.self_transformer(query=coord, key=coord)
 
 
-class PoseEstimator3D(nn.Module):
+class PoseEstimator3D(co.PackedModule):
     """models/pose_estimator_3d.py:9-113"""
 
     def __init__(self, config):
         super().__init__()
+        self._frozen_cache = co.PackCache()           # inference launch arguments of the four convolution blocks (forge_amd/frozen.py)
         self.rot_representation = config.network.rot_representation
         assert self.rot_representation in _ROT_DIMS
         self.rot_dim = _ROT_DIMS[self.rot_representation]
@@ -188,14 +190,23 @@ class PoseEstimator3D(nn.Module):
         b, t, C1, D1, H1, W1 = features.shape
         rows = features.reshape(b * t, C1, D1, H1, W1).permute(0, 2, 3, 4, 1)
         rows = rows if rows.is_contiguous() else rows.contiguous()
-        x = self._block_rows(self.conv3d_1, rows)                                   # [bt,D,H,W,64]
+        from . import frozen as fz
+        if fz.frozen_ok(features, self.conv3d_1, self.conv3d_2, self.conv3d_3, self.pose_head_1):
+            # inference (kubric_eval.py predict_initial / demo.py): one launch per convolution, bias + folded BatchNorm + LeakyReLU in its epilogue
+            seqs = (self.conv3d_1, self.conv3d_2, self.conv3d_3, self.pose_head_1)
+            specs = [fz.chain_specs(q) for q in seqs]
+            packed = self._frozen_cache.get([t for sp in specs for t in fz._sources(sp)], lambda: [[fz.pack_layer(*l) for l in sp] for sp in specs])
+            block = lambda seq, r: fz.run_chain(packed[seqs.index(seq)], r)
+        else:
+            block = self._block_rows
+        x = block(self.conv3d_1, rows)                                              # [bt,D,H,W,64]
         _, D, H, W, C = x.shape
         x = x.reshape(b, t, D * H * W, C).permute(0, 1, 3, 2)                       # [b,t,C,N] view of the rows
         ref = x[:, 0:1].expand(b, t - 1, C, D * H * W).reshape(b * (t - 1), C, -1)
         cur = x[:, 1:].reshape(b * (t - 1), C, -1)
         x = self.pose_transformer(q=ref, k=cur)                                     # [b(t-1),64,N]
         rows = x.reshape(b * (t - 1), self.coord_dim, D, H, W).permute(0, 2, 3, 4, 1).contiguous()
-        rows = self._block_rows(self.pose_head_1, self._block_rows(self.conv3d_3, self._block_rows(self.conv3d_2, rows)))
+        rows = block(self.pose_head_1, block(self.conv3d_3, block(self.conv3d_2, rows)))
         if rows.shape[1:4] != (1, 1, 1):                                            # the reference squeezes [n,1024,1,1,1]; other grids have no meaning here
             raise RuntimeError("forge_amd: PoseEstimator3D needs 32^3 feature volumes (pose_head_1 ends at %s)" % (tuple(rows.shape[1:4]),))
         return rows.reshape(b * (t - 1), -1).squeeze()

@@ -377,6 +377,64 @@ def test_pose_estimators_hip_convolutions_vs_float64_and_stock_torch(dev):
                 assert eh <= (4.0 * es + 1e-3 if train else 3.0 * es + 2e-5), (type(mod).__name__, train, name, eh, es)
 
 
+def test_pose_estimators_inference_schedule_vs_float64_stock_torch_and_autograd_path(dev):
+    """forge_amd/frozen.py: under torch.no_grad() in eval mode (kubric_eval.py predict_initial, demo.py) both pose estimators launch every
+    convolution once with bias + folded BatchNorm + residual + LeakyReLU in the GEMM epilogue. Features against the same module in float64 on the
+    CPU with the stock-torch GPU path as the yardstick (within 3x its distance + 2e-5 of max), against the autograd path of the same weights (a
+    different summation order only), and: a BatchNorm left in train mode keeps the autograd path's launches and batch statistics; an in-place parameter update
+    (an optimizer step's version bump) is seen by the cached launch arguments."""
+    import copy
+    from forge_amd import frozen as fz
+    from forge_amd.pose_estimator_2d import PoseEstimator2D
+    from forge_amd.pose_estimator_3d import PoseEstimator3D
+    torch.manual_seed(5)
+    rel = lambda got, want: (got.detach().double().cpu() - want.detach().double().cpu()).abs().max().item() / max(want.detach().abs().max().item(), 1e-30)
+    cases = [(PoseEstimator3D(syn.kubric_config()), torch.randn(2, 3, 128, 32, 32, 32) * 0.5, "conv3d_2"),
+             (PoseEstimator2D(), torch.rand(1, 4, 3, 256, 256), "conv")]
+    for mod, x, blk in cases:
+        sd = syn.seeded_state_dict({"m." + k: v for k, v in mod.state_dict().items()}, 13)
+        mod.load_state_dict({k[2:]: v for k, v in sd.items()})
+        mod.eval()
+        ref_mod = copy.deepcopy(mod).double()
+        for m in ref_mod.modules():
+            for k, v in list(vars(m).items()):
+                if torch.is_tensor(v) and v.is_floating_point():
+                    setattr(m, k, v.double())
+        with torch.no_grad():
+            ref = ref_mod(x.double(), return_features=True)
+        g = copy.deepcopy(mod).to(dev)
+        xd = x.to(dev)
+        assert fz.frozen_ok(xd, g) is False                                  # autograd on: not the inference schedule
+        with torch.no_grad():
+            assert fz.frozen_ok(xd, g)
+            fro = g(xd, return_features=True)
+        auto = g(xd, return_features=True)                                   # grad mode: convops.conv*_rows + bn_act_rows
+        g2 = copy.deepcopy(mod).to(dev)
+        g2.force_stock_torch = True
+        with torch.no_grad():
+            stock = g2(xd, return_features=True)
+        ef, es, ea = rel(fro, ref), rel(stock, ref), rel(fro, auto)
+        if os.environ.get("FORGE_TEST_REPORT"):
+            print("  %-16s inference schedule/f64 %.2e  stock/f64 %.2e  schedule/autograd path %.2e" % (type(mod).__name__, ef, es, ea))
+        assert ef <= 3.0 * es + 2e-5, (type(mod).__name__, ef, es)
+        assert ea <= 2e-4, (type(mod).__name__, ea)
+        # cached launch arguments follow an in-place parameter update
+        with torch.no_grad():
+            first = [p for n_, p in g.named_parameters() if n_.startswith(blk) and p.dim() > 1][0]
+            first.mul_(1.5)
+            fro2, = [g(xd, return_features=True)]
+        auto2 = g(xd, return_features=True)
+        assert rel(fro2, auto2) <= 2e-4 and rel(fro2, fro) > 1e-3, (type(mod).__name__, rel(fro2, auto2), rel(fro2, fro))
+        # one BatchNorm in train mode: batch statistics, i.e. the autograd path's launches
+        bn = [m for m in getattr(g, blk).modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)][0]
+        bn.train()
+        bn.momentum = 0.0                                                    # running statistics untouched between the two evaluations
+        with torch.no_grad():
+            assert not fz.frozen_ok(xd, g)
+            mixed = g(xd, return_features=True)
+        assert rel(mixed, g(xd, return_features=True)) <= 2e-5 and rel(mixed, fro2) > 1e-3
+
+
 # ------------------------------------------------------------------------------------------------------------- configs[2]
 def test_config2_batch8_vs_oracle_and_per_scene_bit_equality(dev, monkeypatch):
     """BASELINE configs[2]: full HIP path, batch = 8 scenes, 64^3 render grid, 1 GPU. Scenes 2 and 5 of the batch against the CPU

@@ -28,7 +28,9 @@ def timed(fn, n=20):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for gt in (False, True):
+TRACE_STEPS = int(os.environ.get("JOINT_INFER_TRACE", "0"))     # > 0: rocprofv3 run - that many eager predicted-pose forwards between two marker kernels
+
+for gt in ((False,) if TRACE_STEPS else (False, True)):
     cfg = syn.kubric_config(use_gt_pose=gt, parameter="joint")
     model = FORGE(cfg)
     model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
@@ -37,10 +39,32 @@ for gt in (False, True):
     def eager():
         with torch.no_grad():
             return model(sample, ds, dev)
+    if TRACE_STEPS:
+        for _ in range(3):
+            eager()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(1000)
+        for _ in range(TRACE_STEPS):
+            eager()
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        print("joint inference: traced %d eager forwards" % TRACE_STEPS)
+        break
     e = timed(eager)
     try:
         g = GraphedForward(model, sample, ds, dev)
         r = timed(lambda: g(sample))
     except Exception as ex:
         r = repr(ex)[:200]
+    if not gt:
+        feats = torch.randn(1, 5, 128, 32, 32, 32, device=dev) * 0.5
+        clips = sample["images"][:, :5].contiguous()
+        with torch.no_grad():
+            t3 = timed(lambda: model.encoder_traj(feats, return_features=True))
+            t2 = timed(lambda: model.encoder_traj_2d(clips, return_features=True))
+            model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = True
+            s3 = timed(lambda: model.encoder_traj(feats, return_features=True))
+            s2 = timed(lambda: model.encoder_traj_2d(clips, return_features=True))
+            model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = False
+        print("  alone, eager: 3-D pose estimator %.2f ms (stock torch %.2f), 2-D pose estimator %.2f ms (stock torch %.2f)" % (t3, s3, t2, s2))
     print("FORGE inference, %s poses, 10 rendered views: eager %.2f ms, hipGraph replay %s" % ("GT" if gt else "predicted", e, r if isinstance(r, str) else "%.2f ms" % r))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Every matrix-core launch of ONE GT-pose training step (TRAIN_SCENES scenes, default 4; TRAIN_MODE=joint: the joint 2D3D fine-tune step of
-BASELINE configs[4], 1 scene) with HIP events around it: entry point, shape
+BASELINE configs[4], 1 scene; TRAIN_MODE=infer / infer_pose3d: the inference forward of FORGE / FORGE_poseEstimator3D) with HIP events around it: entry point, shape
 (rows, Cout, Cin, taps / kd), ms, TFLOP/s of the FLOPs it executes - grouped by shape, sorted by time. Shows which GEMM shapes sit
 furthest below the 157.3 TF pipe."""
 import collections
@@ -40,7 +40,20 @@ if mode == "joint":
     sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
 
 
+if mode in ("infer", "infer_pose3d"):
+    # the headline forward (FORGE, GT poses, 5 in / 5 out) or FORGE_poseEstimator3D inference (10 rendered views), eval / no_grad, TRAIN_SCENES scenes
+    from forge_amd.model import FORGE
+    cls = FORGE if mode == "infer" else FORGE_poseEstimator3D
+    model = cls(cfg)
+    model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
+    model = model.to(dev).eval()
+
+
 def step():
+    if mode in ("infer", "infer_pose3d"):
+        with torch.no_grad():
+            model(sample, ds, dev)
+        return
     if mode == "joint":
         loss, _, _, _ = train.compute_all_loss_nvs(cfg, 0, sample, ds, model, {}, dev)
         opt.zero_grad(set_to_none=True)

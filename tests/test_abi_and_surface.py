@@ -273,6 +273,37 @@ def test_packed_caches_are_dropped_on_mode_load_and_apply():
     assert isinstance(gru, co.PackedModule)
 
 
+def test_inference_schedule_specs_and_pose_estimator_caches():
+    """forge_amd/frozen.py host logic: conv / BatchNorm / activation grouping of the pose estimators' blocks (models/pose_estimator_3d.py:24-60,
+    models/pose_estimator_2d.py:36-48), the eligibility test (eval BatchNorm, no autograd graph, fp32 on the GPU), and the launch-argument caches of
+    the pose estimators dropped with the module's mode like every other packed cache."""
+    from forge_amd import convops as co, frozen as fz
+    from forge_amd.pose_estimator_2d import FPN, PoseEstimator2D
+    from forge_amd.pose_estimator_3d import PoseEstimator3D
+    p3 = PoseEstimator3D(syn.kubric_config())
+    s1 = fz.chain_specs(p3.conv3d_1)
+    assert [(c.in_channels, c.out_channels, c.stride[0], bn is not None, sl) for c, bn, sl in s1] == [(128, 64, 2, True, 0.01), (64, 64, 1, False, 1.0)]
+    sh = fz.chain_specs(p3.pose_head_1)
+    assert [(c.out_channels, bn is not None, sl) for c, bn, sl in sh] == [(512, True, 0.01), (1024, False, 1.0)]
+    p2 = PoseEstimator2D()
+    assert [(c.out_channels, c.stride[0], sl) for c, bn, sl in fz.chain_specs(p2.conv)] == [(256, 2, 0.01), (512, 2, 0.01), (512, 2, 0.01), (1024, 2, 0.01)]
+    with pytest.raises(TypeError):
+        fz.chain_specs(torch.nn.Sequential(torch.nn.BatchNorm3d(8)))
+    n_src = len(fz._sources(s1))
+    assert n_src == 2 + 4 + 2                                                      # conv w, b + BatchNorm w, b, mean, var + conv w, b
+    x = torch.zeros(1, 8)
+    with torch.no_grad():
+        assert not fz.frozen_ok(x, p3)                                             # a CPU tensor never takes the HIP schedule
+    for m in (p3, p2, p2.backbone):
+        assert isinstance(m, co.PackedModule)
+    caches = [p3._frozen_cache, p2._conv_cache, p2.backbone._res_cache, p2.backbone._head_cache]
+    for c in caches:
+        c._key, c.val = ("armed",), "packed"
+    p3.eval(), p2.eval()
+    assert all(c._key is None and c.val is None for c in caches)
+    assert "_frozen_cache" not in p3.state_dict() and not any("cache" in k for k in p2.state_dict())
+
+
 def test_load_imagenet_trunk_key_mapping():
     """torchvision resnet50 keys -> the nn.Sequential trunk (conv1 -> 0, bn1 -> 1, layerN -> N+3), fc dropped, shapes validated."""
     from forge_amd.encoder import get_resnet50, load_imagenet_trunk

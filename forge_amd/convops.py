@@ -151,19 +151,23 @@ def invalidate_packed(module):
 
 
 class _ZeroArena:
-    """Zero-filled scratch for the weight gradients of ONE backward pass from one allocation and ONE fill: every weight-gradient launch
-    accumulates into a zero-filled dW (fp32 atomics over voxel chunks), i.e. ~100 `torch.zeros` launches of 4-5 us per training step. The
-    first request of a backward pass allocates the bytes the PREVIOUS pass used (+ slack) and zero-fills them once; requests are carved out
-    of it in order (256-byte aligned); when it runs out - or on the very first pass - a request falls back to its own `torch.zeros`. The
-    pass ends with an autograd-engine callback (queued on the first request). The carved tensors are views of the arena: they stay valid for
-    as long as anything (a parameter's .grad) references them; the next pass gets a fresh arena."""
+    """Zero-filled scratch for the weight gradients of ONE backward pass from one allocation and ONE fill per HIP stream: every weight-gradient
+    launch accumulates into a zero-filled dW (fp32 atomics over voxel chunks), i.e. ~100 `torch.zeros` launches of 4-5 us per training step. The
+    first request a backward pass makes on a stream allocates the bytes the PREVIOUS pass used on that stream (+ slack) and zero-fills them once,
+    on that stream; requests are carved out of it in order (256-byte aligned); when it runs out - or on the very first pass - a request falls
+    back to its own `torch.zeros`. One pool per stream because nothing orders a side stream's launches (the weight gradients of the grouped
+    ConvGRU fusion, FORGE's 2-D pose estimator: autograd replays their nodes on the stream their forward ran on) behind a fill queued on another
+    stream. The pass ends with an autograd-engine callback (queued on the first request). The carved tensors are views of the pool: they stay
+    valid for as long as anything (a parameter's .grad) references them; the next pass gets fresh pools."""
 
     def __init__(self):
-        self.buf, self.off, self.used, self.want, self.task, self.device, self.stream = None, 0, 0, 0, -1, None, None
+        self.task, self.device = -1, None
+        self.pools = {}               # stream handle -> [buffer | None, next free byte, bytes requested]  (this pass)
+        self.want = {}                # stream handle -> bytes the previous pass requested on that stream
 
     def _end(self):
-        self.want = self.used
-        self.buf, self.off, self.used, self.task = None, 0, 0, -1
+        self.want = {k: p[2] for k, p in self.pools.items()}
+        self.pools, self.task = {}, -1
 
     # the arena needs two private autograd hooks (the id of the running backward pass, an end-of-pass callback); a torch build without them
     # gets plain torch.zeros for every request (ADVICE r4: feature-detected, not assumed)
@@ -181,21 +185,23 @@ class _ZeroArena:
             return torch.zeros(shape, dtype=torch.float32, device=device)
         if task != self.task:
             # a new pass - also when the previous one never reached its callback (an exception inside backward) or a nested backward runs inside
-            # this one: the old arena is dropped, never carved again (its slices may be live gradients), and this pass gets a fresh one
+            # this one: the old pools are dropped, never carved again (their slices may be live gradients), and this pass gets fresh ones
             if self.task >= 0:
                 self._end()
-            self.task, self.device, self.off, self.used = task, device, 0, 0
+            self.task, self.device = task, device
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of(task))
-            self.buf = torch.zeros(self.want // 4 + 64, dtype=torch.float32, device=device) if self.want else None
-            self.stream = torch.cuda.current_stream(device) if torch.device(device).type == "cuda" else None     # the stream the fill was queued on
-        self.used += nbytes
-        # a request from ANOTHER stream (a branch of the model that ran on a side stream, e.g. FORGE's 2-D pose estimator: autograd replays its nodes
-        # there) must not accumulate into the arena - nothing orders it behind the fill - and gets its own zero-fill on its own stream
-        foreign = self.stream is not None and torch.cuda.current_stream(device) != self.stream
-        if self.buf is None or device != self.device or foreign or self.off + nbytes > self.buf.numel() * 4:
+        if device != self.device:
             return torch.zeros(shape, dtype=torch.float32, device=device)
-        out = self.buf[self.off // 4:self.off // 4 + n].view(shape)
-        self.off += nbytes
+        key = torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0
+        pool = self.pools.get(key)
+        if pool is None:                                          # allocated AND filled on the stream whose launches will accumulate into it
+            want = self.want.get(key, 0)
+            pool = self.pools[key] = [torch.zeros(want // 4 + 64, dtype=torch.float32, device=device) if want else None, 0, 0]
+        pool[2] += nbytes
+        if pool[0] is None or pool[1] + nbytes > pool[0].numel() * 4:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = pool[0][pool[1] // 4:pool[1] // 4 + n].view(shape)
+        pool[1] += nbytes
         return out
 
     def _end_of(self, task):

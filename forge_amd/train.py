@@ -209,12 +209,26 @@ def enable_ray_sharding(model, on=True, group=None, reduce="all"):
 
 
 def clip_grad_norm_(parameters, max_norm):
-    """torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) (scripts/kubric_trainer.py:56) on the multi-tensor (foreach) kernels: with
-    this package's gradients torch's automatic choice lands on the per-tensor path - one norm and one mul_ launch per parameter, ~1100 launches and
-    2.7 ms per joint step (tools/joint_op_profile.py) - the foreach path is two launch chains. Same arithmetic."""
-    params = [p for p in parameters if p.grad is not None]
-    foreach = True if (params and all(p.grad.is_cuda for p in params)) else None
-    return torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2.0, foreach=foreach)
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2) (scripts/kubric_trainer.py:56) on the multi-tensor (foreach) kernels.
+    torch's own foreach path does not get there for FORGE: the 2-D pose estimator's positional embedding is a float64 parameter
+    (models/pose_estimator_2d.py:50-51), so the total norm - and with it the clip coefficient - is a float64 tensor, `_foreach_mul_` refuses a scalar
+    tensor of another dtype than the gradients and falls back to one type-promoting `mul_` per gradient: 550 launches, 2.6 ms per joint step
+    (tools/debug/joint_clip_probe.py). Same arithmetic here - per-tensor norms in the gradients' dtype, their 2-norm in the promoted dtype
+    (torch.nn.utils.get_total_norm), coefficient clamped to 1 - with the coefficient cast to each dtype group before ONE multi-tensor multiply per
+    group, which is the conversion the per-tensor `mul_` performs on the scalar operand anyway. Returns the total norm."""
+    params = [p for p in ([parameters] if torch.is_tensor(parameters) else parameters) if p.grad is not None]
+    grads = [p.grad for p in params]
+    if not grads or not all(g.is_cuda for g in grads):
+        return torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2.0)
+    with torch.no_grad():
+        total = torch.nn.utils.get_total_norm(grads, norm_type=2.0, foreach=True)
+        coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+        groups = {}
+        for g in grads:
+            groups.setdefault((g.device, g.dtype), []).append(g)
+        for (device, dtype), gs in groups.items():
+            torch._foreach_mul_(gs, coef.to(device=device, dtype=dtype))
+    return total
 
 
 def train_step(config, sample, dataset, model, optimizer, device, loss_func=compute_reconstruction_loss, epoch=0, batch_idx=0,

@@ -1311,6 +1311,73 @@ def test_omniobject_density_clamp(dev):
     assert outs[1].max().item() <= 1.0 + 1e-5
 
 
+def test_grad_zero_arena_keeps_one_pool_per_stream(dev):
+    """convops.grad_zeros inside a backward pass whose nodes run on two HIP streams (the grouped fusion's weight gradients, FORGE's 2-D pose
+    estimator): each stream's requests are carved from a pool that was allocated and zero-filled ON that stream - never from the other stream's,
+    whose fill nothing orders them behind - and every slice arrives zeroed."""
+    from forge_amd import convops as co
+    arena = co._ZeroArena()
+    side = torch.cuda.Stream(dev)
+    got = []
+
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            main = torch.cuda.current_stream(dev)
+            a = arena.zeros((1000,), dev)
+            z0 = float(a.abs().sum())
+            a.add_(1.0)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                b, c = arena.zeros((3, 700), dev), arena.zeros((50,), dev)
+                z1 = float(b.abs().sum()) + float(c.abs().sum())
+                b.add_(2.0)
+                c.add_(3.0)
+            main.wait_stream(side)
+            got.append((a, b, c, z0, z1))
+            return g * 2
+
+    x = torch.ones(4, device=dev, requires_grad=True)
+    for _ in range(3):
+        Node.apply(x).sum().backward()
+    torch.cuda.synchronize()
+    assert len(arena.want) == 2 and arena.task == -1
+    a, b, c, z0, z1 = got[-1]
+    assert z0 == 0.0 and z1 == 0.0 and float(a.sum()) == 1000.0 and float(b.sum()) == 4200.0 and float(c.sum()) == 150.0
+    sa, sb, sc = (t.untyped_storage().data_ptr() for t in (a, b, c))
+    assert sb == sc and sa != sb and b.data_ptr() != c.data_ptr()                 # b, c share the side stream's pool; a sits in the main stream's
+    a1, b1 = got[1][0], got[1][1]
+    assert a1.untyped_storage().data_ptr() != sa and b1.untyped_storage().data_ptr() != sb and float(a1.sum()) == 1000.0   # earlier passes' slices untouched
+
+
+def test_clip_grad_norm_equals_torch_on_mixed_dtype_gradients(dev):
+    """train.clip_grad_norm_ (one multi-tensor multiply per dtype group) against torch.nn.utils.clip_grad_norm_ on FORGE's parameter mix - float32
+    gradients plus the float64 positional embedding of the 2-D pose estimator, which sends torch's own foreach path to 550 per-tensor launches: total
+    norm and every clipped gradient bit for bit, with the clip active (coefficient < 1) and inactive."""
+    from forge_amd import train
+    torch.manual_seed(21)
+    shapes = [(64, 32, 3, 3, 3), (128,), (7, 5), (1, 256, 256), (3,), (33, 17)]
+    for scale in (10.0, 1e-3):
+        a = [torch.nn.Parameter(torch.randn(sh, device=dev, dtype=torch.float64 if i == 3 else torch.float32)) for i, sh in enumerate(shapes)]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        for p, q in zip(a, b):
+            p.grad = torch.randn_like(p) * scale
+            q.grad = p.grad.clone()
+        a.append(torch.nn.Parameter(torch.zeros(4, device=dev)))              # a parameter without a gradient
+        b.append(torch.nn.Parameter(torch.zeros(4, device=dev)))
+        t_ref = torch.nn.utils.clip_grad_norm_(b, 10.0, norm_type=2.0)      # torch's default on GPU tensors: multi-tensor norms, then its multiply
+        t_got = train.clip_grad_norm_(a, 10.0)
+        assert t_got.dtype == t_ref.dtype == torch.float64 and torch.equal(t_got, t_ref)
+        assert (t_ref.item() > 10.0) == (scale == 10.0)
+        for p, q in zip(a[:-1], b[:-1]):
+            assert p.grad.dtype == q.grad.dtype and torch.equal(p.grad, q.grad)
+        assert a[-1].grad is None
+
+
 def test_train_step_harness(dev):
     """row f1: compute_reconstruction_loss + train_step (clip 10, Adam) run on the HIP model; the loss dict equals the formulas of
     scripts/kubric_compute_loss.py:26-35 evaluated separately, and a few steps reduce the loss."""

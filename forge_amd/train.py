@@ -214,20 +214,30 @@ def clip_grad_norm_(parameters, max_norm):
     (models/pose_estimator_2d.py:50-51), so the total norm - and with it the clip coefficient - is a float64 tensor, `_foreach_mul_` refuses a scalar
     tensor of another dtype than the gradients and falls back to one type-promoting `mul_` per gradient: 550 launches, 2.6 ms per joint step
     (tools/debug/joint_clip_probe.py). Same arithmetic here - per-tensor norms in the gradients' dtype, their 2-norm in the promoted dtype
-    (torch.nn.utils.get_total_norm), coefficient clamped to 1 - with the coefficient cast to each dtype group before ONE multi-tensor multiply per
+    (as torch.nn.utils.get_total_norm), coefficient clamped to 1 - with the coefficient cast to each dtype group before ONE multi-tensor multiply per
     group, which is the conversion the per-tensor `mul_` performs on the scalar operand anyway. Returns the total norm."""
     params = [p for p in ([parameters] if torch.is_tensor(parameters) else parameters) if p.grad is not None]
     grads = [p.grad for p in params]
     if not grads or not all(g.is_cuda for g in grads):
         return torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2.0)
     with torch.no_grad():
-        total = torch.nn.utils.get_total_norm(grads, norm_type=2.0, foreach=True)
-        coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
         groups = {}
         for g in grads:
             groups.setdefault((g.device, g.dtype), []).append(g)
-        for (device, dtype), gs in groups.items():
-            torch._foreach_mul_(gs, coef.to(device=device, dtype=dtype))
+        # torch.nn.utils.get_total_norm: per-tensor norms group by group (multi-tensor kernels), stacked in that order in the promoted dtype, then
+        # the 2-norm of the stack. The stack itself is written by ONE multi-tensor copy per dtype group into a preallocated vector (then cast and joined): torch.stack of 551 zero-dim
+        # tensors is a 1.5 ms chain of batched-cat launches (tools/joint_op_profile.py). Same values in the same order -> the same vector_norm.
+        first, dtype, parts = grads[0].device, grads[0].dtype, []
+        for (device, gdtype), gs in groups.items():
+            vec = torch.empty(len(gs), dtype=gdtype, device=device)
+            torch._foreach_copy_(list(vec.unbind(0)), torch._foreach_norm(gs, 2.0))       # same dtype on both sides: the multi-tensor route
+            parts.append(vec.to(first))
+            dtype = torch.promote_types(dtype, gdtype)
+        stacked = parts[0].to(dtype) if len(parts) == 1 else torch.cat([v.to(dtype) for v in parts])
+        total = torch.linalg.vector_norm(stacked, 2.0)
+        coef = torch.clamp(float(max_norm) / (total + 1e-6), max=1.0)
+        for (device, gdtype), gs in groups.items():
+            torch._foreach_mul_(gs, coef.to(device=device, dtype=gdtype))
     return total
 
 

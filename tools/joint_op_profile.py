@@ -39,9 +39,9 @@ def phase(name, fn):
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p_:
         out = fn()
         torch.cuda.synchronize()
-    ev = [e for e in p_.key_averages() if e.key.startswith("aten::") and e.count >= 50]
-    ev.sort(key=lambda e: -e.count)
-    print("%-10s %s" % (name, ", ".join("%s x%d (%.2f ms)" % (e.key, e.count, e.self_device_time_total / 1e3) for e in ev[:10])))
+    ev = [e for e in p_.key_averages() if e.key.startswith("aten::") and e.self_device_time_total > 0]
+    ev.sort(key=lambda e: -e.self_device_time_total)
+    print("%-10s %s" % (name, ", ".join("%s x%d (%.2f ms)" % (e.key, e.count, e.self_device_time_total / 1e3) for e in ev[:14])))
     return out
 
 

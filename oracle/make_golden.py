@@ -24,7 +24,7 @@ import forge_oracle as fo          # noqa: E402
 import ref_import                  # noqa: E402
 from forge_amd import synthetic as syn   # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("FORGE_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # FORGE_GOLDEN_OUT: a scratch directory for a reproducibility check
 
 
 def npz(name, **arrays):

@@ -105,14 +105,19 @@ class FORGE(nn.Module):
             feat.record_stream(cur)                                     # allocated on the side stream, consumed (and later freed) on this one
         return feat, join
 
-    def predict_poses(self, features_raw, clips, sample, dataset, device, pose_feat_2d=None):
+    def predict_poses(self, features_raw, clips, sample, dataset, device, pose_feat_2d=None, join_2d=None):
         """models/model.py:60-84 - relative poses of views 1..t-1 from the 3-D pose estimator (on the per-view feature volumes) and the 2-D pose
         estimator (on the images), joined by the pose head; quaternion normalised, toSE3, chained onto the canonical camera.
+        pose_feat_2d / join_2d: the 2-D estimator's features when the caller launched it on a side stream (_pose2d_features) and the join to call
+        before they are consumed - after the 3-D estimator's launches, so that the side stream's tail runs beside them.
         Returns (camPoses_cv2 [b,t,4,4], camE_cv2 [b,t,4,4], {'gt', 'pred', 'conf'})."""
         b, t = features_raw.shape[:2]
         if pose_feat_2d is None:
             pose_feat_2d = self.encoder_traj_2d(clips, return_features=True)
-        pose_feat = torch.cat([self.encoder_traj(features_raw, return_features=True), pose_feat_2d], dim=-1)      # [b(t-1),1024] each
+        pose_feat_3d = self.encoder_traj(features_raw, return_features=True)
+        if join_2d is not None:
+            join_2d()
+        pose_feat = torch.cat([pose_feat_3d, pose_feat_2d], dim=-1)                                               # [b(t-1),1024] each
         pose_vec, conf = self.pose_head(pose_feat).split([self.encoder_traj.pose_dim, 1], dim=-1)
         pose_vec, camPoses_cv2, camE_cv2 = geo_utils.predicted_camera_chain(pose_vec, self.encoder_traj.toSE3, *geo_utils.canonical_cameras(self, dataset, device), b, t)
         gt_rel = sample["cam_poses_rel_cv2"][:, 1:self.N_INPUT].reshape(b * (t - 1), 4, 4)
@@ -134,8 +139,7 @@ class FORGE(nn.Module):
         features_raw = features_raw.reshape(b, t, C, D, H, W)
 
         if not self.config.train.use_gt_pose:
-            join2d()
-            camPoses_cv2, camE_cv2, camPose_return = self.predict_poses(features_raw, clips, sample, dataset, device, pose_feat_2d=f2d)
+            camPoses_cv2, camE_cv2, camPose_return = self.predict_poses(features_raw, clips, sample, dataset, device, pose_feat_2d=f2d, join_2d=join2d)
         else:
             suffix = "_canonicalized" if self.config.train.canonicalize else ""
             camE_cv2 = sample["cam_extrinsics_cv2" + suffix][:, :t]

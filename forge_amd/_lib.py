@@ -66,6 +66,7 @@ SIGNATURES = {
     "forge_sse_groups_blocks": [],
     "forge_sse_groups_fwd": [_P, _LL, _LL, _LL, _LL, _P, _P] + [_I] * 7 + [_P],
     "forge_sse_groups_bwd": [_P, _LL, _LL, _LL, _LL, _P, _P, _P] + [_I] * 7 + [_P],
+    "forge_attention_fwd": [_P, _P, _P, _LL, _P, _I, _I, _I, _I, _P],
     "forge_im2col_nchw": [_P, _P] + [_I] * 9 + [_P],
     "forge_maxpool2d_nhwc": [_P, _P] + [_I] * 7 + [_P],
     "forge_ncdhw_to_ndhwc": [_P, _P, _I, _I, _LL, _P],

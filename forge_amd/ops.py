@@ -220,3 +220,28 @@ class _ResizeBilinear(torch.autograd.Function):
 def resize_bilinear(x, Ho, Wo):
     """F.interpolate(x, size=(Ho, Wo), mode='bilinear', align_corners=False) on the HIP kernels (forward and adjoint)."""
     return _ResizeBilinear.apply(x, int(Ho), int(Wo))
+
+
+def attention_applies(q, k, v):
+    """forge_attention_fwd's domain: fp32 on the MI355X, no autograd graph wanted, one head of 64 channels, token counts multiples of 64,
+    q / k [B,N,64] and v [B,Nk,64] or [1,Nk,64] (shared)."""
+    return (q.is_cuda and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and not torch.is_grad_enabled()
+            and q.dim() == 3 and k.dim() == 3 and v.dim() == 3 and q.shape[-1] == 64 and k.shape[-1] == 64 and v.shape[-1] == 64
+            and q.shape[0] == k.shape[0] and v.shape[0] in (1, q.shape[0]) and v.shape[1] == k.shape[1]
+            and q.shape[1] % 64 == 0 and k.shape[1] % 64 == 0 and q.shape[1] > 0 and k.shape[1] > 0)
+
+
+@_lib.on_tensor_device
+def attention(q, k, v):
+    """softmax(q k^T) v for one head (models/model_utils.py:207-229, unscaled) without materialising the [B,Nq,Nk] matrix: forge_attention_fwd.
+    q [B,Nq,64], k [B,Nk,64], v [B,Nk,64] or [1,Nk,64] (one value table for every batch element) -> [B,Nq,64]. Inference only (no autograd node)."""
+    if not attention_applies(q, k, v):
+        raise RuntimeError("forge_amd: ops.attention needs fp32 [B,N,64] tensors on the MI355X with token counts that are multiples of 64, outside autograd "
+                           "(got q %s, k %s, v %s, grad mode %s)" % (tuple(q.shape), tuple(k.shape), tuple(v.shape), torch.is_grad_enabled()))
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    B, Nq, d = q.shape
+    Nk = k.shape[1]
+    out = torch.empty(B, Nq, d, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().forge_attention_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), 0 if v.shape[0] == 1 and B > 1 else Nk, _lib.ptr(out), B, Nq, Nk, d,
+                                              _lib.current_stream()), "forge_attention_fwd")
+    return out

@@ -47,6 +47,10 @@ class Attention(nn.Module):
 
     def forward(self, query, key, value):
         B, N, C = query.shape
+        if self.num_heads == 1 and not getattr(self, "force_stock_torch", False):
+            from . import ops
+            if ops.attention_applies(query, key, value):                  # inference on the MI355X: the N x N matrix never leaves registers
+                return ops.attention(query, key, value)
         split = lambda x: x.reshape(B, N, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
         q, k, v = split(query), split(key), split(value)
         attn = torch.matmul(q, k.transpose(-2, -1)).softmax(dim=-1)
@@ -92,6 +96,22 @@ class Block(nn.Module):
         k = self.norm(k.permute(0, 2, 1)).permute(0, 2, 1)
         return self.encode_query(q).permute(0, 2, 1), self.encode_key(k).permute(0, 2, 1)
 
+    # ---- tokens-major twins ([B,N,C] in and out): the 1x1 Conv1d encoders are linear layers over the channels, so with the tokens as rows - what
+    # the HIP convolutions around the transformer produce and consume - LayerNorm, encoders, attention and MLP chain without a single permute copy
+    @staticmethod
+    def _lin(conv, x):
+        return torch.nn.functional.linear(x, conv.weight[:, :, 0], conv.bias)
+
+    def qk_tokens(self, query, key):
+        return self._lin(self.encode_query, self.norm(query)), self._lin(self.encode_key, self.norm(key))
+
+    def forward_tokens(self, query, key):
+        from . import ops
+        q, k = self.qk_tokens(query, key)
+        v = self._lin(self.encode_value, key)
+        x = query + (ops.attention(q, k, v) if ops.attention_applies(q, k, v) else self.attn(query=q, key=k, value=v))
+        return x + self.mlp(self.norm2(x))
+
     def get_attn(self, query, key, query_embed=None, key_embed=None):
         q, k = self._qk(query, key, query_embed, key_embed)
         return self.attn.get_attn(query=q, key=k)                       # [B,N,N]
@@ -126,8 +146,23 @@ class PoseTransformer(nn.Module):
             cache[key] = self.pos_embed_3d_coord.to(like)
         return cache[key]
 
+    def forward_tokens(self, q, k):
+        """forward on tokens-major tensors q, k [B,N,C] -> [B,N,C] (inference on the MI355X: PoseEstimator3D._forward_features_hip)."""
+        from . import ops
+        pe = self._pos_embed(q)
+        qn, kn = self.cross_transformer.qk_tokens(q, k)
+        coord = ops.attention(qn, kn, pe) if ops.attention_applies(qn, kn, pe) else torch.matmul(self.cross_transformer.attn.get_attn(query=qn, key=kn), pe)
+        return self.self_transformer.forward_tokens(coord, coord)
+
     def forward(self, q, k, q_pe=None, k_pe=None):
         pe = self._pos_embed(q)
+        if not getattr(self, "force_stock_torch", False):
+            from . import ops
+            qn, kn = self.cross_transformer._qk(q, k, None, None)        # [B,N,C] each
+            if ops.attention_applies(qn, kn, pe):
+                # inference on the MI355X: softmax(q k^T) pe in one launch instead of the [B,N,N] matrix + softmax + matmul
+                coord = ops.attention(qn, kn, pe).permute(0, 2, 1)            # [B,C,N]
+                return self.self_transformer(query=coord, key=coord)
         attn = self.cross_transformer.get_attn(query=q, key=k)          # [B,N,N]
         coord = torch.matmul(attn, pe).permute(0, 2, 1)                  # [B,C,N]
         return self.self_transformer(query=coord, key=coord)
@@ -201,11 +236,18 @@ class PoseEstimator3D(co.PackedModule):
             block = self._block_rows
         x = block(self.conv3d_1, rows)                                              # [bt,D,H,W,64]
         _, D, H, W, C = x.shape
-        x = x.reshape(b, t, D * H * W, C).permute(0, 1, 3, 2)                       # [b,t,C,N] view of the rows
-        ref = x[:, 0:1].expand(b, t - 1, C, D * H * W).reshape(b * (t - 1), C, -1)
-        cur = x[:, 1:].reshape(b * (t - 1), C, -1)
-        x = self.pose_transformer(q=ref, k=cur)                                     # [b(t-1),64,N]
-        rows = x.reshape(b * (t - 1), self.coord_dim, D, H, W).permute(0, 2, 3, 4, 1).contiguous()
+        if block is not self._block_rows:
+            # inference: the rows ARE the tokens - no [B,C,N] round trip around the transformer
+            tok = x.reshape(b, t, D * H * W, C)
+            ref = tok[:, 0:1].expand(b, t - 1, D * H * W, C).reshape(b * (t - 1), D * H * W, C)
+            cur = tok[:, 1:].reshape(b * (t - 1), D * H * W, C)
+            rows = self.pose_transformer.forward_tokens(ref, cur).reshape(b * (t - 1), D, H, W, self.coord_dim)
+        else:
+            x = x.reshape(b, t, D * H * W, C).permute(0, 1, 3, 2)                   # [b,t,C,N] view of the rows
+            ref = x[:, 0:1].expand(b, t - 1, C, D * H * W).reshape(b * (t - 1), C, -1)
+            cur = x[:, 1:].reshape(b * (t - 1), C, -1)
+            x = self.pose_transformer(q=ref, k=cur)                                 # [b(t-1),64,N]
+            rows = x.reshape(b * (t - 1), self.coord_dim, D, H, W).permute(0, 2, 3, 4, 1).contiguous()
         rows = block(self.pose_head_1, block(self.conv3d_3, block(self.conv3d_2, rows)))
         if rows.shape[1:4] != (1, 1, 1):                                            # the reference squeezes [n,1024,1,1,1]; other grids have no meaning here
             raise RuntimeError("forge_amd: PoseEstimator3D needs 32^3 feature volumes (pose_head_1 ends at %s)" % (tuple(rows.shape[1:4]),))
@@ -214,7 +256,10 @@ class PoseEstimator3D(co.PackedModule):
     def forward(self, features, return_features=False):
         """features [b,t,128,D,H,W] -> (pose [b(t-1),pose_dim], conf [b(t-1),1]) or the 1024-d features"""
         b, t, C1, D1, H1, W1 = features.shape
-        if features.is_cuda and features.dtype == torch.float32 and not getattr(self, "force_stock_torch", False):
+        stock = getattr(self, "force_stock_torch", False)                # tests / probes: every op of the module on torch's own kernels
+        for m in (self.pose_transformer, self.pose_transformer.cross_transformer.attn, self.pose_transformer.self_transformer.attn):
+            m.force_stock_torch = stock
+        if features.is_cuda and features.dtype == torch.float32 and not stock:
             x = self.pose_head_2(self._forward_features_hip(features))
         else:
             x = self.conv3d_1(features.reshape(b * t, C1, D1, H1, W1))

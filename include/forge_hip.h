@@ -374,6 +374,14 @@ int forge_bn_sync_bwd_apply(const float* dy, int lddy, const float* x, int ldx, 
 int forge_affine_act_bwd(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale, float slope, float* dx, int ld_dx,
                          long long M, int C, forge_stream_t stream);
 
+/* Single-head dot-product attention out = softmax(q k^T) v, fp32 on the matrix cores with the N x N matrix kept in registers (online softmax over
+ * 32-key tiles). Replaces `Attention.forward` / `Attention.get_attn` + the matmul behind it (models/model_utils.py:207-229, called by
+ * models/pose_estimator_3d.py:116-144 with N = 4096 tokens per volume pair) in predicted-pose INFERENCE; torch computes the same sums with the matrix
+ * materialised three times. Unscaled logits, as the reference. q [B][Nq][d], k [B][Nk][d], v [.][Nk][d] with a batch stride of v_batch_rows rows
+ * (0 = one v shared by all batch elements: the positional table of the cross attention), out [B][Nq][d]; d = 64, Nq and Nk multiples of 64. */
+int forge_attention_fwd(const float* q, const float* k, const float* v, long long v_batch_rows, float* out, int B, int Nq, int Nk, int d,
+                        forge_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a1  ResNet stem helpers (torchvision conv1/bn1/relu/maxpool behind models/encoder.py:71-73).
  * forge_im2col_nchw: img [N][C][H][W] -> patch rows out [N*Ho*Wo][Kpad], k = (ky*kw + kx)*C + c, zeros outside the image and

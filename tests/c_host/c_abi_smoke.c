@@ -177,9 +177,54 @@ int main(void) {
             for (int x = 0; x < Wo; ++x) EXPECT(fabsf(h_q[y * Wo + x] - want[x]) < 1e-6f, "bilinear x2 of a column ramp");
     }
 
+    /* ---------------- attention: softmax(q k^T) v, 64 queries x 128 keys x one 64-channel head, against a double-precision host evaluation;
+     * identical keys make the softmax uniform (out = mean of v) - a closed form next to the general case */
+    {
+        enum { NQ = 64, NK = 128, DH = 64 };
+        static float h_q[NQ * DH], h_k[NK * DH], h_v[NK * DH], h_o[NQ * DH];
+        unsigned rng = 12345u;
+        for (int i = 0; i < NQ * DH; ++i) { rng = rng * 1664525u + 1013904223u; h_q[i] = ((rng >> 8) & 0xffff) / 65536.f - 0.5f; }
+        for (int i = 0; i < NK * DH; ++i) { rng = rng * 1664525u + 1013904223u; h_k[i] = ((rng >> 8) & 0xffff) / 65536.f - 0.5f; }
+        for (int i = 0; i < NK * DH; ++i) { rng = rng * 1664525u + 1013904223u; h_v[i] = ((rng >> 8) & 0xffff) / 32768.f - 1.f; }
+        float *d_q, *d_k, *d_v, *d_o;
+        CHECK_HIP(hipMalloc((void**)&d_q, sizeof(h_q)));
+        CHECK_HIP(hipMalloc((void**)&d_k, sizeof(h_k)));
+        CHECK_HIP(hipMalloc((void**)&d_v, sizeof(h_v)));
+        CHECK_HIP(hipMalloc((void**)&d_o, sizeof(h_o)));
+        CHECK_HIP(hipMemcpy(d_q, h_q, sizeof(h_q), hipMemcpyHostToDevice));
+        CHECK_HIP(hipMemcpy(d_v, h_v, sizeof(h_v), hipMemcpyHostToDevice));
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1)
+                for (int j = 1; j < NK; ++j) memcpy(h_k + j * DH, h_k, DH * sizeof(float));       /* all keys equal: uniform weights */
+            CHECK_HIP(hipMemcpy(d_k, h_k, sizeof(h_k), hipMemcpyHostToDevice));
+            CHECK_FORGE(forge_attention_fwd(d_q, d_k, d_v, NK, d_o, 1, NQ, NK, DH, (forge_stream_t)st));
+            CHECK_HIP(hipStreamSynchronize(st));
+            CHECK_HIP(hipMemcpy(h_o, d_o, sizeof(h_o), hipMemcpyDeviceToHost));
+            double worst = 0.0;
+            for (int i = 0; i < NQ; ++i) {
+                double lg[NK], mx = -1e300, den = 0.0;
+                for (int j = 0; j < NK; ++j) {
+                    double a = 0.0;
+                    for (int c = 0; c < DH; ++c) a += (double)h_q[i * DH + c] * h_k[j * DH + c];
+                    lg[j] = a;
+                    if (a > mx) mx = a;
+                }
+                for (int j = 0; j < NK; ++j) { lg[j] = exp(lg[j] - mx); den += lg[j]; }
+                for (int c = 0; c < DH; ++c) {
+                    double o = 0.0;
+                    for (int j = 0; j < NK; ++j) o += lg[j] * h_v[j * DH + c];
+                    const double e = fabs(o / den - h_o[i * DH + c]);
+                    if (e > worst) worst = e;
+                }
+            }
+            EXPECT(worst < 2e-6, pass ? "attention with identical keys = mean of v" : "attention vs the double-precision host evaluation");
+        }
+        EXPECT(forge_attention_fwd(d_q, d_k, d_v, NK, d_o, 1, NQ - 1, NK, DH, (forge_stream_t)st) == FORGE_ESHAPE, "63 queries must be refused");
+    }
+
     /* ---------------- error path */
     EXPECT(forge_rotate_fwd(NULL, d_xf, d_mode, d_out, n, C, D, D, D, (forge_stream_t)st) == FORGE_EINVAL, "NULL input must return FORGE_EINVAL");
     EXPECT(strlen(forge_last_error()) > 0, "forge_last_error must describe the failure");
-    printf("C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK (central opacity %.6f)\n", h_oo[(Hr / 2) * Wr + Wr / 2]);
+    printf("C host: rotate + render + conv_igemm (explicit plan) + resize + attention + error path OK (central opacity %.6f)\n", h_oo[(Hr / 2) * Wr + Wr / 2]);
     return 0;
 }

@@ -23,7 +23,7 @@ def test_c_host_program_builds_and_runs(tmp_path):
     assert build.returncode == 0, build.stdout + build.stderr
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
-    assert "C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK" in run.stdout
+    assert "C host: rotate + render + conv_igemm (explicit plan) + resize + attention + error path OK" in run.stdout
 
 
 def test_c_host_program_under_address_and_ub_sanitizers(tmp_path):
@@ -51,7 +51,7 @@ def test_c_host_program_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
     assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error:" not in run.stderr, run.stderr[-4000:]
-    assert "C host: rotate + render + conv_igemm (explicit plan) + resize + error path OK" in run.stdout
+    assert "C host: rotate + render + conv_igemm (explicit plan) + resize + attention + error path OK" in run.stdout
 
 
 def test_lds_dma_hardware_assumptions_probe(tmp_path):

@@ -1311,6 +1311,41 @@ def test_omniobject_density_clamp(dev):
     assert outs[1].max().item() <= 1.0 + 1e-5
 
 
+def test_attention_vs_float64_and_torch(dev):
+    """forge_attention_fwd (ops.attention): softmax(q k^T) v of models/model_utils.py:207-229 (one head of 64 channels, unscaled logits) with the
+    N x N matrix kept in registers, against the float64 evaluation of softmax-then-matmul - with torch's fp32 evaluation of the same three ops on
+    the GPU as the yardstick (the kernel has to stay within 2x its distance + 1e-6 of max) - on small ragged-tile shapes, with a value table shared
+    by the batch (the positional table of the cross attention), with peaky logits (|logit| up to ~60: the running-max rescaling at work) and at the
+    pose estimator's size (4 pairs x 4096 tokens). Arguments outside its domain are refused, not approximated."""
+    from forge_amd import _lib, ops
+    torch.manual_seed(17)
+    rel = lambda got, want: (got.double() - want).abs().max().item() / want.abs().max().item()
+    for B, Nq, Nk, shared, gain in ((3, 128, 192, False, 1.0), (2, 64, 64, True, 1.0), (2, 192, 128, False, 6.0), (4, 4096, 4096, True, 1.0), (1, 4096, 4096, False, 2.5)):
+        q, k = torch.randn(B, Nq, 64, device=dev) * gain * 0.5, torch.randn(B, Nk, 64, device=dev) * 0.5
+        v = torch.randn(1 if shared else B, Nk, 64, device=dev)
+        with torch.no_grad():
+            got = ops.attention(q, k, v)
+            t32 = torch.matmul(torch.matmul(q, k.transpose(1, 2)).softmax(dim=-1), v)
+            want = torch.matmul(torch.matmul(q.double(), k.double().transpose(1, 2)).softmax(dim=-1), v.double())
+        eh, et = rel(got, want), rel(t32, want)
+        if os.environ.get("FORGE_TEST_REPORT"):
+            print("  attention B=%d Nq=%d Nk=%d shared_v=%s gain %.1f: hip/f64 %.2e torch/f64 %.2e" % (B, Nq, Nk, shared, gain, eh, et))
+        assert got.shape == (B, Nq, 64) and eh <= 2.0 * et + 1e-6, (B, Nq, Nk, shared, gain, eh, et)
+    q = torch.randn(1, 100, 64, device=dev)
+    with torch.no_grad():
+        assert not ops.attention_applies(q, q, q)                                  # 100 tokens: not a multiple of 64
+        with pytest.raises(RuntimeError, match="multiples of 64"):
+            ops.attention(q, q, q)
+        assert ops.attention_applies(q[:, :64], q[:, :64], q[:, :64]) and not ops.attention_applies(q[:, :64, :32], q[:, :64, :32], q[:, :64, :32])
+    assert not ops.attention_applies(q[:, :64], q[:, :64], q[:, :64])              # autograd on: torch's differentiable ops run instead
+    L = _lib.lib()
+    out = torch.empty(1, 64, 64, device=dev)
+    rc = L.forge_attention_fwd(_lib.ptr(q), _lib.ptr(q), _lib.ptr(q), 64, _lib.ptr(out), 1, 100, 64, 64, _lib.current_stream())
+    assert rc != 0 and b"multiples of 64" in L.forge_last_error()
+    rc = L.forge_attention_fwd(_lib.ptr(q), _lib.ptr(q), _lib.ptr(q), 64, _lib.ptr(out), 1, 64, 64, 32, _lib.current_stream())
+    assert rc != 0 and b"64 channels" in L.forge_last_error()
+
+
 def test_grad_zero_arena_keeps_one_pool_per_stream(dev):
     """convops.grad_zeros inside a backward pass whose nodes run on two HIP streams (the grouped fusion's weight gradients, FORGE's 2-D pose
     estimator): each stream's requests are carved from a pool that was allocated and zero-filled ON that stream - never from the other stream's,

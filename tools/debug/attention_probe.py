@@ -42,3 +42,17 @@ with torch.no_grad():
         m(feats, return_features=True)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=22, max_name_column_width=70))
+
+    # ---- the 2-D pose estimator (FPN + 6 attention blocks + stride-2 tail), same question
+    from forge_amd.pose_estimator_2d import PoseEstimator2D  # noqa: E402
+    m2 = PoseEstimator2D()
+    sd2 = syn.seeded_state_dict({"m." + k_: v_ for k_, v_ in m2.state_dict().items()}, 0)
+    m2.load_state_dict({k_[2:]: v_ for k_, v_ in sd2.items()})
+    m2 = m2.to(dev).eval()
+    clips = torch.rand(1, 5, 3, 256, 256, device=dev)
+    print("2-D pose estimator, 1 scene x 5 views: %.3f ms; FPN alone %.3f ms" % (timed(lambda: m2(clips, return_features=True)),
+                                                                                timed(lambda: m2.backbone.forward_rows(clips[0]))))
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        m2(clips, return_features=True)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=26, max_name_column_width=70))

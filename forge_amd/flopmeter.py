@@ -1,7 +1,7 @@
 """Executed-FLOP meter for the matrix-core launches of libforge_hip.so (measurement aid for bench.py / tools; not on the product path).
 
 `with FlopMeter() as m: step()` wraps the ctypes entry points whose work runs on the fp32 MFMA pipe - forge_conv_igemm, forge_wino_gemm,
-forge_conv_wgrad, forge_wino_wgrad - for the duration of the block and sums the FLOPs each launch EXECUTES, computed from the call's own
+forge_conv_wgrad, forge_wino_wgrad, forge_attention_fwd - for the duration of the block and sums the FLOPs each launch EXECUTES, computed from the call's own
 arguments (2 M N taps Cin for a direct / data-gradient / weight-gradient convolution, 2 x 16 R N kd Cin for the 16 Winograd point problems).
 Only eager launches made by this process are seen (a hipGraph replay makes no Python calls): meter one eager pass, time the replay.
 """
@@ -32,7 +32,12 @@ def _wino_wgrad(a):     # forge_wino_wgrad(dMm,V1,C1,bs1,pt1,V2,C2,bs2,pt2,dU,n,
     return 2.0 * 16 * _v(a[10]) * _v(a[11]) * _v(a[12]) * _v(a[13]) * _v(a[14]) * _v(a[15]) * (_v(a[2]) + _v(a[6]))
 
 
-_ENTRIES = {"forge_conv_igemm": _igemm, "forge_wino_gemm": _wino_gemm, "forge_conv_wgrad": _wgrad, "forge_wino_wgrad": _wino_wgrad}
+def _attention(a):      # forge_attention_fwd(q,k,v,v_batch_rows,out,B,Nq,Nk,d,stream): q k^T and p v
+    return 4.0 * _v(a[5]) * _v(a[6]) * _v(a[7]) * _v(a[8])
+
+
+_ENTRIES = {"forge_conv_igemm": _igemm, "forge_wino_gemm": _wino_gemm, "forge_conv_wgrad": _wgrad, "forge_wino_wgrad": _wino_wgrad,
+            "forge_attention_fwd": _attention}
 
 
 class FlopMeter:

@@ -1320,7 +1320,8 @@ def test_attention_vs_float64_and_torch(dev):
     from forge_amd import _lib, ops
     torch.manual_seed(17)
     rel = lambda got, want: (got.double() - want).abs().max().item() / want.abs().max().item()
-    for B, Nq, Nk, shared, gain in ((3, 128, 192, False, 1.0), (2, 64, 64, True, 1.0), (2, 192, 128, False, 6.0), (4, 4096, 4096, True, 1.0), (1, 4096, 4096, False, 2.5)):
+    for B, Nq, Nk, shared, gain in ((3, 128, 192, False, 1.0), (2, 64, 64, True, 1.0), (2, 192, 128, False, 6.0), (40, 1024, 256, False, 1.0), (4, 4096, 4096, True, 1.0),
+                                     (1, 4096, 4096, False, 2.5)):        # both key splits: 2 parts (ragged key counts, many query tiles) and 4 parts (few query tiles)
         q, k = torch.randn(B, Nq, 64, device=dev) * gain * 0.5, torch.randn(B, Nk, 64, device=dev) * 0.5
         v = torch.randn(1 if shared else B, Nk, 64, device=dev)
         with torch.no_grad():

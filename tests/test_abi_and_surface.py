@@ -65,6 +65,11 @@ def test_ops_refuse_cpu_tensors():
     from forge_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.rotate_warp(torch.zeros(1, 4, 4, 4, 4), torch.zeros(1, 12), torch.zeros(1, dtype=torch.int32))
+    q = torch.zeros(1, 64, 64)
+    with torch.no_grad():
+        assert not ops.attention_applies(q, q, q)                           # a CPU tensor: the caller keeps torch's own ops
+        with pytest.raises(RuntimeError, match="on the MI355X"):
+            ops.attention(q, q, q)
 
 
 @pytest.mark.parametrize("which", ["pose3d", "joint"])

@@ -473,6 +473,31 @@ class _FuseFrozen(torch.autograd.Function):
         return dx.permute(0, 1, 5, 2, 3, 4), None, None, None
 
 
+def _flatten_saved(obj, tensors):
+    """Nested lists / tuples / dicts of tensors and constants -> a structure description with the tensors moved to `tensors` (for
+    ctx.save_for_backward: version-counter checks on the parameters among them, storage released when the backward pass has run)."""
+    if torch.is_tensor(obj):
+        tensors.append(obj)
+        return ("t", len(tensors) - 1)
+    if isinstance(obj, (list, tuple)):
+        return ("l" if isinstance(obj, list) else "u", [_flatten_saved(o, tensors) for o in obj])
+    if isinstance(obj, dict):
+        return ("d", [(k, _flatten_saved(v, tensors)) for k, v in obj.items()])
+    return ("c", obj)
+
+
+def _unflatten_saved(spec, tensors):
+    kind, val = spec
+    if kind == "t":
+        return tensors[val]
+    if kind in ("l", "u"):
+        items = [_unflatten_saved(v, tensors) for v in val]
+        return items if kind == "l" else tuple(items)
+    if kind == "d":
+        return {k: _unflatten_saved(v, tensors) for k, v in val}
+    return val
+
+
 class _FuseGroupsTrain(torch.autograd.Function):
     """Several ConvGRU fusions over subsets of the SAME views WITH weight gradients (the GT-pose training step, model_single_pose_estimator.py:
     108-120: views (0,1,2), (3,4), (0..4)) as ONE autograd node whose forward and backward are hand-scheduled on the Winograd launches:
@@ -552,7 +577,10 @@ class _FuseGroupsTrain(torch.autograd.Function):
             out, svn = bn_rows_fwd(h, gn, bn_, rm, rv, mom, eps, 1.0, None, nbt, group)
             outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
             saved_groups.append((grp, Vm, sv1, Vt0, sv4, steps, svn))
-        ctx.packs, ctx.Vx, ctx.groups_saved, ctx.shape = packs, Vx, saved_groups, (b, t, C, D, H, W)
+        tensors = []
+        ctx.spec = _flatten_saved((packs, Vx, saved_groups), tensors)       # incl. the BatchNorm parameters inside the bn_rows_fwd states
+        ctx.save_for_backward(*tensors)
+        ctx.shape = (b, t, C, D, H, W)
         ctx.has_bias = tuple(v is not None for v in (bg, bo, b0, b3))
         return tuple(outs)
 
@@ -560,7 +588,7 @@ class _FuseGroupsTrain(torch.autograd.Function):
     @_lib.on_tensor_device
     def backward(ctx, *douts):
         b, t, C, D, H, W = ctx.shape
-        packs, Vx, saved_groups = ctx.packs, ctx.Vx, ctx.groups_saved
+        packs, Vx, saved_groups = _unflatten_saved(ctx.spec, ctx.saved_tensors)
         dev = Vx.device
         M, vol, Ht, Wt = b * D * H * W, D * H * W, H // 2, W // 2
         R1 = D * Ht * Wt

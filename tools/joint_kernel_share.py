@@ -12,7 +12,7 @@ import json
 import re
 import sys
 
-FORGE = re.compile(r"(adam_small|affine_act_bwd|bn_apply_bwd|bn_apply_fwd|bn_finalize|bn_from_totals|bn_reduce_bwd|bn_stats|colsum_flat|conv_direct|conv_igemm|"
+FORGE = re.compile(r"forge::|(adam_small|attention_fwd|affine_act_bwd|bn_apply_bwd|bn_apply_fwd|bn_finalize|bn_from_totals|bn_reduce_bwd|bn_stats|colsum_flat|conv_direct|conv_igemm|"
                    r"conv_splitk_epilogue|conv_wgrad|gru_gates|gru_state|im2col_nchw|maxpool2d_nhwc|pack_cameras|pose_chain|pose_xf|render_bwd|render_fwd|"
                    r"resize_bilinear|rotate_bwd|rotate_fwd|sse_groups|transpose_kernel|wino_dw|wino_dy|wino_input|wino_output|wino_weight)[a-z_0-9]*_?kernel|"
                    r"^(void )?(conv_igemm|conv_wgrad|wino_|render_|rotate_|bn_|gru_)")

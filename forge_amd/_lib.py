@@ -59,6 +59,7 @@ SIGNATURES = {
     "forge_bn_train_fwd": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _I, _P, _I, _P, _I, _P],
     "forge_bn_train_bwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _LL, _I, _P, _I, _P, _I, _P],
     "forge_bn_sync_stats": [_P, _I, _P, _LL, _I, _I, _P],
+    "forge_bn_eval_fwd": [_P, _I, _P, _P, _P, _P, _F, _F, _P, _I, _P, _P, _LL, _I, _P, _I, _P],
     "forge_bn_sync_fwd_apply": [_P, _I, _P, _P, _F, _F, _P, _I, _P, _P, _P, _P, _F, _P, _LL, _LL, _I, _P, _I, _P, _P],
     "forge_bn_sync_bwd_reduce": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _P, _P, _LL, _I, _P, _I, _P],
     "forge_bn_sync_bwd_apply": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _LL, _LL, _I, _P, _I, _P, _I, _P],

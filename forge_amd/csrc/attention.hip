@@ -143,8 +143,9 @@ extern "C" int forge_attention_fwd(const float* q, const float* k, const float* 
     FORGE_REQUIRE(d == ATT_D, FORGE_ESHAPE, "forge_attention_fwd: one head of %d channels (got d=%d)", ATT_D, d);
     FORGE_REQUIRE(B > 0 && Nq > 0 && Nk > 0 && Nq % 64 == 0 && Nk % 64 == 0, FORGE_ESHAPE,
                   "forge_attention_fwd: B=%d Nq=%d Nk=%d (Nq and Nk must be multiples of 64)", B, Nq, Nk);
-    // key parts per query: 4 when two-part workgroups (64 queries each) would not give every SIMD of the 256 CUs two waves
-    const bool ks4 = Nk % 128 == 0 && (long long)B * (Nq / 64) < 512;
+    // key parts per query: 4 when two-part workgroups (64 queries each) would not give every CU two workgroups (MI355X in SPX mode: 256 CUs ->
+    // fewer than 512 query tiles). MI355X only, as the whole library: the constant is not derived from the device properties.
+    const bool ks4 = Nk % 128 == 0 && (long long)B * (Nq / 64) < 2 * 256;
     FORGE_REQUIRE(v_batch_rows == 0 || v_batch_rows >= Nk, FORGE_EINVAL, "forge_attention_fwd: v batch stride %lld rows (0 = one v for every batch element, else >= Nk)",
                   v_batch_rows);
     FORGE_REQUIRE((long long)B * (Nq / 64) < (1ll << 31), FORGE_ESHAPE, "forge_attention_fwd: too many query tiles");

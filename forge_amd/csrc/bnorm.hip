@@ -136,6 +136,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_from_totals_kernel(const BnArgs
     }
 }
 
+// Eval-mode BatchNorm under autograd: the statistics ARE the running statistics (read, never updated) - mean / invstd in the form the apply
+// kernels and the backward read them.
+__global__ __launch_bounds__(BN_THREADS) void bn_from_running_kernel(const BnArgs a) {
+    const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (c >= a.C) return;
+    a.mean[c] = a.running_mean[c];
+    a.invstd[c] = (float)(1.0 / sqrt((double)a.running_var[c] + (double)a.eps));
+}
+
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const BnArgs a) {
     int c, rg, RG;
     bn_coords(a.C, c, rg, RG);
@@ -443,6 +452,24 @@ extern "C" int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gam
     hipLaunchKernelGGL(bn_from_totals_kernel, dim3((unsigned)((C + BN_THREADS - 1) / BN_THREADS)), dim3(BN_THREADS), 0, st, a, totals);
     hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
     FORGE_LAUNCH_CHECK("forge_bn_sync_fwd_apply");
+    return 0;
+}
+
+extern "C" int forge_bn_eval_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float eps, float slope, float* y, int ldy, float* mean, float* invstd, long long M, int C, const float* res, int ldres,
+                                 forge_stream_t stream) {
+    if (int rc = bn_check("forge_bn_eval_fwd", x, ldx, M, C, running_mean)) return rc;
+    if (int rc = bn_check_side("forge_bn_eval_fwd", "residual", res, ldres, C)) return rc;
+    FORGE_REQUIRE(y && mean && invstd && running_var && ldy >= C && ldy % 4 == 0, FORGE_EINVAL, "forge_bn_eval_fwd: null output / running-statistics pointer or bad ldy");
+    BnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.ldx = ldx; a.out = y; a.ldo = ldy; a.gamma = gamma; a.beta = beta; a.mean = mean; a.invstd = invstd;
+    a.running_mean = const_cast<float*>(running_mean); a.running_var = const_cast<float*>(running_var);      // read only (bn_from_running_kernel)
+    a.eps = eps; a.slope = slope; a.M = M; a.C = C; a.Mtot = M; a.res = res; a.ldres = ldres;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_from_running_kernel, dim3((unsigned)((C + BN_THREADS - 1) / BN_THREADS)), dim3(BN_THREADS), 0, st, a);
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, bn_grid(M, C, false), dim3(BN_THREADS), 0, st, a);
+    FORGE_LAUNCH_CHECK("forge_bn_eval_fwd");
     return 0;
 }
 

@@ -137,6 +137,46 @@ class _BNTrainRows(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, dres, None, None, None
 
 
+class _BNEvalRows(torch.autograd.Function):
+    """Eval-mode BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows [M, C] under autograd with trainable gamma / beta
+    (forge_bn_eval_fwd): running statistics read, never updated. Backward: dgamma / dbeta from forge_bn_sync_bwd_reduce, dx = gamma invstd g from
+    forge_bn_sync_bwd_apply with all-zero totals - the statistics do not depend on x."""
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, slope, residual):
+        M, C = x.shape
+        L, p = _lib.lib(), _lib.ptr
+        y = torch.empty(M, C, dtype=torch.float32, device=x.device)
+        mean, invstd = torch.empty(C, dtype=torch.float32, device=x.device), torch.empty(C, dtype=torch.float32, device=x.device)
+        res = None if residual is None else (residual if _rows_ok(residual, C) else residual.contiguous())
+        _lib.check(L.forge_bn_eval_fwd(p(x), x.stride(0), p(gamma), p(beta), p(running_mean), p(running_var), float(eps), float(slope), p(y), C, p(mean),
+                                       p(invstd), M, C, p(res), 0 if res is None else res.stride(0), _lib.current_stream()), "forge_bn_eval_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, y if res is not None else None)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @_lib.on_tensor_device
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd, y = ctx.saved_tensors
+        M, C = x.shape
+        L, p, st = _lib.lib(), _lib.ptr, _lib.current_stream
+        dy = dy if _rows_ok(dy, C) else dy.contiguous()
+        dx = torch.empty(M, C, dtype=torch.float32, device=x.device)
+        dres = torch.empty(M, C, dtype=torch.float32, device=x.device) if (y is not None and ctx.needs_input_grad[7]) else None
+        dg = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        db = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        if dg is not None or db is not None:
+            ws = torch.empty(L.forge_bn_ws_doubles(C), dtype=torch.float64, device=x.device)
+            _lib.check(L.forge_bn_sync_bwd_reduce(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dg), p(db), p(ws),
+                                                  M, C, p(y), C, st()), "forge_bn_sync_bwd_reduce")
+        zero = torch.zeros(2 * C, dtype=torch.float64, device=x.device)
+        _lib.check(L.forge_bn_sync_bwd_apply(p(dy), dy.stride(0), p(x), x.stride(0), p(gamma), p(beta), p(mean), p(invstd), ctx.slope, p(dx), C, p(zero),
+                                             M, M, C, p(y), C, p(dres), C, st()), "forge_bn_sync_bwd_apply")
+        return dx, dg, db, None, None, None, None, dres
+
+
 def _sync_world(bn):
     """World size of the SyncBatchNorm module's process group (1: not initialised / single process -> plain batch statistics)."""
     import torch.distributed as tdist
@@ -171,10 +211,21 @@ def bn_act_rows(bn, rows, slope=1.0, residual=None, stats=None):
     """BatchNorm module `bn` (+ `residual`, same shape as rows) + LeakyReLU(slope) (1 = none, 0 = ReLU) applied to channels-last rows [..., C].
     Train mode runs the HIP kernels of csrc/bnorm.hip - per-process batch statistics for nn.BatchNorm*, statistics over the module's process
     group for nn.SyncBatchNorm (one all-reduce of 2C+1 float64 forward, 2C backward: bn_rows_fwd / bn_rows_bwd), running statistics and
-    num_batches_tracked updated by the same launches; eval mode under autograd and a cumulative-average momentum keep the torch module (on an
-    NC... view of the same memory) followed by the residual add and the activation."""
+    num_batches_tracked updated by the same launches; eval mode under autograd (a fine-tune with frozen statistics) runs forge_bn_eval_fwd with
+    the running statistics (_BNEvalRows). One path: host tensors, C % 4 != 0 and a cumulative-average momentum (momentum=None) raise."""
     C = rows.shape[-1]
-    if bn_hip_train(bn, rows):
+    require_hip_input("BatchNorm on channels-last rows", rows)
+    if C % 4:
+        raise RuntimeError("forge_amd: the HIP BatchNorm kernels need a channel count that is a multiple of 4 (got %d)" % C)
+    if bn.training and bn.momentum is None and bn.track_running_stats:
+        raise RuntimeError("forge_amd: BatchNorm with momentum=None (cumulative moving average) is not implemented by the HIP kernels "
+                           "(the reference's modules use the default momentum 0.1)")
+    if not bn.training and bn.track_running_stats and bn.running_mean is not None:
+        x = rows.reshape(-1, C)
+        x = x if _rows_ok(x, C) else x.contiguous()
+        res = None if residual is None else residual.reshape(-1, C)
+        return _BNEvalRows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, slope, res).reshape(rows.shape)
+    if bn_hip_train(bn, rows) or not bn.track_running_stats or bn.running_mean is None:
         x = rows.reshape(-1, C)
         x = x if _rows_ok(x, C) else x.contiguous()
         rm, rv, mom, eps, nbt, group = bn_module_args(bn)
@@ -183,14 +234,7 @@ def bn_act_rows(bn, rows, slope=1.0, residual=None, stats=None):
         # SyncBatchNorm in a job with > 1 ranks (the reference's training configuration): statistics over all ranks, one all-reduce each way
         y = _BNTrainRows.apply(*args, group, stats if (stats is not None and stats.numel() and x.data_ptr() == rows.data_ptr()) else None)
         return y.reshape(rows.shape)
-    nd = rows.dim()
-    y = bn(rows.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1)
-    y = y if y.is_contiguous() else y.contiguous()
-    if residual is not None:
-        y = y + residual
-    if slope == 1.0:
-        return y
-    return torch.relu(y) if slope == 0.0 else torch.nn.functional.leaky_relu(y, slope)
+    raise RuntimeError("forge_amd: unsupported BatchNorm configuration %r" % (bn,))
 
 
 def require_hip_input(what, x, channels=None):

@@ -140,12 +140,15 @@ def predicted_camera_chain(pose_vec, to_se3, canonical_pose, canonical_extrinsic
 def canonical_cameras(owner, dataset, device):
     """(canonical pose, canonical extrinsics) of `dataset` on `device` (models/model.py:74-75), fetched ONCE per (dataset, device) and kept on
     the model `owner`: the dataset hands out host tensors, and a pageable host->device copy per forward synchronises the stream and cannot be
-    captured into a hipGraph."""
+    captured into a hipGraph. The cached copies are made with inference mode OFF: a first forward under torch.inference_mode() would otherwise
+    cache inference tensors, which a later training forward cannot save for backward."""
     cache = owner.__dict__.setdefault("_canon", {})
     key = (id(dataset), str(device))
     if key not in cache:
         cache.clear()                                                   # one dataset at a time; the entry keeps the dataset alive, so its id stays unique
-        cache[key] = (dataset.get_canonical_pose_cv2(device=device).to(torch.float32), dataset.get_canonical_extrinsics_cv2(device=device).to(torch.float32), dataset)
+        with torch.inference_mode(False):
+            own = lambda t: t.to(device=device, dtype=torch.float32).clone()      # clone: a normal tensor even if the dataset handed out an inference tensor
+            cache[key] = (own(dataset.get_canonical_pose_cv2(device=device)), own(dataset.get_canonical_extrinsics_cv2(device=device)), dataset)
     return cache[key][:2]
 
 

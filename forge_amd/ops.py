@@ -225,7 +225,8 @@ def resize_bilinear(x, Ho, Wo):
 def attention_applies(q, k, v):
     """forge_attention_fwd's domain: fp32 on the MI355X, no autograd graph wanted, one head of 64 channels, token counts multiples of 64,
     q / k [B,N,64] and v [B,Nk,64] or [1,Nk,64] (shared)."""
-    return (q.is_cuda and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and not torch.is_grad_enabled()
+    return (q.is_cuda and k.device == q.device and v.device == q.device                 # raw pointers go to the kernel: all three on q's HIP device
+            and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32 and not torch.is_grad_enabled()
             and q.dim() == 3 and k.dim() == 3 and v.dim() == 3 and q.shape[-1] == 64 and k.shape[-1] == 64 and v.shape[-1] == 64
             and q.shape[0] == k.shape[0] and v.shape[0] in (1, q.shape[0]) and v.shape[1] == k.shape[1]
             and q.shape[1] % 64 == 0 and k.shape[1] % 64 == 0 and q.shape[1] > 0 and k.shape[1] > 0)

@@ -5,7 +5,8 @@ blocks of models/model_utils.py:258-427 (einops is not required).
 On the MI355X every convolution of the module - the FPN's LeakyReLU ResNet-50, its lateral / top / smoothing layers and the four stride-2
 convolutions of `conv` - runs on libforge_hip.so with HIP BatchNorm (round 5; FPN.forward_rows, PoseEstimator2D._conv_rows; in eval mode without
 an autograd graph as the inference schedule of forge_amd/frozen.py: one launch per convolution, BatchNorm folded); the six attention
-blocks stay stock torch (rocBLAS GEMMs, softmax, LayerNorm). CPU tensors run the same modules on torch's own kernels."""
+blocks stay stock torch (rocBLAS GEMMs, softmax, LayerNorm). One path: host tensors raise (the stock-torch evaluation of the same modules that
+tests and probes compare against lives in tools/stock_pose.py)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -171,11 +172,8 @@ class FPN(_PackedModule):
                     nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="leaky_relu")
 
     def forward(self, x):
-        c4 = self.layer3(self.layer2(self.layer1(self.layer0(x))))
-        c5 = self.layer4(c4)
-        lat = self.latlayer1(c4)
-        p4 = F.interpolate(self.toplayer(c5), size=lat.shape[-2:], mode="bilinear", align_corners=False) + lat
-        return self.smooth1(p4)
+        """[n,3,H,W] -> p4 [n,256,H/16,W/16] (an NCHW view of forward_rows' NHWC rows)."""
+        return self.forward_rows(x).permute(0, 3, 1, 2)
 
     def forward_rows(self, x):
         """The same pyramid level as NHWC rows [n,h,w,256] on libforge_hip.so: the LeakyReLU ResNet-50 through encoder.resnet_rows_autograd (MFMA
@@ -185,6 +183,8 @@ class FPN(_PackedModule):
         from . import convops as co
         from . import frozen as fz
         from .encoder import resnet_rows_autograd
+        from .fusion import require_hip_input
+        require_hip_input("PoseEstimator2D's FPN", x)
         l0 = self.layer0
         if fz.frozen_ok(x, self):
             # inference: every convolution ONE launch with bias / folded BatchNorm / residual / LeakyReLU in its epilogue; the lateral convolution
@@ -245,23 +245,13 @@ class PoseEstimator2D(_PackedModule):
     def forward(self, x, return_features=False):
         """x [B,T,3,H,W] -> pose features [B(T-1),1024] or 7-D pose"""
         B, T, C, H, W = x.shape
-        hip = x.is_cuda and x.dtype == torch.float32 and not getattr(self, "force_stock_torch", False)
-        if hip:
-            feat = self.backbone.forward_rows(x.reshape(B * T, C, H, W))  # [B*T,h,w,256] NHWC rows
-            h2, w2 = feat.shape[1:3]
-            feat = feat.reshape(B, T, h2 * w2, 256)                       # [B,T,N,256]
-        else:
-            feat = self.backbone(x.reshape(B * T, C, H, W))               # [B*T,256,h,w]
-            h2, w2 = feat.shape[-2:]
-            feat = feat.reshape(B, T, 256, h2 * w2).permute(0, 1, 3, 2)   # [B,T,N,256]
+        feat = self.backbone.forward_rows(x.reshape(B * T, C, H, W))      # [B*T,h,w,256] NHWC rows (raises on host tensors)
+        h2, w2 = feat.shape[1:3]
+        feat = feat.reshape(B, T, h2 * w2, 256)                           # [B,T,N,256]
         pos = self.pos_emb.to(feat.device)
         feat_canonical = (feat[:, 0] + pos).to(feat.dtype)                # [B,N,256]
         feat = (feat[:, 1:] + pos.unsqueeze(1)).to(feat.dtype).reshape(B, (T - 1) * h2 * w2, 256)
         for cross, selfa in zip(self.cross_attn_blks, self.self_attn_blks):
             feat = selfa(cross(x_q=feat, x_k=feat_canonical, x_v=feat_canonical, residual=feat))
-        if hip:
-            feat = self._conv_rows(feat.reshape(B * (T - 1), h2, w2, 256)).reshape(B * (T - 1), -1).squeeze()
-        else:
-            feat = feat.reshape(B * (T - 1), h2, w2, 256).permute(0, 3, 1, 2)
-            feat = self.conv(feat).squeeze()
+        feat = self._conv_rows(feat.reshape(B * (T - 1), h2, w2, 256)).reshape(B * (T - 1), -1).squeeze()
         return feat if return_features else self.out(feat)

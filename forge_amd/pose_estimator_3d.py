@@ -47,7 +47,7 @@ class Attention(nn.Module):
 
     def forward(self, query, key, value):
         B, N, C = query.shape
-        if self.num_heads == 1 and not getattr(self, "force_stock_torch", False):
+        if self.num_heads == 1:
             from . import ops
             if ops.attention_applies(query, key, value):                  # inference on the MI355X: the N x N matrix never leaves registers
                 return ops.attention(query, key, value)
@@ -139,11 +139,13 @@ class PoseTransformer(nn.Module):
 
     def _pos_embed(self, like):
         """The positional table on `like`'s device / dtype, copied there ONCE per (device, dtype) - the reference copies the host tensor in every
-        forward (models/pose_estimator_3d.py:137), a pageable host->device copy that synchronises and cannot be captured into a hipGraph."""
+        forward (models/pose_estimator_3d.py:137), a pageable host->device copy that synchronises and cannot be captured into a hipGraph.
+        Copied with inference mode OFF, so that a table first built under torch.inference_mode() can still be saved for backward later."""
         cache = self.__dict__.setdefault("_pe_cache", {})
         key = (str(like.device), like.dtype)
         if key not in cache:
-            cache[key] = self.pos_embed_3d_coord.to(like)
+            with torch.inference_mode(False):
+                cache[key] = self.pos_embed_3d_coord.to(device=like.device, dtype=like.dtype).clone()
         return cache[key]
 
     def forward_tokens(self, q, k):
@@ -155,15 +157,14 @@ class PoseTransformer(nn.Module):
         return self.self_transformer.forward_tokens(coord, coord)
 
     def forward(self, q, k, q_pe=None, k_pe=None):
+        from . import ops
         pe = self._pos_embed(q)
-        if not getattr(self, "force_stock_torch", False):
-            from . import ops
-            qn, kn = self.cross_transformer._qk(q, k, None, None)        # [B,N,C] each
-            if ops.attention_applies(qn, kn, pe):
-                # inference on the MI355X: softmax(q k^T) pe in one launch instead of the [B,N,N] matrix + softmax + matmul
-                coord = ops.attention(qn, kn, pe).permute(0, 2, 1)            # [B,C,N]
-                return self.self_transformer(query=coord, key=coord)
-        attn = self.cross_transformer.get_attn(query=q, key=k)          # [B,N,N]
+        qn, kn = self.cross_transformer._qk(q, k, None, None)            # [B,N,C] each
+        if ops.attention_applies(qn, kn, pe):
+            # inference on the MI355X: softmax(q k^T) pe in one launch instead of the [B,N,N] matrix + softmax + matmul
+            coord = ops.attention(qn, kn, pe).permute(0, 2, 1)            # [B,C,N]
+            return self.self_transformer(query=coord, key=coord)
+        attn = self.cross_transformer.attn.get_attn(query=qn, key=kn)    # [B,N,N] (autograd path)
         coord = torch.matmul(attn, pe).permute(0, 2, 1)                  # [B,C,N]
         return self.self_transformer(query=coord, key=coord)
 
@@ -255,21 +256,9 @@ class PoseEstimator3D(co.PackedModule):
 
     def forward(self, features, return_features=False):
         """features [b,t,128,D,H,W] -> (pose [b(t-1),pose_dim], conf [b(t-1),1]) or the 1024-d features"""
-        b, t, C1, D1, H1, W1 = features.shape
-        stock = getattr(self, "force_stock_torch", False)                # tests / probes: every op of the module on torch's own kernels
-        for m in (self.pose_transformer, self.pose_transformer.cross_transformer.attn, self.pose_transformer.self_transformer.attn):
-            m.force_stock_torch = stock
-        if features.is_cuda and features.dtype == torch.float32 and not stock:
-            x = self.pose_head_2(self._forward_features_hip(features))
-        else:
-            x = self.conv3d_1(features.reshape(b * t, C1, D1, H1, W1))
-            _, C, D, H, W = x.shape
-            x = x.reshape(b, t, C, D * H * W)
-            ref = x[:, 0:1].repeat(1, t - 1, 1, 1).reshape(b * (t - 1), C, -1)
-            cur = x[:, 1:].reshape(b * (t - 1), C, -1)
-            x = self.pose_transformer(q=ref, k=cur).reshape(b * (t - 1), self.coord_dim, D, H, W)
-            x = self.conv3d_3(self.conv3d_2(x))
-            x = self.pose_head_2(self.pose_head_1(x).squeeze())
+        from .fusion import require_hip_input
+        require_hip_input("PoseEstimator3D", features)                   # one path; tools/stock_pose.py holds the stock-torch evaluation tests compare against
+        x = self.pose_head_2(self._forward_features_hip(features))
         if return_features:
             return x
         x = self.out(x)

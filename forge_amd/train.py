@@ -92,19 +92,11 @@ def compute_reconstruction_loss(config, epoch, sample, dataset, model, losses, d
     target_imgs = clips.reshape(b * t, c, h, w)
     rendered_imgs = rendered_imgs.reshape(b, 2 * t, c, h, w)
     rendered_masks = rendered_masks.reshape(b, 2 * t, 1, h, w)
-    if rendered_imgs.is_cuda:
-        # the four MSE terms (:26-29) as two fused passes over the rendered maps: no slicing / reshaping copies, one backward launch each
-        mi, mm = grouped_mse(rendered_imgs, clips, t), grouped_mse(rendered_masks, masks, t)
-        terms = {"recon_img_sv": config.loss.recon_rgb * mi[0], "recon_mask_sv": config.loss.recon_mask * mm[0],
-                 "recon_img_mv": config.loss.recon_rgb * mi[1], "recon_mask_mv": config.loss.recon_mask * mm[1]}
-    else:
-        target_masks = masks.reshape(b * t, 1, h, w)
-        terms = {
-            "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
-            "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
-            "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
-            "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
-        }
+    # the four MSE terms (:26-29) as two fused passes over the rendered maps: no slicing / reshaping copies, one backward launch each
+    # (grouped_mse raises on host tensors: one implementation, the CPU statement of these losses is the oracle's)
+    mi, mm = grouped_mse(rendered_imgs, clips, t), grouped_mse(rendered_masks, masks, t)
+    terms = {"recon_img_sv": config.loss.recon_rgb * mi[0], "recon_mask_sv": config.loss.recon_mask * mm[0],
+             "recon_img_mv": config.loss.recon_rgb * mi[1], "recon_mask_mv": config.loss.recon_mask * mm[1]}
     if config.loss.perceptual_img > 0:
         tgt = target_imgs.reshape(b, t, c, h, w).repeat(1, 2, 1, 1, 1).reshape(b * 2 * t, c, h, w)
         terms["perceptual_img"] = config.loss.perceptual_img * perceptual_loss(rendered_imgs.reshape(-1, c, h, w), tgt).mean()
@@ -121,18 +113,15 @@ def compute_all_loss_nvs(config, epoch, sample, dataset, model, losses, device, 
     t_all = t + clips_nvs.shape[1]
     rendered_imgs = rendered_imgs.reshape(b, t_all, c, h, w)
     rendered_masks = rendered_masks.reshape(b, t_all, 1, h, w)
-    if rendered_imgs.is_cuda and t_all == 2 * t:
+    if t_all == 2 * t:
         mi = grouped_mse(rendered_imgs, sample["images"].to(device), t)          # (input views, novel views) in one pass each
         mm = grouped_mse(rendered_masks, sample["fg_probabilities"].to(device), t)
-        recon = {"recon_img": config.loss.recon_rgb * mi[0], "recon_mask": config.loss.recon_mask * mm[0],
-                 "recon_img_nvs": config.loss.recon_rgb * mi[1], "recon_mask_nvs": config.loss.recon_mask * mm[1]}
-    else:
-        recon = {
-            "recon_img": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t], clips),
-            "recon_mask": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t], masks),
-            "recon_img_nvs": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:], clips_nvs),
-            "recon_mask_nvs": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:], masks_nvs),
-        }
+    else:                                                                         # another number of novel views: one group per call, same kernel
+        n = t_all - t
+        mi = (grouped_mse(rendered_imgs[:, :t], clips, t)[0], grouped_mse(rendered_imgs[:, t:], clips_nvs, n)[0])
+        mm = (grouped_mse(rendered_masks[:, :t], masks, t)[0], grouped_mse(rendered_masks[:, t:], masks_nvs, n)[0])
+    recon = {"recon_img": config.loss.recon_rgb * mi[0], "recon_mask": config.loss.recon_mask * mm[0],
+             "recon_img_nvs": config.loss.recon_rgb * mi[1], "recon_mask_nvs": config.loss.recon_mask * mm[1]}
     terms = dict(recon, pose=F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]), trans=F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]))
     if config.loss.perceptual_img > 0:
         tgt = torch.cat([clips, clips_nvs], dim=1).reshape(b * t_all, c, h, w)
@@ -164,14 +153,13 @@ def compute_all_loss(config, epoch, sample, dataset, model, losses, device, perc
     clips = sample["images"].to(device)
     masks = sample["fg_probabilities"].to(device)
     b, t, c, h, w = clips.shape
-    target_imgs, target_masks = clips.reshape(b * t, c, h, w), masks.reshape(b * t, 1, h, w)
+    target_imgs = clips.reshape(b * t, c, h, w)
     rendered_imgs = rendered_imgs.reshape(b, 2 * t, c, h, w)
     rendered_masks = rendered_masks.reshape(b, 2 * t, 1, h, w)
+    mi, mm = grouped_mse(rendered_imgs, clips, t), grouped_mse(rendered_masks, masks, t)
     terms = {
-        "recon_img_sv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, :t].reshape(-1, c, h, w), target_imgs),
-        "recon_mask_sv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, :t].reshape(-1, 1, h, w), target_masks),
-        "recon_img_mv": config.loss.recon_rgb * F.mse_loss(rendered_imgs[:, t:].reshape(-1, c, h, w), target_imgs),
-        "recon_mask_mv": config.loss.recon_mask * F.mse_loss(rendered_masks[:, t:].reshape(-1, 1, h, w), target_masks),
+        "recon_img_sv": config.loss.recon_rgb * mi[0], "recon_mask_sv": config.loss.recon_mask * mm[0],
+        "recon_img_mv": config.loss.recon_rgb * mi[1], "recon_mask_mv": config.loss.recon_mask * mm[1],
         "pose": F.mse_loss(pose["pred"][:, :4], pose["gt"][:, :4]),
         "trans": F.mse_loss(pose["pred"][:, 4:], pose["gt"][:, 4:]),
     }
@@ -218,8 +206,8 @@ def clip_grad_norm_(parameters, max_norm):
     group, which is the conversion the per-tensor `mul_` performs on the scalar operand anyway. Returns the total norm."""
     params = [p for p in ([parameters] if torch.is_tensor(parameters) else parameters) if p.grad is not None]
     grads = [p.grad for p in params]
-    if not grads or not all(g.is_cuda for g in grads):
-        return torch.nn.utils.clip_grad_norm_(params, max_norm=max_norm, norm_type=2.0)
+    if not grads:
+        return torch.zeros(())
     with torch.no_grad():
         groups = {}
         for g in grads:

@@ -360,6 +360,14 @@ int forge_bn_sync_stats(const float* x, int ldx, double* ws, long long M, int C,
 int forge_bn_sync_fwd_apply(const float* x, int ldx, const float* gamma, const float* beta, float eps, float slope, float* y, int ldy,
                             float* mean, float* invstd, float* running_mean, float* running_var, float momentum, const double* totals,
                             long long M_total, long long M, int C, const float* res, int ldres, long long* num_batches_tracked, forge_stream_t stream);
+/* Eval-mode BatchNorm (+ residual) + LeakyReLU(slope) on channels-last rows UNDER AUTOGRAD with trainable gamma / beta (a fine-tune that keeps
+ * BatchNorm layers in eval mode: torch's F.batch_norm(training=False), which the reference reaches through nn.BatchNorm*.forward):
+ * mean = running_mean, invstd = 1 / sqrt(running_var + eps) are written for the backward, the running statistics are only read.
+ * Backward = forge_bn_sync_bwd_reduce (dgamma, dbeta) + forge_bn_sync_bwd_apply with all-zero totals (dx = gamma invstd g: the statistics
+ * do not depend on x). */
+int forge_bn_eval_fwd(const float* x, int ldx, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, float slope, float* y, int ldy, float* mean, float* invstd, long long M, int C, const float* res, int ldres,
+                      forge_stream_t stream);
 int forge_bn_sync_bwd_reduce(const float* dy, int lddy, const float* x, int ldx, const float* gamma, const float* beta, const float* mean,
                              const float* invstd, float slope, float* dgamma, float* dbeta, double* ws, long long M, int C,
                              const float* y, int ldy, forge_stream_t stream);

@@ -4,7 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):      # tools/: stock_pose (stock-torch yardstick of the pose estimators)
     if p not in sys.path:
         sys.path.insert(0, p)
 

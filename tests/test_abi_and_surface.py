@@ -222,32 +222,21 @@ def test_plan_model_replica_of_the_fitting_tool_matches_the_library():
     assert n == 405
 
 
-def test_loss_functions_match_reference_golden():
-    """f1: forge_amd.train's four loss functions against the values the REFERENCE's scripts/kubric_compute_loss.py produced on the same
-    tensors through a stub model (tests/golden/loss_terms.npz, generated by oracle/make_golden.py)."""
+def test_loss_functions_refuse_host_tensors():
+    """f1 / north_star "no dual code paths": the loss functions have ONE implementation (csrc/loss.hip through train.grouped_mse); rendered maps on
+    the host raise instead of taking a stock F.mse_loss detour. Their values are pinned against the reference's own numbers on the GPU
+    (tests/test_gpu_parity.py::test_loss_functions_match_reference_golden)."""
     import types
-    import numpy as np
     from forge_amd import train as tr
-    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_terms.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
-    sample10 = {"images": T("images"), "fg_probabilities": T("fg")}
-    sample5 = {k: v[:, :5].contiguous() for k, v in sample10.items()}
-    pose = {"pred": T("pose_pred"), "gt": T("pose_gt")}
-    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(recon_rgb=float(gold["recon_rgb"]), recon_mask=float(gold["recon_mask"]),
-                                                           perceptual_img=0.0, regu_origin_proj=float(gold["regu_origin_proj"])))
-    cases = {
-        "recon": (tr.compute_reconstruction_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"))),
-        "pose": (tr.compute_pose_loss, sample5, lambda s, d, dev: (pose, T("origin"))),
-        "all": (tr.compute_all_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
-        "all_nvs": (tr.compute_all_loss_nvs, sample10, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
-    }
-    for name, (fn, smp, model) in cases.items():
-        loss, terms, _, _ = fn(cfg, 0, smp, None, model, {}, "cpu", None)
-        assert abs(float(loss) - float(gold["total_" + name])) < 1e-5 * max(1.0, abs(float(gold["total_" + name]))), name
-        ref_terms = {k.split("__", 1)[1]: float(gold[k]) for k in gold.files if k.startswith(name + "__")}
-        assert set(terms) == set(ref_terms), (name, sorted(terms), sorted(ref_terms))
-        for k, v in ref_terms.items():
-            assert abs(terms[k] - v) < 1e-5 * max(1.0, abs(v)), (name, k)
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(recon_rgb=5.0, recon_mask=1.0, perceptual_img=0.0, regu_origin_proj=0.0))
+    smp = {"images": torch.zeros(1, 10, 3, 8, 8), "fg_probabilities": torch.zeros(1, 10, 1, 8, 8)}
+    pose = {"pred": torch.zeros(4, 7), "gt": torch.zeros(4, 7)}
+    s5 = {k: v[:, :5] for k, v in smp.items()}
+    for fn, sample, model in ((tr.compute_reconstruction_loss, s5, lambda s, d, dev: (torch.zeros(10, 3, 8, 8), torch.zeros(10, 1, 8, 8))),
+                              (tr.compute_all_loss, s5, lambda s, d, dev: (torch.zeros(10, 3, 8, 8), torch.zeros(10, 1, 8, 8), torch.zeros(5, 2), pose)),
+                              (tr.compute_all_loss_nvs, smp, lambda s, d, dev: (torch.zeros(10, 3, 8, 8), torch.zeros(10, 1, 8, 8), torch.zeros(5, 2), pose))):
+        with pytest.raises(TypeError, match="on the MI355X"):
+            fn(cfg, 0, sample, None, model, {}, "cpu", None)
 
 
 def test_packed_caches_are_dropped_on_mode_load_and_apply():

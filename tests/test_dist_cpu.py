@@ -113,39 +113,52 @@ def test_ray_sharded_render_world2():
         assert max(errs) < 1e-6
 
 
-def test_bench_entry_launches_its_own_ranks_dry_run():
+def test_bench_entry_launches_its_own_ranks_dry_run(tmp_path):
     """`python bench.py --gpus 8` (no torchrun environment) must start 8 ranks itself and report n_gpus: 8 - here as the
     CPU/gloo rehearsal of exactly that entry (`--dry-run`: launch, rendezvous on 127.0.0.1, barrier, MAX / SUM reductions, one JSON
     line from rank 0) - and must FAIL when the launch environment's world size contradicts --gpus."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "2", "--dry-run"],
+    full = str(tmp_path / "full.json")
+
+    def strict_line(stdout):
+        """The driver's view: the LAST stdout line, under 4 KB, strict JSON (no NaN / Infinity tokens)."""
+        out_lines = stdout.splitlines()
+        assert [l for l in out_lines if l.startswith("{")] == [out_lines[-1]], stdout
+        assert len(out_lines[-1]) < 4096
+
+        def refuse(tok):
+            raise AssertionError("non-strict JSON token %s" % tok)
+        return json.loads(out_lines[-1], parse_constant=refuse)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "2", "--dry-run", "--full-record", full],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    c = strict_line(r.stdout)
+    assert c["n_gpus"] == 8 and c["dry_run"] is True and c["ranks_ok"] == 8 and c["full_record"] == full
+    assert set(c["multi_rank"]) == {"ddp_train", "failing_record", "ray_sharded_joint"} and c["multi_rank"]["ddp_train"][3] == 8
+    assert c["multi_rank"]["failing_record"][3] == 7
+    d = json.load(open(full))                                            # every detail lives in the full record
     assert d["n_gpus"] == 8 and d["dry_run"] is True and d["views_counted"] == 8 * 2 * 5 * 3 and d["steps"] == 3
     assert d["ranks_ok"] == 8 and d["error"] is None
-    # the sub-record skeleton of the real multi-rank line (bench.multi_rank_records; VERDICT r4 item 2), rehearsed with token workloads: a DDP step
+    # the sub-record skeleton of the real multi-rank line (benchkit.multirank.multi_rank_records; VERDICT r4 item 2), rehearsed with token workloads: a DDP step
     # with and without no_sync(), a record that fails on ONE rank (reported, the line and the other records survive), the ray-sharded render op
     m = d["multi_rank"]
     assert m["ddp_train"]["ranks_ok"] == 8 and m["ddp_train"]["ms_per_step"] > 0 and m["ddp_train"]["ms_per_step_no_sync"] > 0
     assert m["failing_record"]["ranks_ok"] == 7 and len(m["failing_record"]["errors"]) == 1 and "rank 7" in m["failing_record"]["errors"][0]
     assert m["ray_sharded_joint"]["ranks_ok"] == 8 and m["ray_sharded_joint"]["rows"] == 16 and m["ray_sharded_joint"]["d_feat"] == m["ray_sharded_joint"]["expected_d_feat"]
     # a sub-record that never comes back: the watchdog prints the MAIN line and every rank leaves with exit code 0
-    w = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run", "--rehearse-hang"],
+    w = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-run", "--rehearse-hang", "--full-record", full],
                        capture_output=True, text=True, timeout=300, env=dict(env, FORGE_BENCH_SUBRECORD_DEADLINE_S="3"), cwd=ROOT)
     assert w.returncode == 0, w.stderr[-2000:]
-    dw = json.loads([l for l in w.stdout.splitlines() if l.startswith("{")][0])
+    dw = strict_line(w.stdout)
     assert dw["n_gpus"] == 2 and "did not finish" in dw["multi_rank"]["error"]
     # --train rehearsal: the same entry wraps a model in DistributedDataParallel over the 8 ranks (gloo here, RCCL on the node), steps it, and
     # the replicas end up identical on every rank
-    t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "4", "--dry-run", "--train"],
+    t = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--scenes", "4", "--dry-run", "--train", "--full-record", full],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert t.returncode == 0, t.stderr[-2000:]
-    dt_ = json.loads([l for l in t.stdout.splitlines() if l.startswith("{")][0])
+    dt_ = strict_line(t.stdout)
     assert dt_["n_gpus"] == 8 and dt_["train"] is True and dt_["ranks_ok"] == 8 and dt_["replicas_identical"] is True
     assert dt_["views_counted"] == 8 * 4 * 10 * 3
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,

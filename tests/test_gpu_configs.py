@@ -13,6 +13,7 @@ import torch
 
 import forge_oracle as fo
 import kat_render
+import stock_pose
 from forge_amd import geo_utils, ops, synthetic as syn
 from test_gpu_parity import assert_forward_close
 
@@ -323,7 +324,7 @@ def test_pose_estimators_hip_convolutions_vs_float64_and_stock_torch(dev):
     convolutions run on libforge_hip.so instead of MIOpen's naive fp32 kernels (164 + 21 ms of the 256 ms joint step). Both modules, train mode
     (BatchNorm batch statistics) and eval mode, forward features + gradients of the input and of a parameter from every block, against the SAME
     module evaluated in float64 on the CPU - and, as the yardstick, the stock-torch path on the GPU against the same float64 result
-    (`force_stock_torch`): the HIP path has to stay within 3x the stock path's distance (+ 2e-5 of max) in eval mode and within 4x (+ 1e-3) in train
+    (tools/stock_pose.py): the HIP path has to stay within 3x the stock path's distance (+ 2e-5 of max) in eval mode and within 4x (+ 1e-3) in train
     mode, where the last BatchNorm layers normalise over 2-16 values per channel and amplify any rounding difference chaotically (both paths
     sit 0.3-2e-2 from float64 there)."""
     import copy
@@ -332,9 +333,9 @@ def test_pose_estimators_hip_convolutions_vs_float64_and_stock_torch(dev):
     torch.manual_seed(3)
     rel = lambda got, want: (got.detach().double().cpu() - want.detach()).abs().max().item() / max(want.detach().abs().max().item(), 1e-30)
 
-    def run(mod, x, keys):
+    def run(mod, x, keys, stock=False):
         x = x.clone().requires_grad_(True)
-        out = mod(x, return_features=True)
+        out = (stock_pose.stock_forward(mod) if stock else mod)(x, return_features=True)
         out.square().sum().backward()
         named = dict(mod.named_parameters())
         res = [out.detach(), x.grad] + [named[k].grad for k in keys]
@@ -362,12 +363,11 @@ def test_pose_estimators_hip_convolutions_vs_float64_and_stock_torch(dev):
                 for k, v in list(vars(m).items()):
                     if torch.is_tensor(v) and v.is_floating_point():
                         setattr(m, k, v.double())
-            ref = run(ref_mod, x.double(), keys)
+            ref = run(ref_mod, x.double(), keys, stock=True)
             g = copy.deepcopy(mod).to(dev)
             hip = run(g, x.to(dev), keys)
             g2 = copy.deepcopy(mod).to(dev)
-            g2.force_stock_torch = True
-            stock = run(g2, x.to(dev), keys)
+            stock = run(g2, x.to(dev), keys, stock=True)
             for name, a, b_, r in zip(["features", "d input"] + keys, hip, stock, ref):
                 if a is None and name == "d input" and isinstance(mod, PoseEstimator2D):
                     continue                                               # the HIP stem gathers its patches from the detached image: no d(image), as in the encoder's trunk
@@ -401,7 +401,7 @@ def test_pose_estimators_inference_schedule_vs_float64_stock_torch_and_autograd_
                 if torch.is_tensor(v) and v.is_floating_point():
                     setattr(m, k, v.double())
         with torch.no_grad():
-            ref = ref_mod(x.double(), return_features=True)
+            ref = stock_pose.stock_forward(ref_mod)(x.double(), return_features=True)
         g = copy.deepcopy(mod).to(dev)
         xd = x.to(dev)
         assert fz.frozen_ok(xd, g) is False                                  # autograd on: not the inference schedule
@@ -410,9 +410,8 @@ def test_pose_estimators_inference_schedule_vs_float64_stock_torch_and_autograd_
             fro = g(xd, return_features=True)
         auto = g(xd, return_features=True)                                   # grad mode: convops.conv*_rows + bn_act_rows
         g2 = copy.deepcopy(mod).to(dev)
-        g2.force_stock_torch = True
         with torch.no_grad():
-            stock = g2(xd, return_features=True)
+            stock = stock_pose.stock_forward(g2)(xd, return_features=True)
         ef, es, ea = rel(fro, ref), rel(stock, ref), rel(fro, auto)
         if os.environ.get("FORGE_TEST_REPORT"):
             print("  %-16s inference schedule/f64 %.2e  stock/f64 %.2e  schedule/autograd path %.2e" % (type(mod).__name__, ef, es, ea))

@@ -183,7 +183,19 @@ def test_ray_sharded_render_two_ranks_on_the_gpu():
         assert shapes == [(3, 16, 128, 128), (3, 1, 128, 128), (3, 1, 128, 128)]
 
 
-def test_bench_entry_two_ranks_on_the_shared_gpu():
+def _driver_line(stdout):
+    """bench.py's stdout as the driver reads it: the last line, the only JSON line, under 4 KB, strict JSON."""
+    import json
+    lines = stdout.splitlines()
+    assert [l for l in lines if l.startswith("{")] == [lines[-1]], stdout[-3000:]
+    assert len(lines[-1]) < 4096
+
+    def refuse(tok):
+        raise AssertionError("non-strict JSON token %s" % tok)
+    return json.loads(lines[-1], parse_constant=refuse)
+
+
+def test_bench_entry_two_ranks_on_the_shared_gpu(tmp_path):
     """`python bench.py --gpus 2` (no torchrun environment) on the one-GPU test box: the entry starts its own two ranks, each captures its
     hipGraph BEFORE the process group exists, the ranks rendezvous (gloo here: two ranks on one device; RCCL on a real node), time the step
     between barriers, all-reduce time / SSE / view counts, and rank 0 prints one line with n_gpus = 2 and twice the per-rank views. Without
@@ -193,14 +205,18 @@ def test_bench_entry_two_ranks_on_the_shared_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-microbench"]
+    full = str(tmp_path / "full.json")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-microbench", "--full-record", full]
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert bad.returncode != 0 and "GPU(s) visible" in (bad.stderr + bad.stdout)
     ok = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=root)
     assert ok.returncode == 0, ok.stderr[-2000:]
-    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    c = _driver_line(ok.stdout)                                              # what the driver parses: compact, strict, last
+    assert c["n_gpus"] == 2 and c["value"] > 0 and c["ranks_ok"] == 2 and "cpu_baseline" not in c and c["roofline"]["bound"] == "mfma"
+    assert c["multi_rank"]["ddp_train"][0] > 0 and c["multi_rank"]["ddp_train"][1] > 200 and c["multi_rank"]["ddp_train"][3] == 2
+    assert c["strong_scaling"]["total_scenes"] == 8
+    d = json.load(open(full))                                                # the full record
+    assert d["value"] == pytest.approx(c["value"], rel=1e-3)
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "cpu_baseline" not in d and d["ranks_ok"] == 2 and not d["errors"]
     assert d["strong_scaling"]["total_scenes"] == 8 and d["strong_scaling"]["scenes_per_gpu"] == 4 and d["strong_scaling"]["ranks_ok"] == 2
     assert abs(d["value"] - 2 * 5 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]          # whole-job views / max-over-ranks time
@@ -487,14 +503,14 @@ def test_bench_train_mode_two_ranks_and_n1_paths_agree():
     tr = subprocess.run([sys.executable, bench, "--gpus", "2", "--train", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=1200,
                         env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=ROOT)
     assert tr.returncode == 0, tr.stderr[-3000:]
-    d = json.loads([l for l in tr.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["ranks_ok"] == 2 and not d["errors"] and d["value"] > 0 and d["config"]["global_batch"] == 2
+    d = _driver_line(tr.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_ok"] == 2 and not d.get("errors") and d["value"] > 0 and d["config"]["global_batch"] == 2
     # configs[3]'s real per-GPU shape through the same entry: --grid 64 (128^3-voxel render grid from synthetic 64^3 feature volumes in the sample)
     t64 = subprocess.run([sys.executable, bench, "--gpus", "2", "--train", "--grid", "64", "--steps", "1", "--warmup", "1", "--repeats", "1"], capture_output=True,
                          text=True, timeout=1200, env=dict(env, FORGE_BENCH_ALLOW_SHARED_GPUS="1"), cwd=ROOT)
     assert t64.returncode == 0, t64.stderr[-3000:]
-    d64 = json.loads([l for l in t64.stdout.splitlines() if l.startswith("{")][0])
-    assert d64["n_gpus"] == 2 and d64["ranks_ok"] == 2 and not d64["errors"] and d64["value"] > 0 and d64["config"]["feature_grid"] == 64 and "128^3" in d64["metric"]
+    d64 = _driver_line(t64.stdout)
+    assert d64["n_gpus"] == 2 and d64["ranks_ok"] == 2 and not d64.get("errors") and d64["value"] > 0 and d64["config"]["feature_grid"] == 64 and "128^3" in d64["metric"]
     quick = ["--steps", "3", "--warmup", "1", "--no-microbench", "--no-cpu-baseline", "--no-extra"]
     plain = subprocess.run([sys.executable, bench, "--gpus", "1"] + quick, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert plain.returncode == 0, plain.stderr[-2000:]
@@ -502,7 +518,7 @@ def test_bench_train_mode_two_ranks_and_n1_paths_agree():
     launched = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                                "--master-port", str(port), bench, "--gpus", "1"] + quick, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert launched.returncode == 0, launched.stderr[-2000:]
-    a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]) for r in (plain, launched))
+    a, b = (_driver_line(r.stdout) for r in (plain, launched))
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
     assert abs(a["value"] - b["value"]) < 0.15 * a["value"], (a["value"], b["value"])
 
@@ -540,7 +556,7 @@ dist.destroy_process_group()
 
 
 def test_multi_rank_bench_records_run_on_rccl_with_one_rank():
-    """The sub-records of `bench.py --gpus N` (bench.ddp_train_record, bench.ray_sharded_joint_record) on the REAL backend: the test box has one GPU, so the
+    """The sub-records of `bench.py --gpus N` (benchkit.multirank.ddp_train_record / ray_sharded_joint_record) on the REAL backend: the test box has one GPU, so the
     2-rank tests above run their collectives over gloo; here the same two functions run in a subprocess whose default process group is RCCL (backend "nccl",
     world size 1) - DistributedDataParallel's reducer (bucketed all-reduce of this package's gradients, find_unused_parameters, no_sync), SyncBatchNorm-converted
     modules, `train.train_step`'s sample broadcast and loss all-reduce, and `multi_rank_records`' own gathers all go through the RCCL communicator."""
@@ -553,7 +569,7 @@ os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 torch.cuda.set_device(0)
 dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
-import bench
+from benchkit import multirank as bench
 dev = torch.device("cuda", 0)
 args = types.SimpleNamespace(steps=2)
 rec = bench.multi_rank_records(args, 0, 1, dev, {"metric": "rehearsal"}, records=(

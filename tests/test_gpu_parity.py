@@ -64,7 +64,7 @@ def test_rotate_identity_quirk_d32(dev, golden):
     assert (out[:, 1] - vox[:, 1]).abs().max().item() > 0.3      # identity pose is NOT an identity resample
 
 
-@pytest.mark.parametrize("D,C,B,t", [(16, 8, 2, 3), (32, 128, 1, 5), (48, 4, 1, 2), (64, 16, 1, 2)])
+@pytest.mark.parametrize("D,C,B,t", [(16, 8, 2, 3), (32, 128, 1, 5), (48, 4, 1, 2), (64, 16, 1, 2), (128, 4, 1, 2)])    # every grid of models/rotate.py:18-35
 def test_rotate_vs_oracle(dev, D, C, B, t):
     from forge_amd.rotate import Rotate_world
     g = torch.Generator().manual_seed(D + C)
@@ -1806,3 +1806,43 @@ def test_pose_refinement_two_instances_in_flight_match_sequential_runs(dev):
         e0, e1 = refine.pose_errors(init, gt), refine.pose_errors(got, gt)
         assert e1[0].mean().item() < e0[0].mean().item()
     print("refinement, 2 instances in flight: %.2f ms per iteration and instance (t = 3 views)" % (dt * 1e3))
+
+
+def test_loss_functions_match_reference_golden(dev):
+    """f1: forge_amd.train's four loss functions against the values the REFERENCE's scripts/kubric_compute_loss.py produced on the same
+    tensors through a stub model, on the MI355X: the MSE terms are csrc/loss.hip launches (train.grouped_mse) (tests/golden/loss_terms.npz, generated by oracle/make_golden.py)."""
+    import types
+    import numpy as np
+    from forge_amd import train as tr
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss_terms.npz"))
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
+    sample10 = {"images": T("images"), "fg_probabilities": T("fg")}
+    sample5 = {k: v[:, :5].contiguous() for k, v in sample10.items()}
+    pose = {"pred": T("pose_pred"), "gt": T("pose_gt")}
+    cfg = types.SimpleNamespace(loss=types.SimpleNamespace(recon_rgb=float(gold["recon_rgb"]), recon_mask=float(gold["recon_mask"]),
+                                                           perceptual_img=0.0, regu_origin_proj=float(gold["regu_origin_proj"])))
+    cases = {
+        "recon": (tr.compute_reconstruction_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"))),
+        "pose": (tr.compute_pose_loss, sample5, lambda s, d, dev: (pose, T("origin"))),
+        "all": (tr.compute_all_loss, sample5, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
+        "all_nvs": (tr.compute_all_loss_nvs, sample10, lambda s, d, dev: (T("r_img"), T("r_msk"), T("origin"), pose)),
+    }
+    for name, (fn, smp, model) in cases.items():
+        loss, terms, _, _ = fn(cfg, 0, smp, None, model, {}, dev, None)
+        assert abs(float(loss) - float(gold["total_" + name])) < 1e-5 * max(1.0, abs(float(gold["total_" + name]))), name
+        ref_terms = {k.split("__", 1)[1]: float(gold[k]) for k in gold.files if k.startswith(name + "__")}
+        assert set(terms) == set(ref_terms), (name, sorted(terms), sorted(ref_terms))
+        for k, v in ref_terms.items():
+            assert abs(terms[k] - v) < 1e-5 * max(1.0, abs(v)), (name, k)
+    # a joint sample with another number of novel views (5 input + 3 novel): the same kernel, one group per call, against torch's own MSE
+    import torch.nn.functional as Fn
+    s8 = {k: v[:, :8].contiguous() for k, v in sample10.items()}
+    nb = s8["images"].shape[0]
+    r_img, r_msk = T("r_img").reshape(nb, 10, 3, *T("r_img").shape[-2:])[:, :8], T("r_msk").reshape(nb, 10, 1, *T("r_msk").shape[-2:])[:, :8]
+    model8 = lambda s, d, dv: (r_img.reshape(nb * 8, 3, *r_img.shape[-2:]), r_msk.reshape(nb * 8, 1, *r_msk.shape[-2:]), T("origin"), pose)
+    _, terms8, _, _ = tr.compute_all_loss_nvs(cfg, 0, s8, None, model8, {}, dev, None)
+    want = {"recon_img": cfg.loss.recon_rgb * Fn.mse_loss(r_img[:, :5], s8["images"][:, :5]), "recon_img_nvs": cfg.loss.recon_rgb * Fn.mse_loss(r_img[:, 5:], s8["images"][:, 5:]),
+            "recon_mask": cfg.loss.recon_mask * Fn.mse_loss(r_msk[:, :5], s8["fg_probabilities"][:, :5]),
+            "recon_mask_nvs": cfg.loss.recon_mask * Fn.mse_loss(r_msk[:, 5:], s8["fg_probabilities"][:, 5:])}
+    for k, v in want.items():
+        assert abs(terms8[k] - float(v)) < 1e-5 * max(1.0, abs(float(v))), k

@@ -221,13 +221,16 @@ def test_pytorch3d_shim_reproduces_analytic_kats_on_non_square_targets():
 
 
 def test_pose_estimators_reproduce_reference_predictions(golden):
-    """forge_amd/pose_estimator_{2d,3d}.py + pose_head + geo_utils (stock torch, CPU here) on the oracle's encoder features reproduce
+    """forge_amd/pose_estimator_{2d,3d}.py's MODULES (their nn sub-modules and weights evaluated by tools/stock_pose.py on the CPU: the architecture
+    pin; the product's HIP path is pinned against the same fixture by test_forge_joint_forward_vs_reference_golden on the GPU) + pose_head +
+    geo_utils on the oracle's encoder features reproduce
     the pose vectors / confidences the REFERENCE's FORGE (use_gt_pose=False) and FORGE_poseEstimator3D(use_gt_pose=False) predicted on
     the same seeded sample and weights (tests/golden/forward_joint.npz, oracle/make_golden.py::joint_goldens), and the projected
     origins of the predicted cameras."""
     from forge_amd import geo_utils
     from forge_amd.model import FORGE
     from forge_amd.model_single_pose_estimator import FORGE_poseEstimator3D
+    import stock_pose
     g = golden("forward_joint")
     sample = syn.make_sample(1, 10, 256, 1.5, seed=int(g["sample_seed"]))
     ds = syn.SyntheticDataset(1.5)
@@ -240,10 +243,10 @@ def test_pose_estimators_reproduce_reference_predictions(golden):
         with torch.no_grad():
             f3 = fo.get_feat3D(clips.reshape(5, 3, 256, 256), w).reshape(1, 5, 128, 32, 32, 32)
             if cls is FORGE:
-                pf = torch.cat([model.encoder_traj(f3, return_features=True), model.encoder_traj_2d(clips, return_features=True)], dim=-1)
+                pf = torch.cat([stock_pose.features_3d(model.encoder_traj, f3), stock_pose.features_2d(model.encoder_traj_2d, clips)], dim=-1)
                 pose, conf = model.pose_head(pf).split([model.encoder_traj.pose_dim, 1], dim=-1)
             else:
-                pose, conf = model.encoder_traj(f3)
+                pose, conf = stock_pose.forward_3d(model.encoder_traj, f3)
             pose, poses, extr = geo_utils.predicted_camera_chain(pose, model.encoder_traj.toSE3, ds.get_canonical_pose_cv2(),
                                                                  ds.get_canonical_extrinsics_cv2(), 1, 5)
             oproj = model.render.proj_origin(geo_utils.camera_dict(extr, sample["K_cv2"][:, :5]), "cpu") * 2 / cfg.dataset.img_size

@@ -62,9 +62,9 @@ for gt in ((False,) if TRACE_STEPS else (False, True)):
         with torch.no_grad():
             t3 = timed(lambda: model.encoder_traj(feats, return_features=True))
             t2 = timed(lambda: model.encoder_traj_2d(clips, return_features=True))
-            model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = True
-            s3 = timed(lambda: model.encoder_traj(feats, return_features=True))
-            s2 = timed(lambda: model.encoder_traj_2d(clips, return_features=True))
-            model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = False
+            import stock_pose                                         # tools/stock_pose.py: the same modules on torch's own kernels
+            with stock_pose.patched(model.encoder_traj, model.encoder_traj_2d):
+                s3 = timed(lambda: model.encoder_traj(feats, return_features=True))
+                s2 = timed(lambda: model.encoder_traj_2d(clips, return_features=True))
         print("  alone, eager: 3-D pose estimator %.2f ms (stock torch %.2f), 2-D pose estimator %.2f ms (stock torch %.2f)" % (t3, s3, t2, s2))
     print("FORGE inference, %s poses, 10 rendered views: eager %.2f ms, hipGraph replay %s" % ("GT" if gt else "predicted", e, r if isinstance(r, str) else "%.2f ms" % r))

@@ -26,7 +26,9 @@ model = FORGE(cfg)
 model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
 model = model.to(dev).train()
 if os.environ.get("JOINT_STOCK") == "1":       # the round-4 state: both pose estimators entirely on stock torch kernels (MIOpen / rocBLAS)
-    model.encoder_traj.force_stock_torch = model.encoder_traj_2d.force_stock_torch = True
+    import stock_pose                           # tools/stock_pose.py (this script's own directory is on sys.path)
+    for _m in (model.encoder_traj, model.encoder_traj_2d):
+        _m.forward = stock_pose.stock_forward(_m)
 params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render) for p in m.parameters()]
 opt = torch.optim.Adam(params, lr=1e-4, fused=True)
 sample = {k: v.to(dev) for k, v in syn.make_sample(scenes, 10, 256, 1.5, seed=12).items()}

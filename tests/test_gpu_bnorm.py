@@ -111,11 +111,30 @@ def test_bn_train_residual_form_forward_backward(shape, slope):
     assert (hb.bias.grad.double().cpu() - ref_bn.bias.grad).abs().max().item() < 2e-5 * max(1.0, ref_bn.bias.grad.abs().max().item())
     assert (hb.running_var.double().cpu() - ref_bn.running_var).abs().max().item() < 1e-5
     assert int(hb.num_batches_tracked) == 1
-    # eval mode under autograd (the torch module + add + activation) gives the same function of (x, residual)
+    # eval mode under autograd with trainable gamma / beta (a fine-tune with frozen statistics): forge_bn_eval_fwd + the sync-backward kernels with zero
+    # totals (_BNEvalRows) - output and every gradient against the torch module in float64; the running statistics are read, never updated
     he = copy.deepcopy(hb).eval()
-    ye = bn_act_rows(he, xd.detach(), slope, residual=rd.detach())
-    re = he(xd.detach().permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + rd.detach()
-    assert torch.equal(ye, torch.relu(re) if slope == 0.0 else torch.nn.functional.leaky_relu(re, slope))
+    for p in he.parameters():
+        p.grad = None
+    rm0, rv0, nbt0 = he.running_mean.clone(), he.running_var.clone(), int(he.num_batches_tracked)
+    ref_e = copy.deepcopy(he).double()
+    x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    e64 = ref_e(x64.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + r64
+    e64 = torch.relu(e64) if slope == 0.0 else torch.nn.functional.leaky_relu(e64, slope)
+    e64.backward(dy.double())
+    xe, rde = x.to(dev).requires_grad_(True), res.to(dev).requires_grad_(True)
+    ye = bn_act_rows(he, xe, slope, residual=rde)
+    ye.backward(dy.to(dev))
+    assert (ye.detach().double().cpu() - e64.detach()).abs().max().item() < 2e-6 * max(1.0, e64.abs().max().item())
+    for got, ref in ((xe.grad, x64.grad), (rde.grad, r64.grad)):
+        e = (got.double().cpu() - ref).abs()
+        assert (e > 1e-5 * ref.abs().max()).double().mean().item() < 1e-4 and e.norm().item() < 1e-4 * ref.norm().item()
+    assert (he.weight.grad.double().cpu() - ref_e.weight.grad).abs().max().item() < 2e-5 * max(1.0, ref_e.weight.grad.abs().max().item())
+    assert (he.bias.grad.double().cpu() - ref_e.bias.grad).abs().max().item() < 2e-5 * max(1.0, ref_e.bias.grad.abs().max().item())
+    assert torch.equal(he.running_mean, rm0) and torch.equal(he.running_var, rv0) and int(he.num_batches_tracked) == nbt0
+    # one path: host rows raise instead of running the torch module
+    with pytest.raises(RuntimeError, match="no CPU or stock-PyTorch path"):
+        bn_act_rows(copy.deepcopy(he).cpu(), x, slope)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride", [(3, 32, 32, 256, 512, 1, 1), (2, 16, 16, 64, 96, 3, 1), (5, 12, 20, 64, 128, 3, 2), (1, 7, 9, 32, 32, 1, 1)])

@@ -13,6 +13,9 @@ from forge_amd import _lib, nvs, synthetic as syn  # noqa: E402
 dev = torch.device("cuda:0")
 lib, st = _lib.lib(), _lib.current_stream()
 iters = int(os.environ.get("RENDER_PROBE_ITERS", "10"))
+# image rows: 128 = the product shape (16 tile rows -> the XCD band order of forge_render_fwd); 120 = 15 tile rows, which the library launches in plain
+# launch order (ny % 8 != 0): the same kernel and volume WITHOUT the band placement, for the traffic comparison of tools/pmc_render.sh
+Hr = int(os.environ.get("RENDER_PROBE_HR", "128"))
 cases = [tuple(int(v) for v in c.split("x")) for c in os.environ.get("RENDER_PROBE_CASES", "64x5,64x28,128x5,128x28").split(",")]
 for Dr, V in cases:
     feat, dens = syn.blob_volumes(1, Dr, 16, seed=0)
@@ -29,10 +32,10 @@ for Dr, V in cases:
     cam = torch.cat([E[:, :3, :3].reshape(V, 9), E[:, :3, 3], K[0, 0].expand(V, 1), K[1, 1].expand(V, 1), K[0, 2].expand(V, 1), K[1, 2].expand(V, 1)],
                     dim=1).contiguous().to(dev)
     v2v = torch.zeros(V, dtype=torch.int32, device=dev)
-    of, oo = torch.empty(V, 128, 128, 16, device=dev), torch.empty(V, 128, 128, device=dev)
+    of, oo = torch.empty(V, Hr, 128, 16, device=dev), torch.empty(V, Hr, 128, device=dev)
     h = 0.5 * (Dr - 1) / Dr
     f = lambda: _lib.check(lib.forge_render_fwd(_lib.ptr(feat), _lib.ptr(dens), _lib.ptr(cam), _lib.ptr(v2v), _lib.ptr(of), _lib.ptr(oo), None,
-                                                V, 1, 16, Dr, Dr, Dr, 128, 128, 64, 0.5, 2.0, h, h, h, st), "render")
+                                                V, 1, 16, Dr, Dr, Dr, Hr, 128, 64, 0.5, 2.0, h, h, h, st), "render")
     f()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,5 +46,5 @@ for Dr, V in cases:
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
     hit = (oo > 0).float().mean().item()
-    print("render D_r=%d V=%d: %.4f ms/launch  %.1f us/view  %.2f G taps/s  (opacity>0 on %.0f%% of the rays; xcd_order=%s)"
-          % (Dr, V, ms, ms * 1e3 / V, V * 128 * 128 * 64 * 17 * 8 / ms / 1e6, 100 * hit, "launch"))
+    print("render D_r=%d V=%d rows=%d: %.4f ms/launch  %.1f us/view  %.2f G taps/s  (opacity>0 on %.0f%% of the rays; workgroup order: %s)"
+          % (Dr, V, Hr, ms, ms * 1e3 / V, V * Hr * 128 * 64 * 17 * 8 / ms / 1e6, 100 * hit, "XCD row bands" if (Hr // 8) % 8 == 0 else "launch order"))

@@ -16,6 +16,9 @@ GF_ENCODER = 64.3 * T_IN
 GF_FUSE = 927.7
 GF_HEADS = 45.3
 GF_CONVRGB = 0.80 * V_OUT
+# what every training-step number of this bench leaves out / cannot promise
+TRAIN_CAVEATS = ("; perceptual term excluded (config/kubric/gt_pose.yaml:37 perceptual_img 0.02 needs VGG-16 weights: SURVEY.md 2 row 8, out of scope); "
+                 "weight gradients accumulate with fp32 atomics (csrc/conv_wgrad.hip): not bit-reproducible run to run")
 # LDS -> MFMA loop alone (no global -> LDS staging), direct gates launch K = 6912: debug builds of tools/debug/gemm_ceiling.py,
 # profiles/TUNING_LOG.md "K-loop ceiling"
 KLOOP_CEILING_TF = {"64x64": 130.0, "64x128": 137.0, "128x128": 141.0}

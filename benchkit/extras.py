@@ -5,7 +5,7 @@ import os
 import torch
 
 from forge_amd import synthetic as syn
-from benchkit.common import FP32_MFMA_PEAK_TF, ROOT, T_IN, V_OUT, _timed, floor_of
+from benchkit.common import FP32_MFMA_PEAK_TF, ROOT, T_IN, TRAIN_CAVEATS, V_OUT, _timed, floor_of
 
 
 def extra_configs(dev, steps=5):
@@ -38,8 +38,11 @@ def extra_configs(dev, steps=5):
                 fn_eager()
             torch.cuda.synchronize()
             ms = _timed(fn_timed, n)
-            e = {"name": name, "workload": workload, "steps": n, "ms_per_step": ms, "views_per_s": views / ms * 1e3,
+            training = name.startswith(("train_step", "joint_step"))
+            e = {"name": name, "workload": workload + (TRAIN_CAVEATS if training else ""), "steps": n, "ms_per_step": ms, "views_per_s": views / ms * 1e3,
                  "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches)}
+            if training:
+                e.update(perceptual_term="excluded", deterministic=False)
             if make_pipe is not None:                          # the same step with several replays in flight (PipelinedForward), as the headline runs it
                 holder.clear()
                 torch.cuda.empty_cache()
@@ -170,6 +173,27 @@ def extra_configs(dev, steps=5):
         opt.step()
     entry("train_step", "GT-pose training step (kubric_train_pose_3D.py; scripts/kubric_trainer.py:47-59): FORGE_poseEstimator3D, 1 scene x 5 views, "
           "3 fusions, 10 rendered views, fused MSE, backward, clip 10, Adam; train-mode BatchNorm on the HIP kernels; eager launch", 10, train_step, train_step)
+    try:
+        # how far apart are two backward passes of the SAME state (atomics-ordered weight gradients)? max |g1 - g2| / max |g1| over the parameters
+        def grads():
+            imgs, masks = m3(s1, ds, dev)
+            mi = grouped_mse(imgs.reshape(1, 10, 3, 256, 256), s1["images"][:, :T_IN], T_IN)
+            mm = grouped_mse(masks.reshape(1, 10, 1, 256, 256), s1["fg_probabilities"][:, :T_IN], T_IN)
+            ps = [p for p in m3.parameters() if p.requires_grad]
+            gs = torch.autograd.grad(5.0 * (mi[0] + mi[1]) + mm[0] + mm[1], ps, allow_unused=True)
+            return [g for g in gs if g is not None]
+        bn_state = {k: v.clone() for k, v in m3.state_dict().items() if "running_" in k or "num_batches" in k}
+        g1 = grads()
+        m3.load_state_dict(bn_state, strict=False)              # the same running statistics for the second pass
+        g2 = grads()
+        m3.load_state_dict(bn_state, strict=False)
+        rel = max(float((a - b).abs().max() / a.abs().max().clamp_min(1e-30)) for a, b in zip(g1, g2))
+        for e_ in out:
+            if e_.get("name") == "train_step":
+                e_["gradient_run_to_run_rel_max"] = rel
+        del g1, g2
+    except Exception as e:
+        out.append({"name": "train_step_determinism_probe", "error": repr(e)[:200]})
     # the per-GPU shape of BASELINE configs[3]: 4 scenes per GPU (bounded: 3 timed steps of ~175 ms)
     try:
         s4 = {k: v.to(dev) for k, v in syn.make_sample(4, T_IN, 256, 1.5, seed=1001).items()}
@@ -208,7 +232,7 @@ def extra_configs(dev, steps=5):
             train.clip_grad_norm_(m3.parameters(), 10.0)
             opt.step()
         entry("train_step_4_scenes_grid64", "BASELINE configs[3] per-GPU shape: GT-pose training step, 4 scenes x 5 synthetic [128,64^3] feature volumes "
-              "(128^3-voxel render grid) -> rotate(D=64) -> 3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
+              "(128^3-voxel render grid; the ENCODER is not run - its forward, backward and gradient all-reduce are not in this number) -> rotate(D=64) -> 3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
               40, train_step4g, train_step4g, n=steps)
         del s4, f4
     except Exception as e:
@@ -334,7 +358,8 @@ def joint_configs(dev, steps=5):
             torch.cuda.synchronize()
             ms = _timed(step, steps, warm=1)
             ms_pose = _timed(pose_nets_only(), steps, warm=1)
-            e = {"name": name, "workload": workload, "steps": steps, "ms_per_step": ms, "views_per_s": 10 / ms * 1e3,
+            e = {"name": name, "workload": workload + TRAIN_CAVEATS, "perceptual_term": "excluded", "deterministic": False,
+                 "steps": steps, "ms_per_step": ms, "views_per_s": 10 / ms * 1e3,
                  "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches,
                                   note="executed_gflop = libforge matrix-core launches (the pose estimators' convolutions included since round 5); the attention "
                                        "blocks' rocBLAS GEMMs are in stock_torch.gflop"),
@@ -379,7 +404,8 @@ def joint_configs(dev, steps=5):
             step4()
         torch.cuda.synchronize()
         ms4 = _timed(step4, max(2, steps // 2), warm=1)
-        out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> 40 rendered views per step); eager launch",
+        out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> 40 rendered views per step); eager launch" + TRAIN_CAVEATS,
+                    "perceptual_term": "excluded", "deterministic": False,
                     "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3, "stock_torch": {"rocprofv3": (share or {}).get("joint_step_4_scenes")},
                     "roofline": dict(floor_of(fm4.gflop, ms4), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm4.gflop / ms4, launches=fm4.launches)})
         del s4

@@ -4,7 +4,7 @@ import os
 import torch
 
 from forge_amd import dist as fdist, synthetic as syn
-from benchkit.common import T_IN, _bracketed
+from benchkit.common import T_IN, TRAIN_CAVEATS, _bracketed
 from benchkit.emit import emit
 
 
@@ -44,8 +44,8 @@ def ddp_train_record(rank, world, dev, steps, scenes=4, grid=32):
     grad_bytes = sum(p.numel() for p in ddp.parameters() if p.requires_grad) * 4
     return {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered views/scene, "
                         "%s, SyncBatchNorm + DDP, clip 10, Adam" % (scenes, "reference-native 32^3 / 64^3 grids" if grid == 32 else
-                                                                    "128^3-voxel render grid from synthetic [128,64^3] feature volumes (encoder not run)"),
-            "scenes_per_gpu": scenes, "global_batch": scenes * world, "feature_grid": grid, "steps": steps,
+                                                                    "128^3-voxel render grid from synthetic [128,64^3] feature volumes (encoder not run)") + TRAIN_CAVEATS,
+            "perceptual_term": "excluded", "deterministic": False, "scenes_per_gpu": scenes, "global_batch": scenes * world, "feature_grid": grid, "steps": steps,
             "ms_per_step": s_sync * 1e3, "views_per_s": scenes * 10 * world / s_sync, "ms_per_step_no_sync": s_nosync * 1e3,
             "gradient_all_reduce_exposed_ms": (s_sync - s_nosync) * 1e3,
             "gradient_bytes_all_reduced_per_step": grad_bytes, "syncbn_layers": n_bn,
@@ -82,7 +82,8 @@ def ray_sharded_joint_record(rank, world, dev, steps, grid=32):
     def step():
         loss[0] = train.train_step(cfg, sample, ds, ddp, opt, dev, loss_func=train.compute_all_loss_nvs)[0]
     out = {"workload": "BASELINE configs[4] step: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input + 5 novel views -> 10 rendered views, rays of every "
-                       "view sharded over the ranks in row bands; %s; DDP over the replicas" % ("reference-native grids" if grid == 32 else "128^3-voxel render grid (synthetic 64^3 features)"),
+                       "view sharded over the ranks in row bands; %s; DDP over the replicas" % ("reference-native grids" if grid == 32 else "128^3-voxel render grid (synthetic 64^3 features)") + TRAIN_CAVEATS,
+           "perceptual_term": "excluded", "deterministic": False,
            "feature_grid": grid, "steps": steps, "band_rows": 128 // world if 128 % world == 0 else None}
     train.enable_ray_sharding(ddp, False)
     s_full = _bracketed(step, steps, 2, dev)

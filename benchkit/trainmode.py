@@ -4,7 +4,7 @@ import os
 import torch
 
 from forge_amd import dist as fdist, synthetic as syn
-from benchkit.common import T_IN, region_stats, timed_region
+from benchkit.common import T_IN, TRAIN_CAVEATS, region_stats, timed_region
 from benchkit.emit import emit
 
 
@@ -64,7 +64,8 @@ def train_bench(args, rank, world, dev, affinity):
             "mean_loss_all_ranks": loss_sum / max(ranks_ok, 1.0),
             "config": {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered "
                                    "views/scene, %s, SyncBatchNorm + DDP" % (B, "reference-native 32^3 / 64^3 grids" if args.grid == 32 else "128^3-voxel render grid from synthetic "
-                                   "[128,64^3] feature volumes (encoder not run)"), "scenes_per_gpu": B, "feature_grid": args.grid,
+                                   "[128,64^3] feature volumes (encoder not run: its forward, backward and gradient all-reduce are not in this number)") + TRAIN_CAVEATS,
+                       "perceptual_term": "excluded", "deterministic": False, "scenes_per_gpu": B, "feature_grid": args.grid,
                        "global_batch": B * world, "parallelism": "dp%d (DDP bucketed RCCL all-reduce of 221 MB fp32 gradients; HIP SyncBatchNorm)" % world,
                        "rank0_affinity": affinity}}, args.full_record)
     fdist.barrier()

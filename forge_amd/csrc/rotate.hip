@@ -36,6 +36,17 @@ __device__ __forceinline__ void taps_ac_false(float sx, float sy, float sz, int 
     t.wz1 = pz - fz; t.wz0 = (fz + 1.f) - pz;
 }
 
+// Normalised voxel-centre coordinate i -> [-1, 1] of a D-point axis, bit for bit torch.linspace(-1, 1, D)[i] in fp32 (what PyTorch3D's
+// Volumes.get_coord_grid, i.e. models/rotate.py:50-51, builds its grid from): step = 2 / (D - 1) rounded once, the lower half counted up from -1,
+// the upper half counted down from +1, each value ONE fused multiply-add (ATen's vectorised CPU kernel and the contracted `start + step * i` of its
+// GPU kernel both round once; checked against torch.linspace for D = 7 .. 128 in tests/test_abi_and_surface.py). Replaces the IEEE division
+// 2 i / (D - 1) - 1 of rounds 1-5, which agreed with linspace only to an ulp - at D = 128 an ulp of the coordinate is 1.5e-5 of a voxel after
+// un-normalisation.
+__device__ __forceinline__ float linspace_pm1(int i, int D) {
+    const float step = 2.f / (float)(D - 1);
+    return i < D / 2 ? fmaf(step, (float)i, -1.f) : fmaf(-step, (float)(D - 1 - i), 1.f);
+}
+
 // Voxel traversal order: linear index -> (x, y, z). Plain x-fastest order makes a workgroup's neighbours in time (same XCD, same
 // L2) a full x-row / z-slice of the OUTPUT, whose SOURCE footprint under a rotation is a tilted slab spanning tens of z-slices
 // (44 MB at 64^3 x 128 ch for 20 degrees) - every source row is then re-fetched from HBM for each of its y/z taps. Walking the output
@@ -59,9 +70,17 @@ __device__ __forceinline__ void voxel_of(unsigned v, int W, int H, int D, int& x
     }
 }
 
-// NQ = 16-byte channel groups per thread (c4, c4 + C4/NQ, ...): the tap / weight arithmetic (~150 VALU instructions with IEEE
-// divisions in ATen's order) is the same for every channel of a voxel, and with one group per thread the kernel is VALU-issue
-// bound, not HBM-bound (3.1 TB/s at 64^3 x 128 ch); two groups per thread halve that cost per byte. All index math is 32-bit
+// NQ = 16-byte channel groups per thread (c4, c4 + C4/NQ, ...): the tap / weight arithmetic (~150 VALU instructions in ATen's order) is the
+// same for every channel of a voxel; two groups per thread halve that cost per byte (one group: 3.1 TB/s at 64^3 x 128 ch).
+// What limits the kernel at 3.4-3.8 TB/s algorithmic on HBM-resident volumes (round 6, profiles/r06_rotate_limiter.md: timing of the same kernel
+// under access patterns that differ only in the source walk + rocprofv3 SQ / TCP / TCC passes): NOT DRAM locality of the rotated gather (the
+// identity warp, whose taps are neighbouring rows in output order, runs at the rotated rate: 3.56 vs 3.51 TB/s), NOT L2->fabric over-fetch
+// (FETCH = algorithmic bytes), NOT VALU issue alone (VALU active 0.10 of wave-cycles at 2.7 resident waves per SIMD = 28 % of SIMD time) - the
+// mode-0 copy through the same kernel streams at 5.1 TB/s, and every warped output costs 8 x the copy's load requests through TA / L1 (hit rate
+// 0.83) / L2 (hit rate 0.60, mean TCP->TCC read latency 685 cycles): the warp is bound by the gather's request rate through the vector memory
+// path, half of its wave-cycles waiting on it (SQ_WAIT_ANY 0.53) and a third stalled at issue (SQ_WAIT_INST_ANY 0.32). A persistent grid
+// (6 workgroups per CU striding through XCD-contiguous chunk ranges) measured 12 % SLOWER (50.0 vs 44.7 us at the bench transform), nontemporal
+// stores and 4 channel groups per thread changed nothing (TUNING_LOG r5-16, r6-3). All index math is 32-bit
 // (a volume holds < 2^31 float4 elements; checked on the host side).
 template <int NQ>
 __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restrict__ vox, const float* __restrict__ xf,
@@ -86,9 +105,7 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float4* __restric
         return;
     }
     const float* A = xf + n * 12;  // uniform per workgroup -> scalar loads
-    const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
-    const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
-    const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+    const float gx = linspace_pm1(x, W), gy = linspace_pm1(y, H), gz = linspace_pm1(z, D);
     const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
     const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
     const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
@@ -164,9 +181,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_affine_kernel(const float4* __
         const int y = (int)(v % H);
         const int z = (int)(v / H);
         const float* A = xf + n * 12;
-        const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
-        const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
-        const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+        const float gx = linspace_pm1(x, W), gy = linspace_pm1(y, H), gz = linspace_pm1(z, D);
         const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
         const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
         const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));
@@ -277,11 +292,11 @@ __global__ __launch_bounds__(256) void rotate_bwd_gather_kernel(const float4* __
     for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const unsigned sW = (unsigned)C4, sH = (unsigned)W * C4, sD = (unsigned)H * W * C4;
     for (int z = lo[2]; z <= hi[2]; ++z) {
-        const float gz = 2.f * (float)z / (float)(D - 1) - 1.f;
+        const float gz = linspace_pm1(z, D);
         for (int y = lo[1]; y <= hi[1]; ++y) {
-            const float gy = 2.f * (float)y / (float)(H - 1) - 1.f;
+            const float gy = linspace_pm1(y, H);
             for (int x = lo[0]; x <= hi[0]; ++x) {
-                const float gx = 2.f * (float)x / (float)(W - 1) - 1.f;
+                const float gx = linspace_pm1(x, W);
                 const float sx = fmaf(A[0], gx, fmaf(A[1], gy, fmaf(A[2], gz, A[3])));
                 const float sy = fmaf(A[4], gx, fmaf(A[5], gy, fmaf(A[6], gz, A[7])));
                 const float sz = fmaf(A[8], gx, fmaf(A[9], gy, fmaf(A[10], gz, A[11])));

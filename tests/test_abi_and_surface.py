@@ -386,3 +386,13 @@ def test_grad_zero_arena_never_hands_out_memory_twice():
     assert a4.untyped_storage().data_ptr() != fa.untyped_storage().data_ptr()
     assert float(fa.sum()) == 35.0 and float(fb.sum()) == 128.0                  # pass 3's slices untouched by pass 4's zero-fill / adds
     assert float(a4.sum()) == 35.0 and float(b4.sum()) == 128.0 and arena.task == -1
+
+
+def test_rotate_grid_coordinate_formula_is_torch_linspace():
+    """csrc/rotate.hip::linspace_pm1 (the normalised voxel-centre coordinate of the warp) restated on the host: step = fp32(2 / (D - 1)), the lower half
+    fma(step, i, -1), the upper half fma(-step, D - 1 - i, 1) - bit for bit torch.linspace(-1, 1, D), the grid models/rotate.py:50-51 gets from PyTorch3D."""
+    for D in (7, 16, 32, 33, 48, 64, 128):
+        step = np.float32(2.0) / np.float32(D - 1)
+        fma = lambda a, b, c: np.float32(np.float64(a) * np.float64(b) + np.float64(c))          # exact product and sum in double, ONE rounding: fmaf
+        got = np.array([fma(step, np.float32(i), np.float32(-1.0)) if i < D // 2 else fma(-step, np.float32(D - 1 - i), np.float32(1.0)) for i in range(D)], dtype=np.float32)
+        assert np.array_equal(got, torch.linspace(-1.0, 1.0, D).numpy()), D

@@ -117,7 +117,7 @@ def test_bn_train_residual_form_forward_backward(shape, slope):
     for p in he.parameters():
         p.grad = None
     rm0, rv0, nbt0 = he.running_mean.clone(), he.running_var.clone(), int(he.num_batches_tracked)
-    ref_e = copy.deepcopy(he).double()
+    ref_e = copy.deepcopy(he).cpu().double()
     x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
     e64 = ref_e(x64.permute(0, nd - 1, *range(1, nd - 1))).permute(0, *range(2, nd), 1) + r64
     e64 = torch.relu(e64) if slope == 0.0 else torch.nn.functional.leaky_relu(e64, slope)

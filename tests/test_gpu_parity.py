@@ -75,7 +75,10 @@ def test_rotate_vs_oracle(dev, D, C, B, t):
     ref = fo.rotate_world(vox, P, 1.0)
     out = Rotate_world(syn.kubric_config()).to(dev)(vox.to(dev), P.to(dev), grid_size=D).cpu()
     assert out.shape == ref.shape
-    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # the un-normalised coordinate ((s + 1) D - 1) / 2 is rounded at magnitude 2 D: its ulp (2^-23 x 2 D: 1.5e-5 of a voxel at D = 128) moves a
+    # trilinear weight by as much, whichever fp32 implementation computes it - the bound scales with D beyond 64
+    tol = max(2e-5, 3.0 * D * 2.0 ** -23)
+    assert (out - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
 
 
 def test_rotate_layout_agnostic_and_far_pose(dev):

@@ -36,7 +36,7 @@ def timed(fn, iters=20, warm=3):
 
 B, D, C = 1, 32, 128
 R = B * D * (D // 2) * (D // 2)
-print("one scene: R = %d rows per Winograd point, 16 points" % R)
+print("one scene: R = %d rows per Winograd point, 16 points" % R, flush=True)
 for name, Cout, C2 in (("gates N=256 K=768", 256, C), ("state N=128 K=768", 128, C), ("fusion_conv N=128 K=384", 128, 0)):
     K = 3 * (C + C2)
     V1, V2 = torch.randn(16, R, C, device=dev), torch.randn(16, R, C, device=dev)
@@ -46,17 +46,17 @@ for name, Cout, C2 in (("gates N=256 K=768", 256, C), ("state N=128 K=768", 128,
     gf = 2.0 * 16 * R * Cout * K / 1e9
     print("%-26s exact fp32 (forge wino_gemm): %.3f ms  %.1f TF executed" % (name, ms32, gf / ms32))
     for terms in (6, 3):
-        A = torch.randn(16, R, terms * K, device=dev).to(torch.bfloat16)
-        Bm = (torch.randn(16, terms * K, Cout, device=dev) * 0.02).to(torch.bfloat16)
-        out = torch.empty(16, R, Cout, device=dev, dtype=torch.bfloat16)
-        ms = timed(lambda: torch.bmm(A, Bm, out=out))
-        # the same with the B operand stored [N, K] (K-contiguous for both operands, what an MFMA kernel stages)
-        Bt = Bm.transpose(1, 2).contiguous()
-        ms_t = timed(lambda: torch.bmm(A, Bt.transpose(1, 2), out=out))
+        # ONE 2-D library GEMM over all 16 points' rows ([16 R x terms K] x [terms K x N], the weight shared instead of per point: the same MFMA work and
+        # operand traffic per row, and the grid the real launch has - 16 separate GEMMs of 8192 rows each fill half the chip; torch.bmm(out=) faulted here)
+        A = torch.randn(16 * R, terms * K, device=dev).to(torch.bfloat16)
+        Bm = (torch.randn(terms * K, Cout, device=dev) * 0.02).to(torch.bfloat16)
+        Bt = Bm.t().contiguous()                                      # [N, K]: K-contiguous for both operands, what an MFMA kernel stages
+        ms = timed(lambda: torch.matmul(A, Bm), iters=10, warm=3)
+        ms_t = timed(lambda: torch.matmul(A, Bt.t()), iters=10, warm=3)
         best = min(ms, ms_t)
         print("    %d bf16 products as one library GEMM (K = %d): %.3f ms (B as [K,N]) / %.3f ms (B as [N,K])  -> %.0f TF bf16;  vs exact fp32: %.2fx"
-              % (terms, terms * K, ms, ms_t, terms * gf / best, ms32 / best))
-        del A, Bm, Bt, out
+              % (terms, terms * K, ms, ms_t, terms * gf / best, ms32 / best), flush=True)
+        del A, Bm, Bt
     # the split's cost outside the GEMM: three bf16 planes of the transformed operand instead of one fp32 plane (written by the input transform, here as
     # a stand-alone pass: read fp32, write 3 x bf16)
     X = torch.randn(16, R, C + C2, device=dev)

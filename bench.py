@@ -64,8 +64,10 @@ def main():
                          "1 = one stream, back to back")
     ap.add_argument("--dump-conv", action="store_true", help="print every conv launch of one step (shape, ms, TFLOP/s) to stderr")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-oracle-check", action="store_true", help="with --no-cpu-baseline: also skip the one CPU oracle forward the last output is checked against")
-    ap.add_argument("--min-psnr-db", type=float, default=None, help="exit non-zero unless the last output of the timed region is at least this close to the oracle "
+    ap.add_argument("--no-oracle-check", action="store_true", help="with --no-cpu-baseline: also skip the one CPU oracle forward the last output is "
+            "checked against")
+    ap.add_argument("--min-psnr-db", type=float, default=None, help="exit non-zero unless the last output of the timed region is at least this close to "
+            "the oracle "
                                                                     "(soak runs: --steps 3000 --no-cpu-baseline --no-extra --min-psnr-db 100)")
     ap.add_argument("--no-microbench", action="store_true", help="skip the per-kernel micro-benchmarks (clean rocprofv3 stats)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra_configs / strong_scaling (the other BASELINE configurations)")

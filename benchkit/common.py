@@ -41,7 +41,8 @@ def time_kernel(fn, iters=20, warm=3):
 def floor_of(gflop, ms):
     """A step against its own executed-FLOP time floor on the fp32 MFMA pipe."""
     floor_ms = gflop / FP32_MFMA_PEAK_TF
-    return {"executed_gflop": gflop, "floor_ms": floor_ms, "executed_frac": floor_ms / ms if ms > 0 else None, "step_over_floor": ms / floor_ms if floor_ms > 0 else None}
+    return {"executed_gflop": gflop, "floor_ms": floor_ms, "executed_frac": floor_ms / ms if ms > 0 else None,
+            "step_over_floor": ms / floor_ms if floor_ms > 0 else None}
 
 
 def _timed(fn, steps, warm=2):

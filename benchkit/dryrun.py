@@ -64,7 +64,8 @@ def dry_run(args, rank, world):
                 with dd.no_sync():
                     st()
             a, b_ = _bracketed(st, 2, 1, "cpu"), _bracketed(st_ns, 2, 1, "cpu")
-            return {"ms_per_step": a * 1e3, "ms_per_step_no_sync": b_ * 1e3, "gradient_bytes_all_reduced_per_step": sum(p.numel() for p in net.parameters()) * 4}
+            return {"ms_per_step": a * 1e3, "ms_per_step_no_sync": b_ * 1e3,
+                    "gradient_bytes_all_reduced_per_step": sum(p.numel() for p in net.parameters()) * 4}
 
         def token_fail():
             if rank == world - 1:
@@ -76,7 +77,8 @@ def dry_run(args, rank, world):
             feat = torch.ones(1, 2, 2, 2, 2, requires_grad=True)
             dens = torch.ones(1, 1, 2, 2, 2, requires_grad=True)
             cam = torch.zeros(3, 16)
-            toy = lambda f, d, c, v2v, hr, wr, *a: (f.sum() * torch.ones(3, 2, hr, wr) + c[:, 15].reshape(3, 1, 1, 1), d.sum() * torch.ones(3, 1, hr, wr))   # noqa: E731
+            # noqa: E731
+            toy = lambda f, d, c, v2v, hr, wr, *a: (f.sum() * torch.ones(3, 2, hr, wr) + c[:, 15].reshape(3, 1, 1, 1), d.sum() * torch.ones(3, 1, hr, wr))
             o = fdist.render_rays_sharded(feat, dens, cam, None, Hr, 4, 8, 0.5, 2.0, (1.0, 1.0, 1.0), render_fn=toy)
             (o[0].sum() + o[1].sum()).backward()
             return {"rows": int(o[0].shape[2]), "d_feat": float(feat.grad.sum()), "expected_d_feat": float(3 * 2 * Hr * 4 * 16)}
@@ -90,7 +92,8 @@ def dry_run(args, rank, world):
     if rank == 0:
         emit({"metric": "rendered views/sec (5 views, 128^2 px, 64^3 voxel)", "value": None, "unit": "views/s", "n_gpus": world, "multi_rank": multi,
               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "views_counted": units, "ms_per_step": dt / args.steps * 1e3,
-              "scaling": "weak", "ranks_ok": int(ranks_ok), "process_group": fdist.group_info(), "train": bool(args.train), "replicas_identical": same, "error": err,
+              "scaling": "weak", "ranks_ok": int(ranks_ok), "process_group": fdist.group_info(), "train": bool(args.train), "replicas_identical": same,
+                      "error": err,
               "config": {"workload": "dry run: no HIP work, launch + rendezvous + reductions only"}}, args.full_record)
     fdist.barrier()
     fdist.shutdown()

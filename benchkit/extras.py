@@ -108,7 +108,8 @@ def extra_configs(dev, steps=5):
         out.append({"name": "refinement", "workload": "pose-refinement iteration (kubric_eval.py:412-530): 1 scene, 5 views, 4 free 7-D poses; rotate -> fuse "
                     "-> heads -> ray-march -> conv_rgb forward + data-gradient backward + Adam, hipGraph replay", "steps": 2 * steps,
                     "ms_per_step": ms, "views_per_s": T_IN / ms * 1e3,
-                    "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches)})
+                    "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms,
+                            launches=fm.launches)})
         try:                                                       # two refinement problems in flight (refine_poses_many): per iteration AND instance
             probs = [(feats, init, tgt_i, tgt_m, s1["K_cv2"][:, :T_IN]), (feats, init.clone(), tgt_i, tgt_m, s1["K_cv2"][:, :T_IN])]
             _, dt2 = refine.refine_poses_many(model, cfg, ds, probs, dev, iter_num=2 * steps, depth=2)
@@ -136,7 +137,8 @@ def extra_configs(dev, steps=5):
     entry("pose3d_inference", "FORGE_poseEstimator3D inference (GT poses): 1 scene x 5 views -> 3 fusions (shared input halves) -> 10 rendered views "
           "(hipGraph replay)", 10, eager3, timed3, make_pipe=pipe3)
     holder.clear()
-    # --- FORGE with PREDICTED poses in inference (kubric_eval.py:371-410 predict_initial / demo.py): both pose estimators + pose head -> cameras -> reconstruction -> 10 views
+    # --- FORGE with PREDICTED poses in inference (kubric_eval.py:371-410 predict_initial / demo.py): both pose estimators + pose head -> cameras ->
+    # reconstruction -> 10 views
     try:
         mj = FORGE(syn.kubric_config(use_gt_pose=False, parameter="joint"))
         mj.load_state_dict(syn.seeded_state_dict(mj.state_dict(), 0))
@@ -151,7 +153,8 @@ def extra_configs(dev, steps=5):
             if "g" not in holder:
                 holder["g"] = GraphedForward(mj, s10, ds, dev)
             holder["g"](s10)
-        entry("joint_inference", "FORGE inference with PREDICTED poses (2-D + 3-D pose estimators + pose head -> cameras): 1 scene x 5 input views -> 10 rendered views "
+        entry("joint_inference", "FORGE inference with PREDICTED poses (2-D + 3-D pose estimators + pose head -> cameras): 1 scene x 5 input views -> 10 "
+                "rendered views "
               "(5 predicted + 5 given novel cameras); the 2-D estimator on a side HIP stream beside the encoder (hipGraph replay)", 10, eagerj, timedj)
         holder.clear()
         del mj, s10
@@ -232,7 +235,8 @@ def extra_configs(dev, steps=5):
             train.clip_grad_norm_(m3.parameters(), 10.0)
             opt.step()
         entry("train_step_4_scenes_grid64", "BASELINE configs[3] per-GPU shape: GT-pose training step, 4 scenes x 5 synthetic [128,64^3] feature volumes "
-              "(128^3-voxel render grid; the ENCODER is not run - its forward, backward and gradient all-reduce are not in this number) -> rotate(D=64) -> 3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
+              "(128^3-voxel render grid; the ENCODER is not run - its forward, backward and gradient all-reduce are not in this number) -> rotate(D=64) -> "
+                      "3 fusions -> heads -> 128^3 x 17 volumes -> 40 rendered views, backward, clip 10, Adam; eager launch",
               40, train_step4g, train_step4g, n=steps)
         del s4, f4
     except Exception as e:
@@ -286,7 +290,8 @@ def joint_stock_share():
 def joint_configs(dev, steps=5):
     """BASELINE configs[4] on one GPU: the joint 2D3D fine-tune iteration of kubric_train_joint.py:111-141 - FORGE with
     PREDICTED poses (attention blocks of the 2-D / 3-D pose estimators and the pose head on stock torch kernels; encoder / rotate / fusion / heads / ray-march /
-    conv_rgb and, since round 5, every convolution + BatchNorm of the two pose estimators on the HIP kernels), 5 input + 5 novel views, compute_all_loss_nvs (scripts/kubric_compute_loss.py:121-172), backward through the
+    conv_rgb and, since round 5, every convolution + BatchNorm of the two pose estimators on the HIP kernels), 5 input + 5 novel views, compute_all_loss_nvs
+    (scripts/kubric_compute_loss.py:121-172), backward through the
     pose chain (rotate's d pose, the ray-marcher's d(R, T)), clip 10, Adam over the parameter list of kubric_train_joint.py:111-116.
       joint_step          reference-native grids (32^3 features, 64^3 render volume)
       joint_step_grid64   the configuration's 128^3-voxel scenes: synthetic [1,5,128,64^3] feature volumes enter the reconstruction
@@ -344,9 +349,12 @@ def joint_configs(dev, steps=5):
 
     share = joint_stock_share()
     for name, feats, workload in (
-            ("joint_step", None, "BASELINE configs[4] step at the reference-native grids: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input + 5 novel "
-             "views 256^2 -> 10 rendered views, compute_all_loss_nvs, backward incl. the pose chain, clip 10, Adam; train-mode BatchNorm / Dropout; eager launch"),
-            ("joint_step_grid64", f64, "BASELINE configs[4] at its 128^3-voxel grid: the same step with 5 synthetic [128,64^3] feature volumes entering rotate(D=64) -> "
+            ("joint_step", None, "BASELINE configs[4] step at the reference-native grids: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input "
+                    "+ 5 novel "
+             "views 256^2 -> 10 rendered views, compute_all_loss_nvs, backward incl. the pose chain, clip 10, Adam; train-mode BatchNorm / Dropout; "
+                     "eager launch"),
+            ("joint_step_grid64", f64, "BASELINE configs[4] at its 128^3-voxel grid: the same step with 5 synthetic [128,64^3] feature volumes entering "
+                    "rotate(D=64) -> "
              "fusion at M=262144 -> heads -> 128^3 x 17 volume -> 10 rendered views; pose networks on their native inputs; eager launch")):
         try:
             step = make_step(feats)
@@ -361,11 +369,14 @@ def joint_configs(dev, steps=5):
             e = {"name": name, "workload": workload + TRAIN_CAVEATS, "perceptual_term": "excluded", "deterministic": False,
                  "steps": steps, "ms_per_step": ms, "views_per_s": 10 / ms * 1e3,
                  "roofline": dict(floor_of(fm.gflop, ms), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm.gflop / ms, launches=fm.launches,
-                                  note="executed_gflop = libforge matrix-core launches (the pose estimators' convolutions included since round 5); the attention "
+                                  note="executed_gflop = libforge matrix-core launches (the pose estimators' convolutions included since round 5); the "
+                                          "attention "
                                        "blocks' rocBLAS GEMMs are in stock_torch.gflop"),
-                 "pose_networks": {"what": "2-D + 3-D pose estimators and pose head alone, forward + backward on the step's inputs (convolutions + BatchNorm on libforge, "
+                 "pose_networks": {"what": "2-D + 3-D pose estimators and pose head alone, forward + backward on the step's inputs (convolutions + "
+                         "BatchNorm on libforge, "
                                            "attention blocks on rocBLAS / ATen)", "fwd_bwd_ms": ms_pose, "share_of_step": ms_pose / ms},
-                 "stock_torch": {"what": "kernels that are not libforge's (rocBLAS attention GEMMs, ATen element-wise / softmax / LayerNorm / optimizer): FLOPs "
+                 "stock_torch": {"what": "kernels that are not libforge's (rocBLAS attention GEMMs, ATen element-wise / softmax / LayerNorm / "
+                         "optimizer): FLOPs "
                                          "counted by torch's FlopCounterMode; share of kernel time by kernel NAME from the committed rocprofv3 trace",
                                  "gflop": fc.get_total_flops() / 1e9, "rocprofv3": (share or {}).get(name)}}
             # the same step as ONE hipGraph (forge_amd.graph.GraphedStep: forward, loss, backward, clip, capturable Adam): the eager step is host-bound
@@ -404,10 +415,13 @@ def joint_configs(dev, steps=5):
             step4()
         torch.cuda.synchronize()
         ms4 = _timed(step4, max(2, steps // 2), warm=1)
-        out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> 40 rendered views per step); eager launch" + TRAIN_CAVEATS,
+        out.append({"name": "joint_step_4_scenes", "workload": "the joint step at the reference configuration's per-GPU batch (4 scenes x (5 + 5) views -> "
+                "40 rendered views per step); eager launch" + TRAIN_CAVEATS,
                     "perceptual_term": "excluded", "deterministic": False,
-                    "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3, "stock_torch": {"rocprofv3": (share or {}).get("joint_step_4_scenes")},
-                    "roofline": dict(floor_of(fm4.gflop, ms4), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm4.gflop / ms4, launches=fm4.launches)})
+                    "steps": max(2, steps // 2), "ms_per_step": ms4, "views_per_s": 40 / ms4 * 1e3,
+                            "stock_torch": {"rocprofv3": (share or {}).get("joint_step_4_scenes")},
+                    "roofline": dict(floor_of(fm4.gflop, ms4), bound="mfma", peak=FP32_MFMA_PEAK_TF, unit="TFLOP/s", achieved=fm4.gflop / ms4,
+                            launches=fm4.launches)})
         del s4
     except Exception as e:
         out.append({"name": "joint_step_4_scenes", "error": repr(e)[:300]})

@@ -40,7 +40,8 @@ def run_headline(args, rank, world, dev, affinity):
             # 128^3-voxel scenes: per-view feature volumes [B,5,128,64^3] (671 MB per scene) resident in HBM, GT poses / cameras of the sample
             from forge_amd import geo_utils
             gen = torch.Generator(device=dev).manual_seed(77 + rank)
-            feats64 = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+            feats64 = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3,
+                    4)
             poses64 = sample["cam_poses_cv2_canonicalized"][:, :T_IN].contiguous()
             cams64 = geo_utils.camera_dict(sample["cam_extrinsics_cv2_canonicalized"][:, :V_OUT], sample["K_cv2"][:, :V_OUT])
 
@@ -121,7 +122,8 @@ def run_headline(args, rank, world, dev, affinity):
         minimal = {"metric": metric_main, "value": (int(views_per_step) * args.steps / dt) if (ok and dt > 0) else None, "unit": "views/s", "n_gpus": world,
                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                    "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_ok": int(ranks_ok), "errors": errors, "process_group": pg,
-                   "strong_scaling": strong_res, "config": {"workload": "BASELINE configs[1]: FORGE hot path, %d scene(s)/GPU x 5 views (see the full line of a run "
+                   "strong_scaling": strong_res, "config": {"workload": "BASELINE configs[1]: FORGE hot path, %d scene(s)/GPU x 5 views (see the full "
+                           "line of a run "
                                                                         "whose sub-records finished)" % B, "scenes_per_gpu": B}}
         if graphed is not None:
             graphed.wait()
@@ -217,14 +219,17 @@ def run_headline(args, rank, world, dev, affinity):
                 "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_algorithmic_bytes": tr["algorithmic_bytes"] if tr else None,
                 "traffic_launch": tr["launch"] if tr else None, "traffic_source": ("profiles/" + tr["source"]) if tr else None,
                 # (5b) the same fraction from pure kernel durations: rocprofv3 --kernel-trace --stats of this command, one step in flight
-                "frac_rocprof": (tot_gf / rp["ms_per_step"] / FP32_MFMA_PEAK_TF) if rp else None, "rocprof_kernel_ms_per_step": rp["ms_per_step"] if rp else None,
+                "frac_rocprof": (tot_gf / rp["ms_per_step"] / FP32_MFMA_PEAK_TF) if rp else None,
+                        "rocprof_kernel_ms_per_step": rp["ms_per_step"] if rp else None,
                 "rocprof_source": ("profiles/" + rp["source"]) if rp else None,
                 # (5c) what the kernel's own LDS -> MFMA loop can do with staging removed (measured on debug builds): the exact-fp32 ceiling of this design
                 "ceiling": {"kloop_without_staging_tflops": KLOOP_CEILING_TF, "frac_of_peak": ceil_tf / FP32_MFMA_PEAK_TF,
-                            "source": "profiles/TUNING_LOG.md 'K-loop ceiling' (tools/debug/gemm_ceiling.py on FORGE_EXP_* debug builds, direct gates launch K = 6912)"},
+                            "source": "profiles/TUNING_LOG.md 'K-loop ceiling' (tools/debug/gemm_ceiling.py on FORGE_EXP_* debug builds, direct gates "
+                                    "launch K = 6912)"},
                 "frac_of_ceiling": (tot_gf / (rp["ms_per_step"] if rp else tot_ms)) / ceil_tf,
                 "avg_launch_ms": tot_ms / n_launch,
-                "executed_gflop": fl["executed_gflop"], "executed_frac": fl["executed_frac"], "floor_ms": fl["floor_ms"], "step_over_floor": fl["step_over_floor"],
+                "executed_gflop": fl["executed_gflop"], "executed_frac": fl["executed_frac"], "floor_ms": fl["floor_ms"],
+                        "step_over_floor": fl["step_over_floor"],
                 "kernel_ms_per_step": tot_ms, "share_of_step": tot_ms / step_ms, "instantiations": inst,
                 "note": "frac = FLOPs the dominant kernel's launches EXECUTE / their HIP-event time / peak (a statement about the kernel; eager pass, each "
                         "event pair includes the host launch gap and, for split-K launches, the reduction); frac_rocprof = the same FLOPs / the kernels' own "
@@ -237,7 +242,8 @@ def run_headline(args, rank, world, dev, affinity):
         metric = "rendered views/sec (5 views, 128^2 px, 64^3 voxel)"
         workload = ("BASELINE configs[%d]: FORGE hot path, %d scene(s)/GPU x 5 input views 256^2 -> 32^3x128 feature "
                     "grid -> 64^3 render grid -> 5 views x 128^2 rays x 64 samples -> 5 RGB 256^2; HIP rotate, "
-                    "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU (Winograd F(2x2,3x3) x 3 depth taps) / heads / conv_rgb, HIP ray-march (no MIOpen/rocBLAS kernel in the step); "
+                    "fp32-MFMA implicit-GEMM ResNet-50 trunk / conv1 / ConvGRU (Winograd F(2x2,3x3) x 3 depth taps) / heads / conv_rgb, HIP ray-march (no "
+                            "MIOpen/rocBLAS kernel in the step); "
                     "eval BN, random-init seeded weights" % (1 if B == 1 else 2, B))
         gflop = B * (GF_ENCODER + GF_FUSE + GF_HEADS + GF_CONVRGB)
     else:
@@ -282,7 +288,8 @@ def run_headline(args, rank, world, dev, affinity):
             # a soak run must look at what it produced ("a soak that never looks at its output proves only that nothing crashed")
             one = {k: v[:1] for k, v in sample_cpu.items()}
             with torch.no_grad():
-                ref = fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN], one["cam_extrinsics_cv2_canonicalized"][:, :T_IN],
+                ref = fo.forward_hot_path(one["images"][:, :T_IN], one["cam_poses_cv2_canonicalized"][:, :T_IN], one["cam_extrinsics_cv2_canonicalized"][:,
+                        :T_IN],
                                           one["K_cv2"][:, :T_IN], weights, cfg, order_by_distance=True)
         img0 = out[0][:V_OUT].cpu()
         result["psnr_vs_oracle_db"] = fo.psnr(img0, ref[0])

@@ -71,7 +71,8 @@ def stage_timers(model):
         out = o_g(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, **kw)
         e1.record()
         R = n * D * Ht * Wt
-        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout, C1 + C2)], []).append((e0, e1, 2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2), 2.25))
+        rec.setdefault("conv_igemm_kernel<%s>" % co.TILE_NAMES[co.wino_gemm_tile(R, Cout, C1 + C2)], []).append((e0, e1,
+                2.0 * 16 * R * Cout * U.shape[1] * (C1 + C2), (16 * R, Cout, U.shape[1], C1 + C2), 2.25))
         return out
 
     def input_timed(x, C, ld, n, D, H, W, **kw):
@@ -79,7 +80,8 @@ def stage_timers(model):
         e0.record()
         out = o_i(x, C, ld, n, D, H, W, **kw)
         e1.record()
-        rec.setdefault("wino_input_kernel", []).append((e0, e1, 4.0 * n * D * H * W * C * (kw.get("nsum", 1) + 4)))   # reads the rows (of nsum views) once, writes 16 points x R = 4x
+        # reads the rows (of nsum views) once, writes 16 points x R = 4x
+        rec.setdefault("wino_input_kernel", []).append((e0, e1, 4.0 * n * D * H * W * C * (kw.get("nsum", 1) + 4)))
         return out
 
     def output_timed(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, **kw):
@@ -91,7 +93,8 @@ def stage_timers(model):
         side = {co.EPI_GRU_GATES: (2 if out2 is not None else 1) * Cout // 2 + Cout // 2, co.EPI_GRU_OUT: 3 * Cout + (Cout if out2 is not None else 0)}.get(
             epilogue, Cout if out is not None else 0)
         side += 4 * Cout if kw.get("Mm2") is not None else 0
-        rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * (4 * Cout + side)))       # reads 16 points x R x Cout = 4x, then the tail's operands
+        # reads 16 points x R x Cout = 4x, then the tail's operands
+        rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * (4 * Cout + side)))
         return r
     co.wino_gemm, co.wino_input, co.wino_output = gemm_timed, input_timed, output_timed
     undo.append(lambda: (setattr(co, "wino_gemm", o_g), setattr(co, "wino_input", o_i), setattr(co, "wino_output", o_o)))
@@ -99,7 +102,8 @@ def stage_timers(model):
 
 
 def pmc_traffic(prefix):
-    """HBM bytes per launch of the kernel whose summary key contains `prefix`, from the committed rocprofv3 PMC passes (profiles/*pmc_summary.json: separate --pmc
+    """HBM bytes per launch of the kernel whose summary key contains `prefix`, from the committed rocprofv3 PMC passes (profiles/*pmc_summary.json: separate
+    --pmc
     FETCH_SIZE / WRITE_SIZE runs of tools/probe_kernels.py, FETCH_SIZE doubled per MI355X_MICROARCH.md). PMC counters
     cannot be read from inside this process; null when no summary is committed."""
     import glob
@@ -213,7 +217,8 @@ def kernel_rooflines(dev, B, D=32):
         flops = 2.0 * M * Cout * 27 * (Cc + C2)
         out["conv_igemm " + name] = {"bound": "mfma", "ms": ms, "flops": flops, "achieved": flops / ms / 1e9,
                                                   "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / FP32_MFMA_PEAK_TF,
-                                                  "used_by": "the direct form of the same convolution (`convops.winograd(False)`, odd grids, operands beyond the buffer range); "
+                                                  "used_by": "the direct form of the same convolution (`convops.winograd(False)`, odd grids, operands "
+                                                          "beyond the buffer range); "
                                                              "inference, refinement and training run the Winograd launches below"}
     # the same kernel as the fusion's inference path launches it: 16 Winograd point GEMMs per launch, 3 depth taps, K = 3 Cin
     R = B * D * (D // 2) * (D // 2)

@@ -28,7 +28,8 @@ def ddp_train_record(rank, world, dev, steps, scenes=4, grid=32):
     sample = {k: v.to(dev) for k, v in syn.make_sample(scenes, T_IN, 256, 1.5, seed=3000 + rank).items()}
     if grid == 64:
         gen = torch.Generator(device=dev).manual_seed(80 + rank)
-        sample["features_recon"] = torch.randn(scenes, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+        sample["features_recon"] = torch.randn(scenes, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5,
+                2).contiguous().permute(0, 1, 5, 2, 3, 4)
     ds = syn.SyntheticDataset(1.5)
     loss = [None]
 
@@ -44,14 +45,17 @@ def ddp_train_record(rank, world, dev, steps, scenes=4, grid=32):
     grad_bytes = sum(p.numel() for p in ddp.parameters() if p.requires_grad) * 4
     return {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered views/scene, "
                         "%s, SyncBatchNorm + DDP, clip 10, Adam" % (scenes, "reference-native 32^3 / 64^3 grids" if grid == 32 else
-                                                                    "128^3-voxel render grid from synthetic [128,64^3] feature volumes (encoder not run)") + TRAIN_CAVEATS,
-            "perceptual_term": "excluded", "deterministic": False, "scenes_per_gpu": scenes, "global_batch": scenes * world, "feature_grid": grid, "steps": steps,
+                                                                    "128^3-voxel render grid from synthetic [128,64^3] feature volumes "
+                                                                            "(encoder not run)") + TRAIN_CAVEATS,
+            "perceptual_term": "excluded", "deterministic": False, "scenes_per_gpu": scenes, "global_batch": scenes * world, "feature_grid": grid,
+                    "steps": steps,
             "ms_per_step": s_sync * 1e3, "views_per_s": scenes * 10 * world / s_sync, "ms_per_step_no_sync": s_nosync * 1e3,
             "gradient_all_reduce_exposed_ms": (s_sync - s_nosync) * 1e3,
             "gradient_bytes_all_reduced_per_step": grad_bytes, "syncbn_layers": n_bn,
             "syncbn_bytes_all_reduced_per_step": (2 * bn_ch + n_bn) * 8 + 2 * bn_ch * 8,
             "mean_loss_all_ranks": fdist.all_reduce_scalars([l_sync], dev, "sum")[0] / world,
-            "note": "no_sync = the same step without DDP's gradient all-reduce (SyncBatchNorm statistics still exchanged): the difference is the all-reduce time "
+            "note": "no_sync = the same step without DDP's gradient all-reduce (SyncBatchNorm statistics still exchanged): the difference is the "
+                    "all-reduce time "
                     "the backward does not hide"}
 
 
@@ -68,21 +72,28 @@ def ray_sharded_joint_record(rank, world, dev, steps, grid=32):
     torch.manual_seed(1234)                                            # every rank draws the same Dropout masks: the replicas must predict the same poses
     model = FORGE(cfg)
     model.load_state_dict(syn.seeded_state_dict(model.state_dict(), 0))
-    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.to(dev).train())                                        # kubric_train_joint.py:136 (HIP SyncBatchNorm: one all-reduce per layer and direction)
+    # kubric_train_joint.py:136 (HIP SyncBatchNorm: one all-reduce per layer and direction)
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model.to(dev).train())
     ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)         # kubric_train_joint.py:141
-    params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head, model.render) for p in m.parameters()]
+    params = [p for m in (model.encoder_traj, model.pose_head, model.encoder_3d.fusion_feature, model.encoder_3d.density_head,
+            model.render) for p in m.parameters()]
     opt = torch.optim.Adam(params, lr=1e-4, fused=True)
-    sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}           # the same scene on every rank (train_step broadcasts rank 0's anyway)
+    # the same scene on every rank (train_step broadcasts rank 0's anyway)
+    sample = {k: v.to(dev) for k, v in syn.make_sample(1, 10, 256, 1.5, seed=12).items()}
     if grid == 64:
         gen = torch.Generator(device=dev).manual_seed(79)
-        sample["features_recon"] = torch.randn(1, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+        sample["features_recon"] = torch.randn(1, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5,
+                2).contiguous().permute(0, 1, 5, 2, 3, 4)
     ds = syn.SyntheticDataset(1.5)
     loss = [None]
 
     def step():
         loss[0] = train.train_step(cfg, sample, ds, ddp, opt, dev, loss_func=train.compute_all_loss_nvs)[0]
-    out = {"workload": "BASELINE configs[4] step: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input + 5 novel views -> 10 rendered views, rays of every "
-                       "view sharded over the ranks in row bands; %s; DDP over the replicas" % ("reference-native grids" if grid == 32 else "128^3-voxel render grid (synthetic 64^3 features)") + TRAIN_CAVEATS,
+    out = {"workload": "BASELINE configs[4] step: FORGE joint 2D3D fine-tune (predicted poses), 1 scene x 5 input + 5 novel views -> 10 rendered views, "
+            "rays of every "
+                       "view sharded over the ranks in row bands; %s; DDP over "
+                               "the replicas" % ("reference-native grids" if grid == 32 else "128^3-voxel render grid (synthetic "
+                                       "64^3 features)") + TRAIN_CAVEATS,
            "perceptual_term": "excluded", "deterministic": False,
            "feature_grid": grid, "steps": steps, "band_rows": 128 // world if 128 % world == 0 else None}
     train.enable_ray_sharding(ddp, False)
@@ -102,7 +113,8 @@ def ray_sharded_joint_record(rank, world, dev, steps, grid=32):
     if 128 % world == 0 and grid == 32:                               # once per line (the grid-64 record does not repeat it)
         _, extr, _ = syn.orbit_cameras(10, 1.5, 10.0)
         K = syn.intrinsics(256) / 2.0
-        cam = torch.cat([extr[:, :3, :3].reshape(10, 9), extr[:, :3, 3], K[0, 0].expand(10, 1), K[1, 1].expand(10, 1), K[0, 2].expand(10, 1), K[1, 2].expand(10, 1)],
+        cam = torch.cat([extr[:, :3, :3].reshape(10, 9), extr[:, :3, 3], K[0, 0].expand(10, 1), K[1, 1].expand(10, 1), K[0, 2].expand(10, 1), K[1,
+                2].expand(10, 1)],
                         dim=1).contiguous().to(dev)
         v2v = torch.zeros(10, dtype=torch.int32, device=dev)
         for D in (64, 128):

@@ -32,7 +32,8 @@ def train_bench(args, rank, world, dev, affinity):
             # configs[3]'s REAL per-GPU shape: the 128^3-voxel render grid = 64^3 feature grid; synthetic feature volumes ride in the sample
             # (FORGE_poseEstimator3D.forward(features_recon=): the encoder cannot produce them from 256^2 images and is not run)
             gen = torch.Generator(device=dev).manual_seed(78 + rank)
-            sample["features_recon"] = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5, 2).contiguous().permute(0, 1, 5, 2, 3, 4)
+            sample["features_recon"] = torch.randn(B, T_IN, 128, 64, 64, 64, device=dev, generator=gen).mul_(0.5).permute(0, 1, 3, 4, 5,
+                    2).contiguous().permute(0, 1, 5, 2, 3, 4)
         ds = syn.SyntheticDataset(1.5)
 
         def step():
@@ -57,14 +58,17 @@ def train_bench(args, rank, world, dev, affinity):
     if rank == 0:
         ms = dt / args.steps * 1e3 if dt > 0 else None
         emit({
-            "metric": "rendered views/sec incl. backward (GT-pose training step, 10 views/scene, %d^3 voxel)" % (2 * args.grid), "value": views * args.steps / dt if dt > 0 else None,
+            "metric": "rendered views/sec incl. backward (GT-pose training step, 10 views/scene, %d^3 voxel)" % (2 * args.grid),
+                    "value": views * args.steps / dt if dt > 0 else None,
             "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks_ok": int(ranks_ok), "errors": [e for e in errs if e],
             "process_group": pg, "repeats": region_stats(dts, args.steps, views)[1] if dt > 0 else None,
             "mean_loss_all_ranks": loss_sum / max(ranks_ok, 1.0),
             "config": {"workload": "BASELINE configs[3] step: FORGE_poseEstimator3D GT-pose training, %d scene(s)/GPU x 5 views -> 3 fusions -> 10 rendered "
-                                   "views/scene, %s, SyncBatchNorm + DDP" % (B, "reference-native 32^3 / 64^3 grids" if args.grid == 32 else "128^3-voxel render grid from synthetic "
-                                   "[128,64^3] feature volumes (encoder not run: its forward, backward and gradient all-reduce are not in this number)") + TRAIN_CAVEATS,
+                                   "views/scene, %s, SyncBatchNorm + DDP" % (B, "reference-native 32^3 / "
+                                           "64^3 grids" if args.grid == 32 else "128^3-voxel render grid from synthetic "
+                                   "[128,64^3] feature volumes (encoder not run: its forward, backward and gradient all-reduce are not in "
+                                           "this number)") + TRAIN_CAVEATS,
                        "perceptual_term": "excluded", "deterministic": False, "scenes_per_gpu": B, "feature_grid": args.grid,
                        "global_batch": B * world, "parallelism": "dp%d (DDP bucketed RCCL all-reduce of 221 MB fp32 gradients; HIP SyncBatchNorm)" % world,
                        "rank0_affinity": affinity}}, args.full_record)

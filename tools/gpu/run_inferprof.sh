@@ -1,5 +1,5 @@
 # rocprofv3 kernel statistics of the inference bench command, ONE step at a time (a kernel's duration is its own): tag = $1
-TAG=${1:-r04_infer_b1}
+TAG=${1:-infer_b1}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_inf -o inf --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --repeats 1 --pipeline-depth 1 --no-cpu-baseline --no-oracle-check --no-microbench --no-extra ${BENCH_ARGS:-} > $GRAFT_REPO_ROOT/gpurun_out/${TAG}.json 2> $GRAFT_REPO_ROOT/gpurun_out/${TAG}.err
 cd $GRAFT_REPO_ROOT
@@ -18,7 +18,7 @@ print("total kernel ms:", tot / 1e6)
 for r in rows[:22]:
     print("%-86s %6s calls %9.3f ms %6.2f%%  avg %8.1f us" % (r["Name"][:86], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["Percentage"]), float(r["AverageNs"]) / 1e3))
 try:
-    j = json.loads(open("gpurun_out/%s.json" % tag).read().strip().splitlines()[-1])
+    j = json.loads(open("gpurun_out/%s_bench_line.json" % tag.replace("_rocprofv3", "")).read().strip().splitlines()[-1])
     print("bench:", j["value"], "views/s", j["ms_per_step"], "ms/step")
 except Exception as e:
     print("bench line unreadable:", e)

@@ -132,6 +132,12 @@ def compact(full):
     if isinstance(full.get("extra_configs"), list):
         c["extra"] = {e.get("name", "?"): extra_row(e) for e in full["extra_configs"] if isinstance(e, dict)}
         c["extra_columns"] = ["ms_per_step", "views_per_s", "executed_frac"]
+        # the same step with several replays / refinement instances in flight, as the headline runs configs[1] (throughput, not latency)
+        fl = {e.get("name", "?"): [sig(e["pipelined"].get("ms_per_step"), 4), sig(e["pipelined"].get("views_per_s"), 4),
+                                   sig(e["pipelined"].get("executed_frac"), 3), e["pipelined"].get("depth")]
+              for e in full["extra_configs"] if isinstance(e, dict) and isinstance(e.get("pipelined"), dict) and "ms_per_step" in e["pipelined"]}
+        if fl:
+            c["extra_in_flight"] = fl
     if isinstance(full.get("strong_scaling"), dict):
         c["strong_scaling"] = pick(full["strong_scaling"], ("total_scenes", "scenes_per_gpu", "ms_per_step", "views_per_s", "ranks_ok"))
     if isinstance(full.get("multi_rank"), dict):
@@ -146,7 +152,7 @@ def dumps(c):
     """Strict one-line JSON of the compact record, shrunk until it fits MAX_LINE (optional parts go first; the contract keys, roofline and
     cpu_baseline never do)."""
     c = strict(c)
-    for drop in (None, "hbm_kernels_frac", "repeats", "extra_columns", "multi_rank_columns", "errors", "extra", "strong_scaling", "multi_rank"):
+    for drop in (None, "extra_in_flight", "hbm_kernels_frac", "repeats", "extra_columns", "multi_rank_columns", "errors", "extra", "strong_scaling", "multi_rank"):
         if drop is not None:
             c.pop(drop, None)
         line = json.dumps(c, allow_nan=False, separators=(",", ":"))

@@ -138,6 +138,11 @@ def compact(full):
               for e in full["extra_configs"] if isinstance(e, dict) and isinstance(e.get("pipelined"), dict) and "ms_per_step" in e["pipelined"]}
         if fl:
             c["extra_in_flight"] = fl
+        rp = {e.get("name", "?"): [sig(e["hipgraph_replay"].get("ms_per_step"), 4), sig(e["hipgraph_replay"].get("views_per_s"), 4),
+                                   sig(e["hipgraph_replay"].get("executed_frac"), 3)]
+              for e in full["extra_configs"] if isinstance(e, dict) and isinstance(e.get("hipgraph_replay"), dict) and "ms_per_step" in e["hipgraph_replay"]}
+        if rp:                                           # the training steps whose `extra` row is the eager (host-launched) step: the same step as ONE hipGraph
+            c["extra_hipgraph_replay"] = rp
     if isinstance(full.get("strong_scaling"), dict):
         c["strong_scaling"] = pick(full["strong_scaling"], ("total_scenes", "scenes_per_gpu", "ms_per_step", "views_per_s", "ranks_ok"))
     if isinstance(full.get("multi_rank"), dict):
@@ -152,7 +157,7 @@ def dumps(c):
     """Strict one-line JSON of the compact record, shrunk until it fits MAX_LINE (optional parts go first; the contract keys, roofline and
     cpu_baseline never do)."""
     c = strict(c)
-    for drop in (None, "extra_in_flight", "hbm_kernels_frac", "repeats", "extra_columns", "multi_rank_columns", "errors", "extra", "strong_scaling", "multi_rank"):
+    for drop in (None, "extra_hipgraph_replay", "extra_in_flight", "hbm_kernels_frac", "repeats", "extra_columns", "multi_rank_columns", "errors", "extra", "strong_scaling", "multi_rank"):
         if drop is not None:
             c.pop(drop, None)
         line = json.dumps(c, allow_nan=False, separators=(",", ":"))

@@ -93,8 +93,8 @@ def stage_timers(model):
         side = {co.EPI_GRU_GATES: (2 if out2 is not None else 1) * Cout // 2 + Cout // 2, co.EPI_GRU_OUT: 3 * Cout + (Cout if out2 is not None else 0)}.get(
             epilogue, Cout if out is not None else 0)
         side += 4 * Cout if kw.get("Mm2") is not None else 0
-        # reads 16 points x R x Cout = 4x, then the tail's operands
-        rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * (4 * Cout + side)))
+        # reads 16 points x R x Cout = 4x (8 planes = 2x when the row stage ran in the GEMM epilogue), then the tail's operands
+        rec.setdefault("wino_output_kernel", []).append((e0, e1, 4.0 * rows * ((2 if kw.get("half") else 4) * Cout + side)))
         return r
     co.wino_gemm, co.wino_input, co.wino_output = gemm_timed, input_timed, output_timed
     undo.append(lambda: (setattr(co, "wino_gemm", o_g), setattr(co, "wino_input", o_i), setattr(co, "wino_output", o_o)))

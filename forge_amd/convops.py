@@ -534,15 +534,27 @@ def wino_input(x, C, ld, n, D, H, W, bs=0, out=None, nsum=1, sum_stride=0):
     return V
 
 
+def wino_half_applies(R, Cout, Cin):
+    """The inference launches whose inverse transform's row stage runs in the GEMM epilogue (forge_wino_gemm_half / forge_wino_output_half, bitwise
+    the same results, half the point-product bytes through HBM): those forge_wino_gemm would give its 64 x 128 tile, without a forced plan."""
+    return STATE.plan_override is None and wino_gemm_tile(R, Cout, Cin) == "B"
+
+
 @_lib.on_tensor_device
-def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1):
+def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1, half=False):
     """Mm[16][n D Ht Wt][Cout] = the 16 point GEMMs. V1 [16][n views D Ht Wt][C1] may hold `views` views per batch element (the
-    transformed inputs of every view of a scene, made by ONE wino_input launch): this call reads view `view`. V2 [16][R][C2] or None."""
+    transformed inputs of every view of a scene, made by ONE wino_input launch): this call reads view `view`. V2 [16][R][C2] or None.
+    half: Mm receives the 8 planes [2][4][R][Cout] of forge_wino_gemm_half (its first half is used); pair with wino_output(half=True)."""
     vol = D * Ht * Wt
     kd = U.shape[1]
     if U.shape != (16, kd, Cout, C1 + C2) or kd not in (1, 3):
         raise ValueError("transformed weight %s does not match Cout=%d Cin=%d" % (tuple(U.shape), Cout, C1 + C2))
     p1 = ctypes.c_void_p(V1.data_ptr() + 4 * view * vol * C1)
+    if half:
+        _lib.check(_lib.lib().forge_wino_gemm_half(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
+                                                   0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd,
+                                                   _lib.current_stream()), "forge_wino_gemm_half")
+        return Mm
     _lib.check(_lib.lib().forge_wino_gemm(p1, C1, C1, views * vol if views > 1 else 0, V1.shape[1] * C1, _lib.ptr(V2), C2, C2, 0,
                                           0 if V2 is None else V2.shape[1] * C2, _lib.ptr(U), _lib.ptr(Mm), n, D, Ht, Wt, Cout, kd,
                                           ord(wino_gemm_tile(n * vol, Cout, C1 + C2)), _lib.current_stream()),
@@ -559,10 +571,18 @@ def wino_gemm_tile(R, Cout, Cin):
 
 
 @_lib.on_tensor_device
-def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1):
+def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1, half=False):
     """out = epilogue(A^T (Mm + Mm2) A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles. Mm2 (optional)
-    [16][n views D H/2 W/2][Cout]: point products of the input half for `views` views per batch element; this call adds view `view`."""
+    [16][n views D H/2 W/2][Cout]: point products of the input half for `views` views per batch element; this call adds view `view`.
+    half: Mm holds wino_gemm(half=True)'s 8 planes (column stage only; no Mm2)."""
     vol = D * (H // 2) * (W // 2)
+    if half:
+        if Mm2 is not None:
+            raise ValueError("wino_output(half=True) takes no second addend")
+        _lib.check(_lib.lib().forge_wino_output_half(_lib.ptr(Mm), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
+                                                     _lib.ptr(aux_h), _lib.ptr(aux_z), _lib.ptr(out), _lib.ptr(out2), _lib.ptr(out3), n, D, H, W, Cout, ldo,
+                                                     epilogue, _lib.current_stream()), "forge_wino_output_half")
+        return out
     p2 = None if Mm2 is None else ctypes.c_void_p(Mm2.data_ptr() + 4 * view * vol * Cout)
     _lib.check(_lib.lib().forge_wino_output(_lib.ptr(Mm), p2, views * vol, 0 if Mm2 is None else Mm2.shape[1] * Cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
                                             _lib.ptr(aux_h), _lib.ptr(aux_z), _lib.ptr(out), _lib.ptr(out2), _lib.ptr(out3), n, D, H, W, Cout, ldo,

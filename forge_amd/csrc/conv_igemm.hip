@@ -100,8 +100,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // float offset o
 // order, bitwise the same results): +5..21 % per launch (profiles/TUNING_LOG.md, round 3: 64x128 tile 106 -> 129 TF on the Winograd gates
 // GEMM, 128x128 tile 112 -> 135 TF on the K = 6912 direct launch). A third LDS stage (loads two steps ahead) was slower than two: the extra
 // LDS costs a resident workgroup per CU.
-template <int BM, int BN, int NW, int MT = 1>
+//
+// RS = 1 (forge_wino_gemm_half, 64x128 tile): one workgroup runs the FOUR Winograd points i = 0..3 of a point column j on its tile, one K loop after
+// the other into four accumulator sets (the first stage of the next point is loaded under the last step of the current one), and its epilogue
+// applies the ROW stage of the inverse transform A^T M A in registers - the same lane holds element (row, col) of all four points:
+// s0 = (m0 + m1) + m2, s1 = (m1 - m2) - m3, wino_output_kernel's own operations in its own order - and stores 2 planes instead of 4:
+// Mm8 [2][4][R][Cout]. The point products then cross HBM as 2x instead of 4x the output tensor, written here and read by the inverse transform.
+template <int BM, int BN, int NW, int MT = 1, int RS = 0>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int NP = RS ? 4 : 1;                   // points per workgroup
     constexpr int WM = BM / (32 * MT), WN = NW / WM; // NW waves as WM(M) x WN(N); wave tile (32 MT) x (BN / WN)
     constexpr int NT = BN / (32 * WN);              // 32-col MFMA tiles per wave
     static_assert(NT >= 1 && WM * WN == NW && NT * 32 * WN == BN && WM * 32 * MT == BM, "unsupported tile");
@@ -145,7 +152,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     const int s_begin = (int)((long long)ks * nsteps_all / a.ksplit), s_end = (int)((long long)(ks + 1) * nsteps_all / a.ksplit);
     const int nsteps = s_end - s_begin;
 
-    const forge_v4i32 w1 = make_rsrc_words(a.in1 + pb * a.pt1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 + pb * a.pt2 : a.in1, a.in2 ? a.span2 : 0),
+    // RS: pb = the point column j; the workgroup's points are pb, pb + 4, pb + 8, pb + 12 (descriptors re-made at every point switch)
+    forge_v4i32 w1 = make_rsrc_words(a.in1 + pb * a.pt1, a.span1), w2 = make_rsrc_words(a.in2 ? a.in2 + pb * a.pt2 : a.in1, a.in2 ? a.span2 : 0),
                 ww = make_rsrc_words(a.wp + pb * a.ptw, (long long)a.ntaps * a.Cout * Cin * 4);
     // LDS byte address of this WAVE's first 1 KB block of a stage (lane L lands at + 16 L: the row-major [row][32 k] image, 8 lanes per row)
     const unsigned lds_wave = lds_addr(smem) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     // inside the input grid; the input row of tap t is base + delta(t) with the uniform delta(t) = (dz Hi + dy) Wi + dx (LDS table),
     // so a tap switch costs a shift, a test and an add per row. The other tiles switch taps once per Cin / 32 K-steps and compute it directly.
     constexpr bool KC_OUTER = (BM == 128 && BN == 128);
+    static_assert(!RS || (!KC_OUTER && MT == 1), "the row-stage form exists on the tap-outer tiles");
     __shared__ int sdelta[KC_OUTER ? 2 * MAX_TAPS : 1];             // byte deltas of the taps for in1 / in2
     unsigned long long vmask[KC_OUTER ? ACH : 1];
     unsigned base1[KC_OUTER ? ACH : 1], base2[KC_OUTER ? ACH : 1];  // byte offset of (row of tap (0,0,0), this thread's 16-byte chunk) in in1 / in2
@@ -246,13 +255,16 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < BCH; ++j) lds_dma16(ww, boff[j] + wbase, stage + (unsigned)(A_FLOATS * 4 + j * NW * 1024));
     };
-    f32x16 acc[MT][NT];
+    f32x16 accs[NP][MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[q][i][j][r] = 0.f;
+    f32x16 (&acc)[MT][NT] = accs[0];                                // the single-point form's accumulators (epilogues below)
 
     const int half = lane >> 5, l31 = lane & 31;
     // K order of the 128x128 tile: channel chunk OUTER, tap INNER. All workgroups of an XCD walk the taps of one 32-channel slice of
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
     FORGE_STAMP(1);
     // One K-step = 4 MFMA groups of 8 k-values. (A/B in round 1: issuing the next tile's global loads after group 0 and its LDS
     // writes after group 2, pinned with sched_barrier, changed nothing: 127.3 vs 126.3 TF on the ConvGRU gates shape.)
-    auto mfma_group = [&](const float* sa, const float* sb, int g) {
+    auto mfma_group = [&](f32x16 (&acc)[MT][NT], const float* sa, const float* sb, int g) {
         float4 fa[MT], fb[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4*>(sa + lds_off(wm * (32 * MT) + i * 32 + l31, 2 * g + half));
@@ -302,18 +314,30 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
     };
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
-        const float* sb = sa + A_FLOATS;
-        if (s + 1 < nsteps) {                                     // the other stage was last read in step s - 1: every wave is past that barrier
-            advance();
-            issue_step(t, kc, buf ^ 1);                           // in flight under this step's MFMAs
-        }
+    int buf = 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) mfma_group(sa, sb, g);
-        lds_dma_wait();                                           // this wave's part of step s + 1 is in LDS ...
-        __syncthreads();                                          // ... and so is everybody else's
+    for (int q = 0; q < NP; ++q) {
+        for (int s = 0; s < nsteps; ++s) {
+            const float* sa = smem + buf * (A_FLOATS + B_FLOATS);
+            const float* sb = sa + A_FLOATS;
+            if (s + 1 < nsteps) {                                 // the other stage was last read in step s - 1: every wave is past that barrier
+                advance();
+                issue_step(t, kc, buf ^ 1);                       // in flight under this step's MFMAs
+            } else if (q + 1 < NP) {                              // RS: the next point's first stage, in flight under this point's last step
+                const long long pn = pb + 4 * (q + 1);
+                w1 = make_rsrc_words(a.in1 + pn * a.pt1, a.span1);
+                w2 = make_rsrc_words(a.in2 ? a.in2 + pn * a.pt2 : a.in1, a.in2 ? a.span2 : 0);
+                ww = make_rsrc_words(a.wp + pn * a.ptw, (long long)a.ntaps * a.Cout * Cin * 4);
+                t = s_begin / kchunks; kc = s_begin - t * kchunks; t += t_lo;
+                prep_tap(t);
+                issue_step(t, kc, buf ^ 1);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_group(accs[q], sa, sb, g);
+            lds_dma_wait();                                       // this wave's part of the next step is in LDS ...
+            __syncthreads();                                      // ... and so is everybody else's
+            buf ^= 1;
+        }
     }
 
     FORGE_STAMP(2);
@@ -427,6 +451,26 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
     };
+    if constexpr (RS) {                                             // row stage of A^T M A over the four points, two planes stored (identity rows, no bias)
+        float* const o0 = a.out + pb * a.pto;                        // plane (i' = 0, j)
+        float* const o1 = a.out + (pb + 4) * a.pto;                  // plane (i' = 1, j)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + l31;
+            if (col < a.Cout) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long orow = s_row[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                    if (orow >= 0) {
+                        const float m0 = accs[0][0][j][r], m1 = accs[1][0][j][r], m2 = accs[NP - 2][0][j][r], m3 = accs[NP - 1][0][j][r];
+                        o0[orow * a.ldo + col] = (m0 + m1) + m2;
+                        o1[orow * a.ldo + col] = (m1 - m2) - m3;
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (a.ksplit > 1) {                                             // raw partial sums; conv_splitk_epilogue_kernel finishes the job
         float* wsl = a.ws + (long long)ks * M * a.Cout;
 #pragma unroll
@@ -847,9 +891,17 @@ static ConvPlan plan_conv(long long M, int Cout, int Cin, int ntaps, bool can_sp
 }
 
 // Launch conv_igemm_kernel with the planned tile: ceil(M / BM) x ceil(Cout / BN) workgroups per (K slice, phase, batched problem).
-static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st) {
+static int launch_conv_tile(const ConvArgs& a, char tile, hipStream_t st, bool row_stage = false) {
     const long long M = (long long)a.n * a.D * a.H * a.W;
     auto nblk = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn); };
+    if (row_stage) {                                                 // forge_wino_gemm_half: a.nbat = 4 point columns, four points per workgroup
+        const long long grid = nblk(64, 128) * a.nbat;
+        FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_wino_gemm_half: grid too large");
+        const size_t lds = 2 * (64 * BK + 128 * BK) * sizeof(float);
+        FORGE_SET_MAX_LDS_ONCE((conv_igemm_kernel<64, 128, 8, 1, 1>), lds);
+        hipLaunchKernelGGL((conv_igemm_kernel<64, 128, 8, 1, 1>), dim3((unsigned)grid), dim3(8 * 64), lds, st, a);
+        return 0;
+    }
 #define FORGE_LAUNCH_CONV(BMv, BNv, NWv)                                                                                   \
     do {                                                                                                                   \
         const long long grid = nblk(BMv, BNv) * a.ksplit * a.nphase * a.nbat;                                              \
@@ -998,8 +1050,8 @@ extern "C" int forge_wino_gemm_tile(long long R, int Cout, int Cin) {
 // the transformed inputs V[p] (rows = (n, z, tile row, tile col), channels-last, the channel concatenation of V1 and V2) with the
 // transformed weights U[p] [kd depth taps][Cout][C1 + C2] into Mm[p] [rows][Cout] - a kd-tap implicit GEMM over the tile grid, K = kd (C1 + C2);
 // kd = 3 for the 3x3x3 convolutions, kd = 1 for the 3x3 convolutions of a 2-D network (D = 1 or D = images: planes do not mix).
-extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
-                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile, forge_stream_t stream) {
+static int wino_gemm_impl(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
+                          long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile, bool half, forge_stream_t stream) {
     FORGE_REQUIRE(tile == 0 || (tile >= 'A' && tile <= 'E'), FORGE_EINVAL, "forge_wino_gemm: tile must be 0 (default rule) or 'A'..'E'");
     FORGE_REQUIRE(V1 && U && Mm && (kd == 1 || kd == 3), FORGE_EINVAL, "forge_wino_gemm: null pointer argument / kd not 1 or 3");
     FORGE_REQUIRE(n > 0 && D > 0 && Ht > 0 && Wt > 0 && Cout > 16, FORGE_EINVAL, "forge_wino_gemm: bad dims n=%d D=%d Ht=%d Wt=%d Cout=%d (Cout > 16)", n,
@@ -1017,9 +1069,22 @@ extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, 
                   "forge_wino_gemm: an operand spans >= 2 GiB per Winograd point (32-bit buffer offsets); split the batch");
     a.wp = U; a.slope = 1.f; a.out = Mm; a.n = n; a.D = D; a.H = Ht; a.W = Wt; a.is = 1; a.Di = D; a.Hi = Ht; a.Wi = Wt;
     a.Cout = Cout; a.ldo = Cout; a.ldr = Cout; a.ntaps = kd; a.os = 1; a.Do = D; a.Ho = Ht; a.Wo = Wt; a.nphase = 1; a.tpp = kd; a.epi = EPI_BIAS;
-    a.ksplit = 1; a.nbat = 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = (long long)kd * Cout * (C1 + C2); a.pto = R * Cout;
+    a.ksplit = 1; a.nbat = half ? 4 : 16; a.pt1 = pt1; a.pt2 = pt2; a.ptw = (long long)kd * Cout * (C1 + C2); a.pto = R * Cout;
     if (kd == 3) { a.tap[0][0] = -1; a.tap[2][0] = 1; }                 // depth taps (-1,0,0), (0,0,0), (1,0,0); kd = 1: the 2-D convolution's single tap
-    if (int rc = launch_conv_tile(a, (char)(tile ? tile : forge_wino_gemm_tile(R, Cout, C1 + C2)), (hipStream_t)stream)) return rc;
+    if (int rc = launch_conv_tile(a, (char)(tile ? tile : forge_wino_gemm_tile(R, Cout, C1 + C2)), (hipStream_t)stream, half)) return rc;
     FORGE_LAUNCH_CHECK("forge_wino_gemm");
     return 0;
+}
+
+extern "C" int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
+                               long long pt2, const float* U, float* Mm, int n, int D, int Ht, int Wt, int Cout, int kd, int tile, forge_stream_t stream) {
+    return wino_gemm_impl(V1, C1, ld1, bs1, pt1, V2, C2, ld2, bs2, pt2, U, Mm, n, D, Ht, Wt, Cout, kd, tile, false, stream);
+}
+
+// forge_wino_gemm with the ROW stage of the inverse transform applied in the GEMM's epilogue (conv_igemm_kernel<..., RS = 1>): Mm8 [2][4][R][Cout],
+// Mm8[i'][j] = sum over the four points (i, j) of A^T[i'][i] Mm[i][j] = (m0 + m1) + m2 | (m1 - m2) - m3 - bitwise what forge_wino_output computes
+// first. forge_wino_output_half finishes the transform. 64 x 128 tile only (the launches forge_wino_gemm_tile gives 'B').
+extern "C" int forge_wino_gemm_half(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
+                                    long long pt2, const float* U, float* Mm8, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream) {
+    return wino_gemm_impl(V1, C1, ld1, bs1, pt1, V2, C2, ld2, bs2, pt2, U, Mm8, n, D, Ht, Wt, Cout, kd, 'B', true, stream);
 }

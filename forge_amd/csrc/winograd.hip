@@ -152,7 +152,9 @@ struct WinoOutArgs {
 };
 
 // one thread = one tile x 4 output channels: 16 float4 loads, 24 float4 additions, then the element-wise tail of 2x2 output voxels
-template <int EPI>
+// HALF: Mm holds 8 planes [2][4] - the row stage s = A^T m was applied by the GEMM's epilogue (forge_wino_gemm_half) - and this kernel runs the
+// column stage only (8 instead of 16 float4 loads); no second addend.
+template <int EPI, bool HALF = false>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
     const int C4 = a.Cout >> 2, Ht = a.H >> 1, Wt = a.W >> 1;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -164,24 +166,31 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
     const int tw = (int)(q - t * (unsigned)Wt); q = t; t = q / (unsigned)Ht;
     const int th = (int)(q - t * (unsigned)Ht);                    // q / Ht = (n, z) plane index
     const float* mp = a.Mm + (long long)r * a.Cout + c;
-    float4 m[4][4];
+    float4 s[2][4];                                  // A^T m
+    if constexpr (HALF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(mp + (4 * i + j) * a.ptm);
-    if (a.Mm2) {
-        const unsigned R1 = (unsigned)(a.D * Ht * Wt), nn = r / R1;
-        const float* mp2 = a.Mm2 + ((long long)nn * a.bs2 + (r - nn * R1)) * a.Cout + c;
+            for (int j = 0; j < 4; ++j) s[i][j] = *reinterpret_cast<const float4*>(mp + (4 * i + j) * a.ptm);
+    } else {
+        float4 m[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[i][j] = f4_add(m[i][j], *reinterpret_cast<const float4*>(mp2 + (4 * i + j) * a.ptm2));
-    }
-    float4 s[2][4];                                  // A^T m
+            for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const float4*>(mp + (4 * i + j) * a.ptm);
+        if (a.Mm2) {
+            const unsigned R1 = (unsigned)(a.D * Ht * Wt), nn = r / R1;
+            const float* mp2 = a.Mm2 + ((long long)nn * a.bs2 + (r - nn * R1)) * a.Cout + c;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[0][j] = f4_add(f4_add(m[0][j], m[1][j]), m[2][j]);
-        s[1][j] = f4_sub(f4_sub(m[1][j], m[2][j]), m[3][j]);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[i][j] = f4_add(m[i][j], *reinterpret_cast<const float4*>(mp2 + (4 * i + j) * a.ptm2));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = f4_add(f4_add(m[0][j], m[1][j]), m[2][j]);
+            s[1][j] = f4_sub(f4_sub(m[1][j], m[2][j]), m[3][j]);
+        }
     }
     float4 y[2][2];
 #pragma unroll
@@ -391,9 +400,9 @@ extern "C" int forge_wino_input_dy(const float* dy, int ld, float* V, float* dM,
     return 0;
 }
 
-extern "C" int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
-                                 const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
-                                 int ldo, int epilogue, forge_stream_t stream) {
+static int wino_output_impl(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                            const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
+                            int ldo, int epilogue, bool half, forge_stream_t stream) {
     FORGE_REQUIRE(Mm && out, FORGE_EINVAL, "forge_wino_output: null pointer argument");
     FORGE_REQUIRE(n > 0 && D > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && Cout > 0 && Cout % 8 == 0 && ldo % 4 == 0, FORGE_ESHAPE,
                   "forge_wino_output: n=%d D=%d H=%d W=%d Cout=%d ldo=%d (H, W even; Cout multiple of 8; ldo of 4)", n, D, H, W, Cout, ldo);
@@ -412,12 +421,34 @@ extern "C" int forge_wino_output(const float* Mm, const float* Mm2, long long bs
     FORGE_REQUIRE(grid < (1ll << 31), FORGE_ESHAPE, "forge_wino_output: grid too large");
     const dim3 g((unsigned)grid), b(256);
     hipStream_t st = (hipStream_t)stream;
-    switch (epilogue) {
-        case W_BIAS: hipLaunchKernelGGL(wino_output_kernel<W_BIAS>, g, b, 0, st, a); break;
-        case W_AFFINE_ACT: hipLaunchKernelGGL(wino_output_kernel<W_AFFINE_ACT>, g, b, 0, st, a); break;
-        case W_GRU_GATES: hipLaunchKernelGGL(wino_output_kernel<W_GRU_GATES>, g, b, 0, st, a); break;
-        default: hipLaunchKernelGGL(wino_output_kernel<W_GRU_OUT>, g, b, 0, st, a); break;
+    if (half) {
+        switch (epilogue) {
+            case W_BIAS: hipLaunchKernelGGL((wino_output_kernel<W_BIAS, true>), g, b, 0, st, a); break;
+            case W_AFFINE_ACT: hipLaunchKernelGGL((wino_output_kernel<W_AFFINE_ACT, true>), g, b, 0, st, a); break;
+            case W_GRU_GATES: hipLaunchKernelGGL((wino_output_kernel<W_GRU_GATES, true>), g, b, 0, st, a); break;
+            default: hipLaunchKernelGGL((wino_output_kernel<W_GRU_OUT, true>), g, b, 0, st, a); break;
+        }
+    } else {
+        switch (epilogue) {
+            case W_BIAS: hipLaunchKernelGGL(wino_output_kernel<W_BIAS>, g, b, 0, st, a); break;
+            case W_AFFINE_ACT: hipLaunchKernelGGL(wino_output_kernel<W_AFFINE_ACT>, g, b, 0, st, a); break;
+            case W_GRU_GATES: hipLaunchKernelGGL(wino_output_kernel<W_GRU_GATES>, g, b, 0, st, a); break;
+            default: hipLaunchKernelGGL(wino_output_kernel<W_GRU_OUT>, g, b, 0, st, a); break;
+        }
     }
     FORGE_LAUNCH_CHECK("forge_wino_output");
     return 0;
+}
+
+extern "C" int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                                 const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
+                                 int ldo, int epilogue, forge_stream_t stream) {
+    return wino_output_impl(Mm, Mm2, bs2, pt2, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, false, stream);
+}
+
+// The column stage of the inverse transform + the fused tail on forge_wino_gemm_half's 8 planes Mm8 [2][4][R][Cout]: bitwise forge_wino_output's result.
+extern "C" int forge_wino_output_half(const float* Mm8, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
+                                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
+                                      int ldo, int epilogue, forge_stream_t stream) {
+    return wino_output_impl(Mm8, nullptr, 0, 0, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, true, stream);
 }

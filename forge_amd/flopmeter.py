@@ -20,7 +20,7 @@ def _igemm(a):          # forge_conv_igemm(in1,C1,ld1,bs1,in2,C2,ld2,bs2,wp,bias
     return 2.0 * n * D * H * W * Cout * ntaps * (C1 + C2)          # merged transposed-conv phases: M rows x ntaps / P taps x P phases = the same product
 
 
-def _wino_gemm(a):      # forge_wino_gemm(V1,C1,ld1,bs1,pt1,V2,C2,ld2,bs2,pt2,U,Mm,n,D,Ht,Wt,Cout,kd,tile,stream)
+def _wino_gemm(a):      # forge_wino_gemm(V1,C1,ld1,bs1,pt1,V2,C2,ld2,bs2,pt2,U,Mm,n,D,Ht,Wt,Cout,kd,tile,stream) / forge_wino_gemm_half (same, no tile)
     return 2.0 * 16 * _v(a[12]) * _v(a[13]) * _v(a[14]) * _v(a[15]) * _v(a[16]) * _v(a[17]) * (_v(a[1]) + _v(a[6]))
 
 
@@ -36,7 +36,7 @@ def _attention(a):      # forge_attention_fwd(q,k,v,v_batch_rows,out,B,Nq,Nk,d,s
     return 4.0 * _v(a[5]) * _v(a[6]) * _v(a[7]) * _v(a[8])
 
 
-_ENTRIES = {"forge_conv_igemm": _igemm, "forge_wino_gemm": _wino_gemm, "forge_conv_wgrad": _wgrad, "forge_wino_wgrad": _wino_wgrad,
+_ENTRIES = {"forge_conv_igemm": _igemm, "forge_wino_gemm": _wino_gemm, "forge_wino_gemm_half": _wino_gemm, "forge_conv_wgrad": _wgrad, "forge_wino_wgrad": _wino_wgrad,
             "forge_attention_fwd": _attention}
 
 

@@ -895,12 +895,13 @@ class ConvGRU_3D(co.PackedModule):
         BatchNorm + LeakyReLU tail (scratch Vh / Mc / t0); the view mean of models/encoder.py:62 is taken inside the first input transform."""
         b, D, H, W = geo
         C = h.shape[-1]
+        hf = co.wino_half_applies(b * D * (H // 2) * (W // 2), C, C)     # row stage of the inverse transform in the GEMM epilogue (bitwise the same)
         co.wino_input(src, C, C, b, D, H, W, bs=bs, out=Vh, nsum=nsum, sum_stride=sum_stride)
-        co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, H // 2, W // 2, C)
-        co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
+        co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, H // 2, W // 2, C, half=hf)
+        co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT, half=hf)
         co.wino_input(t0, C, C, b, D, H, W, out=Vh)
-        co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, H // 2, W // 2, C)
-        co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
+        co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, H // 2, W // 2, C, half=hf)
+        co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT, half=hf)
 
     def _fuse_wino(self, xr, h0=None):
         """fuse_hip with every 3x3x3 convolution as Winograd F(2x2, 3x3) x 3 depth taps (csrc/winograd.hip): 2.25x fewer MFMA FLOPs.
@@ -925,14 +926,15 @@ class ConvGRU_3D(co.PackedModule):
         else:
             h.copy_(h0.permute(0, 2, 3, 4, 1).reshape(M, C))
         z, hr, h2, out = new(), new(), t0, new()
+        hg, hc = co.wino_half_applies(R, 2 * C, 2 * C), co.wino_half_applies(R, C, 2 * C)
         for ti in range(t):
             co.wino_input(h, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t)
-            co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES)
+            co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t, half=hg)
+            co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, half=hg)
             co.wino_input(hr, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t)
+            co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t, half=hc)
             last = ti == t - 1
-            co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C, co.EPI_GRU_OUT)
+            co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C, co.EPI_GRU_OUT, half=hc)
             h, h2 = h2, h
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 

@@ -307,3 +307,51 @@ def test_input_transform_of_the_view_mean_equals_mean_then_transform():
     sub = co.wino_input(x[:, 1:], C, C, b, D, H, W, bs=t * vol, nsum=3, sum_stride=vol)    # a run of views 1..3
     ref3 = co.wino_input(((x[:, 1] + x[:, 2] + x[:, 3]) / 3.0).contiguous(), C, C, b, D, H, W)
     assert torch.equal(sub, ref3)
+
+
+@pytest.mark.parametrize("shape", [(1, 8, 32, 32, 64, 64, 128), (1, 9, 32, 30, 32, 32, 96), (2, 32, 32, 32, 128, 0, 256), (1, 8, 32, 32, 64, 0, 128)])
+def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_form(shape):
+    """forge_wino_gemm_half + forge_wino_output_half (the inverse transform's row stage in the GEMM epilogue: four points per workgroup, 8 planes through
+    HBM instead of 16) against forge_wino_gemm + forge_wino_output: the same fp32 operations in the same order, so every epilogue must agree BIT FOR BIT -
+    full and ragged tile rows / output columns, one and two concatenated operands, several batch elements (depth taps must not cross them)."""
+    from forge_amd import convops as co
+    n, D, H, W, C1, C2, Cout = shape
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x1 = torch.randn(n, D, H, W, C1, device=dev, generator=g)
+    x2 = torch.randn(n, D, H, W, C2, device=dev, generator=g) if C2 else None
+    U = co.wino_pack_weight(torch.randn(Cout, C1 + C2, 3, 3, 3, device=dev, generator=g) * 0.05)
+    R, M = n * D * (H // 2) * (W // 2), n * D * H * W
+    assert co.wino_half_applies(R, Cout, C1 + C2)
+    V1 = co.wino_input(x1, C1, C1, n, D, H, W)
+    V2 = None if x2 is None else co.wino_input(x2, C2, C2, n, D, H, W)
+    Mm, Mm8 = torch.empty(16, R, Cout, device=dev), torch.full((8, R, Cout), float("nan"), device=dev)
+    co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
+    co.wino_gemm(V1, C1, V2, C2, U, Mm8, n, D, H // 2, W // 2, Cout, half=True)
+    s0 = (Mm[0:4] + Mm[4:8]) + Mm[8:12]                              # rows of A^T M over the point index i (p = 4 i + j)
+    s1 = (Mm[4:8] - Mm[8:12]) - Mm[12:16]
+    assert torch.equal(Mm8[0:4], s0) and torch.equal(Mm8[4:8], s1)
+    bias, sc, sh = (torch.randn(Cout, device=dev, generator=g) for _ in range(3))
+    res = torch.randn(M, Cout, device=dev, generator=g)
+    for epi, kw in ((co.EPI_BIAS, {}), (co.EPI_AFFINE_ACT, dict(scale=sc, shift=sh, slope=0.01, residual=res))):
+        a, b = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
+        co.wino_output(Mm, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, a, None, None, n, D, H, W, Cout, Cout, epi)
+        co.wino_output(Mm8, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, b, None, None, n, D, H, W, Cout, Cout, epi,
+                       half=True)
+        assert torch.equal(a, b)
+    if Cout % 2 == 0:                                                 # the GRU tails: gates (z | r -> h r) on Cout = 2 Ch columns, state update on Cout columns
+        Ch = Cout // 2
+        h = torch.randn(M, Ch, device=dev, generator=g)
+        outs = []
+        for half in (False, True):
+            z, hr, r = (torch.empty(M, Ch, device=dev) for _ in range(3))
+            co.wino_output(Mm8 if half else Mm, bias, None, None, 1.0, None, h, None, z, hr, r, n, D, H, W, Cout, Ch, co.EPI_GRU_GATES, half=half)
+            outs.append((z, hr, r))
+        assert all(torch.equal(u, v) for u, v in zip(*outs))
+    hfull, zfull = torch.randn(M, Cout, device=dev, generator=g), torch.rand(M, Cout, device=dev, generator=g)
+    outs = []
+    for half in (False, True):
+        hn, hb, cand = (torch.empty(M, Cout, device=dev) for _ in range(3))
+        co.wino_output(Mm8 if half else Mm, bias, sc, sh, 1.0, None, hfull, zfull, hn, hb, cand, n, D, H, W, Cout, Cout, co.EPI_GRU_OUT, half=half)
+        outs.append((hn, hb, cand))
+    assert all(torch.equal(u, v) for u, v in zip(*outs))

@@ -45,7 +45,7 @@ SIGNATURES = {
     "forge_wino_input_dy": [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "forge_wino_gemm": [_P, _I, _I, _LL, _LL, _P, _I, _I, _LL, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_gemm_half": [_P, _I, _I, _LL, _LL, _P, _I, _I, _LL, _LL, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "forge_wino_output_half": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "forge_wino_output_half": [_P, _P, _LL, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_wino_gemm_tile": [_LL, _I, _I],
     "forge_wino_output": [_P, _P, _LL, _LL, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "forge_conv_igemm_plan": [_LL, _I, _I, _I, _I, _I, _I, _LL, _P, _P],

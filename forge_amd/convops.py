@@ -574,12 +574,11 @@ def wino_gemm_tile(R, Cout, Cin):
 def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1, half=False):
     """out = epilogue(A^T (Mm + Mm2) A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles. Mm2 (optional)
     [16][n views D H/2 W/2][Cout]: point products of the input half for `views` views per batch element; this call adds view `view`.
-    half: Mm holds wino_gemm(half=True)'s 8 planes (column stage only; no Mm2)."""
+    half: Mm (and Mm2) hold wino_gemm(half=True)'s 8 planes (column stage only)."""
     vol = D * (H // 2) * (W // 2)
-    if half:
-        if Mm2 is not None:
-            raise ValueError("wino_output(half=True) takes no second addend")
-        _lib.check(_lib.lib().forge_wino_output_half(_lib.ptr(Mm), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
+    if half:                                                            # Mm2 (if any) is in the 8-plane form too
+        p2 = None if Mm2 is None else ctypes.c_void_p(Mm2.data_ptr() + 4 * view * vol * Cout)
+        _lib.check(_lib.lib().forge_wino_output_half(_lib.ptr(Mm), p2, views * vol, 0 if Mm2 is None else Mm2.shape[1] * Cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),
                                                      _lib.ptr(aux_h), _lib.ptr(aux_z), _lib.ptr(out), _lib.ptr(out2), _lib.ptr(out3), n, D, H, W, Cout, ldo,
                                                      epilogue, _lib.current_stream()), "forge_wino_output_half")
         return out

@@ -152,8 +152,8 @@ struct WinoOutArgs {
 };
 
 // one thread = one tile x 4 output channels: 16 float4 loads, 24 float4 additions, then the element-wise tail of 2x2 output voxels
-// HALF: Mm holds 8 planes [2][4] - the row stage s = A^T m was applied by the GEMM's epilogue (forge_wino_gemm_half) - and this kernel runs the
-// column stage only (8 instead of 16 float4 loads); no second addend.
+// HALF: Mm (and Mm2) hold 8 planes [2][4] - the row stage s = A^T m was applied by the GEMM's epilogue (forge_wino_gemm_half) - and this kernel runs the
+// column stage only (8 instead of 16 float4 loads per operand).
 template <int EPI, bool HALF = false>
 __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
     const int C4 = a.Cout >> 2, Ht = a.H >> 1, Wt = a.W >> 1;
@@ -172,6 +172,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const WinoOutArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) s[i][j] = *reinterpret_cast<const float4*>(mp + (4 * i + j) * a.ptm);
+        if (a.Mm2) {                                  // the second addend in the same 8-plane form (the transform is linear)
+            const unsigned R1 = (unsigned)(a.D * Ht * Wt), nn = r / R1;
+            const float* mp2 = a.Mm2 + ((long long)nn * a.bs2 + (r - nn * R1)) * a.Cout + c;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[i][j] = f4_add(s[i][j], *reinterpret_cast<const float4*>(mp2 + (4 * i + j) * a.ptm2));
+        }
     } else {
         float4 m[4][4];
 #pragma unroll
@@ -446,9 +454,10 @@ extern "C" int forge_wino_output(const float* Mm, const float* Mm2, long long bs
     return wino_output_impl(Mm, Mm2, bs2, pt2, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, false, stream);
 }
 
-// The column stage of the inverse transform + the fused tail on forge_wino_gemm_half's 8 planes Mm8 [2][4][R][Cout]: bitwise forge_wino_output's result.
-extern "C" int forge_wino_output_half(const float* Mm8, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
-                                      const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
-                                      int ldo, int epilogue, forge_stream_t stream) {
-    return wino_output_impl(Mm8, nullptr, 0, 0, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, true, stream);
+// The column stage of the inverse transform + the fused tail on forge_wino_gemm_half's 8 planes Mm8 [2][4][R][Cout] (+ a second addend in the same form, as
+// forge_wino_output's Mm2): without Mm2_8 bitwise forge_wino_output's result; with it the two operands are row-combined before they are added.
+extern "C" int forge_wino_output_half(const float* Mm8, const float* Mm2_8, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope,
+                                      const float* residual, const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W,
+                                      int Cout, int ldo, int epilogue, forge_stream_t stream) {
+    return wino_output_impl(Mm8, Mm2_8, bs2, pt2, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, true, stream);
 }

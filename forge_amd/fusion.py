@@ -953,13 +953,17 @@ class ConvGRU_3D(co.PackedModule):
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         geo = (b, D, H, W)
         Vx = co.wino_input(xr, C, C, b * t, D, H, W)
-        MXg = torch.empty(16, b * t * R1, 2 * C, dtype=torch.float32, device=dev)
-        MXc = torch.empty(16, b * t * R1, C, dtype=torch.float32, device=dev)
-        co.wino_gemm(Vx, C, None, 0, p["gate_Ux"], MXg, b * t, D, Ht, Wt, 2 * C)
-        co.wino_gemm(Vx, C, None, 0, p["out_Ux"], MXc, b * t, D, Ht, Wt, C)
+        # 8-plane form (row stage of the inverse transform in the GEMM epilogue) when every launch of the chain takes the 64 x 128 tile: the shared
+        # input-half products and the per-step hidden-half products are then row-combined separately and added in the column-stage kernel
+        hf = all(co.wino_half_applies(r_, n_, C) for r_, n_ in ((R, 2 * C), (R, C), (b * t * R1, 2 * C), (b * t * R1, C)))
+        P = 8 if hf else 16
+        MXg = torch.empty(P, b * t * R1, 2 * C, dtype=torch.float32, device=dev)
+        MXc = torch.empty(P, b * t * R1, C, dtype=torch.float32, device=dev)
+        co.wino_gemm(Vx, C, None, 0, p["gate_Ux"], MXg, b * t, D, Ht, Wt, 2 * C, half=hf)
+        co.wino_gemm(Vx, C, None, 0, p["out_Ux"], MXc, b * t, D, Ht, Wt, C, half=hf)
         Vh = torch.empty(16, R, C, dtype=torch.float32, device=dev)
-        Mm = torch.empty(16, R, 2 * C, dtype=torch.float32, device=dev)
-        Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)
+        Mm = torch.empty(P, R, 2 * C, dtype=torch.float32, device=dev)
+        Mc = Mm.view(-1)[:P * R * C].view(P, R, C)
         outs = []
         for grp in groups:
             grp = list(grp)
@@ -973,13 +977,13 @@ class ConvGRU_3D(co.PackedModule):
             z, hr, h2, out = new(), new(), t0, new()
             for k, ti in enumerate(grp):
                 co.wino_input(h, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vh, C, None, 0, p["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C)
-                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t)
+                co.wino_gemm(Vh, C, None, 0, p["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C, half=hf)
+                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t, half=hf)
                 co.wino_input(hr, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vh, C, None, 0, p["out_Uh"], Mc, b, D, Ht, Wt, C)
+                co.wino_gemm(Vh, C, None, 0, p["out_Uh"], Mc, b, D, Ht, Wt, C, half=hf)
                 last = k == len(grp) - 1
                 co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C,
-                               co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t)
+                               co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t, half=hf)
                 h, h2 = h2, h
             outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
         return outs

@@ -273,13 +273,13 @@ int forge_wino_gemm(const float* V1, int C1, int ld1, long long bs1, long long p
 /* The same pair with the inverse transform's ROW stage moved into the GEMM's epilogue (inference of models/fusion.py:29-35, 61-68 and models/encoder.py:36-40):
  * one workgroup runs the four points (i = 0..3, j) of a point column on its 64 x 128 tile and stores s0 = (m0 + m1) + m2, s1 = (m1 - m2) - m3 - the
  * operations forge_wino_output performs first, in its order - as Mm8 [2][4][R][Cout]: the point products cross HBM as 2x instead of 4x the output
- * tensor. forge_wino_output_half runs the column stage + the same fused tails on Mm8 (no second addend). Results are bitwise those of
- * forge_wino_gemm + forge_wino_output. For the launches forge_wino_gemm_tile answers with 'B' (R >= 2048 tile rows, Cout > 64). */
+ * tensor. forge_wino_output_half runs the column stage + the same fused tails on Mm8. Without a second addend the results are bitwise those of
+ * forge_wino_gemm + forge_wino_output; a second addend (the shared input halves) arrives in the same 8-plane form and is added after the row stage. For the launches forge_wino_gemm_tile answers with 'B' (R >= 2048 tile rows, Cout > 64). */
 int forge_wino_gemm_half(const float* V1, int C1, int ld1, long long bs1, long long pt1, const float* V2, int C2, int ld2, long long bs2,
                          long long pt2, const float* U, float* Mm8, int n, int D, int Ht, int Wt, int Cout, int kd, forge_stream_t stream);
-int forge_wino_output_half(const float* Mm8, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
-                           const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,
-                           int ldo, int epilogue, forge_stream_t stream);
+int forge_wino_output_half(const float* Mm8, const float* Mm2_8 /* nullable second addend, 8 planes too */, long long bs2, long long pt2, const float* bias, const float* scale,
+                           const float* shift, float slope, const float* residual, const float* aux_h, const float* aux_z, float* out, float* out2, float* out3,
+                           int n, int D, int H, int W, int Cout, int ldo, int epilogue, forge_stream_t stream);
 int forge_wino_gemm_tile(long long R, int Cout, int Cin);   /* the workgroup tile letter ('A'..'E', see forge_conv_igemm_plan) forge_wino_gemm uses for R tile rows per point, Cin = C1 + C2 */
 int forge_wino_output(const float* Mm, const float* Mm2, long long bs2, long long pt2, const float* bias, const float* scale, const float* shift, float slope, const float* residual,
                       const float* aux_h, const float* aux_z, float* out, float* out2, float* out3, int n, int D, int H, int W, int Cout,

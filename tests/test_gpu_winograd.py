@@ -339,6 +339,14 @@ def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_f
         co.wino_output(Mm8, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, b, None, None, n, D, H, W, Cout, Cout, epi,
                        half=True)
         assert torch.equal(a, b)
+    # a second addend (the shared input halves of the grouped fusions) in the same 8-plane form: row-combined before the addition - not the same
+    # order of fp32 additions as the 16-plane kernel's (m + m2 first), so equal to rounding only
+    Mx = torch.randn(16, R, Cout, device=dev, generator=g)
+    Mx8 = torch.cat([(Mx[0:4] + Mx[4:8]) + Mx[8:12], (Mx[4:8] - Mx[8:12]) - Mx[12:16]])
+    a, b = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
+    co.wino_output(Mm, bias, None, None, 1.0, None, None, None, a, None, None, n, D, H, W, Cout, Cout, co.EPI_BIAS, Mm2=Mx)
+    co.wino_output(Mm8, bias, None, None, 1.0, None, None, None, b, None, None, n, D, H, W, Cout, Cout, co.EPI_BIAS, Mm2=Mx8, half=True)
+    assert (a - b).abs().max().item() <= 4e-6 * a.abs().max().item()
     if Cout % 2 == 0:                                                 # the GRU tails: gates (z | r -> h r) on Cout = 2 Ch columns, state update on Cout columns
         Ch = Cout // 2
         h = torch.randn(M, Ch, device=dev, generator=g)

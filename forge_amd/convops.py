@@ -396,7 +396,8 @@ def _wino_conv(x1, C1, bs1, x2, C2, bs2, U, bias, out, residual, grid, V1=None):
     if V1 is None:
         V1 = wino_input(x1, C1, C1, n, D, H, W, bs=bs1)
     V2 = None if x2 is None else wino_input(x2, C2, C2, n, D, H, W, bs=bs2)
-    Mm = torch.empty(16, n * D * (H // 2) * (W // 2), Cout, dtype=torch.float32, device=out.device)
+    R = n * D * (H // 2) * (W // 2)
+    Mm = torch.empty(8 if wino_half_applies(R, Cout, C1 + C2) else 16, R, Cout, dtype=torch.float32, device=out.device)
     wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
     return wino_output(Mm, bias, None, None, 1.0, residual, None, None, out, None, None, n, D, H, W, Cout, Cout, EPI_BIAS)
 
@@ -535,17 +536,22 @@ def wino_input(x, C, ld, n, D, H, W, bs=0, out=None, nsum=1, sum_stride=0):
 
 
 def wino_half_applies(R, Cout, Cin):
-    """The inference launches whose inverse transform's row stage runs in the GEMM epilogue (forge_wino_gemm_half / forge_wino_output_half, bitwise
-    the same results, half the point-product bytes through HBM): those forge_wino_gemm would give its 64 x 128 tile, without a forced plan."""
+    """The point-GEMM launches whose inverse transform's row stage runs in the GEMM epilogue (forge_wino_gemm_half / forge_wino_output_half: half the
+    point-product bytes through HBM; bitwise the same result without a second addend): those forge_wino_gemm would give its 64 x 128 tile - a rule
+    of (R, Cout) only - and no forced plan."""
     return STATE.plan_override is None and wino_gemm_tile(R, Cout, Cin) == "B"
 
 
 @_lib.on_tensor_device
-def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1, half=False):
+def wino_gemm(V1, C1, V2, C2, U, Mm, n, D, Ht, Wt, Cout, view=0, views=1, half=None):
     """Mm[16][n D Ht Wt][Cout] = the 16 point GEMMs. V1 [16][n views D Ht Wt][C1] may hold `views` views per batch element (the
     transformed inputs of every view of a scene, made by ONE wino_input launch): this call reads view `view`. V2 [16][R][C2] or None.
-    half: Mm receives the 8 planes [2][4][R][Cout] of forge_wino_gemm_half (its first half is used); pair with wino_output(half=True)."""
+    half: Mm receives the 8 planes [2][4][R][Cout] of forge_wino_gemm_half (the first half of a 16-plane buffer) for wino_output(half=True).
+    None = wino_half_applies' rule, which depends on (R, Cout) only - wino_output applies the same rule to ITS row count, so a GEMM / inverse pair over
+    the same rows always agrees; a caller whose products are consumed as the second addend (Mm2) of launches over FEWER rows passes their decision."""
     vol = D * Ht * Wt
+    if half is None:
+        half = wino_half_applies(n * vol, Cout, C1 + C2)
     kd = U.shape[1]
     if U.shape != (16, kd, Cout, C1 + C2) or kd not in (1, 3):
         raise ValueError("transformed weight %s does not match Cout=%d Cin=%d" % (tuple(U.shape), Cout, C1 + C2))
@@ -571,11 +577,13 @@ def wino_gemm_tile(R, Cout, Cin):
 
 
 @_lib.on_tensor_device
-def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1, half=False):
+def wino_output(Mm, bias, scale, shift, slope, residual, aux_h, aux_z, out, out2, out3, n, D, H, W, Cout, ldo, epilogue, Mm2=None, view=0, views=1, half=None):
     """out = epilogue(A^T (Mm + Mm2) A): the element-wise tails of conv_igemm (EPI_*) on the inverse-transformed tiles. Mm2 (optional)
     [16][n views D H/2 W/2][Cout]: point products of the input half for `views` views per batch element; this call adds view `view`.
-    half: Mm (and Mm2) hold wino_gemm(half=True)'s 8 planes (column stage only)."""
+    half: Mm (and Mm2) hold wino_gemm(half=True)'s 8 planes (column stage only); None = the rule wino_gemm applied to make them."""
     vol = D * (H // 2) * (W // 2)
+    if half is None:
+        half = wino_half_applies(n * vol, Cout, 0)
     if half:                                                            # Mm2 (if any) is in the 8-plane form too
         p2 = None if Mm2 is None else ctypes.c_void_p(Mm2.data_ptr() + 4 * view * vol * Cout)
         _lib.check(_lib.lib().forge_wino_output_half(_lib.ptr(Mm), p2, views * vol, 0 if Mm2 is None else Mm2.shape[1] * Cout, _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), float(slope), _lib.ptr(residual),

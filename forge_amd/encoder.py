@@ -461,8 +461,8 @@ class Encoder3D(co.PackedModule):
             R = n * D * (H // 2) * (W // 2)
             hf = co.wino_half_applies(R, 128, C)                        # row stage of the inverse transform in the GEMM epilogue: 8 planes instead of 16
             Mm = torch.empty(8 if hf else 16, R, 128, dtype=torch.float32, device=vol_rows.device)
-            co.wino_gemm(V, C, None, 0, U, Mm, n, D, H // 2, W // 2, 128, half=hf)
-            co.wino_output(Mm, bias, sc, sh, 0.01, None, None, None, out, None, None, n, D, H, W, 128, 128, co.EPI_AFFINE_ACT, half=hf)
+            co.wino_gemm(V, C, None, 0, U, Mm, n, D, H // 2, W // 2, 128)
+            co.wino_output(Mm, bias, sc, sh, 0.01, None, None, None, out, None, None, n, D, H, W, 128, 128, co.EPI_AFFINE_ACT)
         else:
             co.conv_igemm(vol_rows, C, C, None, 0, 0, w, bias, sc, sh, 0.01, None, None, None, out, None,
                           (n, D, H, W), (D, H, W), 128, 128, co.TAPS_3x3x3, epilogue=co.EPI_AFFINE_ACT)

@@ -580,8 +580,9 @@ class _FuseGroupsTrain(torch.autograd.Function):
         U = {k: co.wino_pack_packed(v) for k, v in packs.items()}
         Vx = co.wino_input(xr, C, C, b * t, D, H, W)                         # [16][b t R1][C]: all views of all scenes
         MXg, MXc = newV(b * t * R1, 2 * C), newV(b * t * R1, C)
-        co.wino_gemm(Vx, C, None, 0, U["gx"], MXg, b * t, D, Ht, Wt, 2 * C)
-        co.wino_gemm(Vx, C, None, 0, U["ox"], MXc, b * t, D, Ht, Wt, C)
+        hx = co.wino_half_applies(R, C, C)                                   # the form (8 / 16 planes) of the per-step launches that consume MXg / MXc as second addends
+        co.wino_gemm(Vx, C, None, 0, U["gx"], MXg, b * t, D, Ht, Wt, 2 * C, half=hx)
+        co.wino_gemm(Vx, C, None, 0, U["ox"], MXc, b * t, D, Ht, Wt, C, half=hx)
         Mm = newV(R, 2 * C)
         Mc = Mm.view(-1)[:16 * R * C].view(16, R, C)                         # the C-column problems reuse the front of the buffer
         bnargs = lambda m: bn_module_args(m)
@@ -895,13 +896,12 @@ class ConvGRU_3D(co.PackedModule):
         BatchNorm + LeakyReLU tail (scratch Vh / Mc / t0); the view mean of models/encoder.py:62 is taken inside the first input transform."""
         b, D, H, W = geo
         C = h.shape[-1]
-        hf = co.wino_half_applies(b * D * (H // 2) * (W // 2), C, C)     # row stage of the inverse transform in the GEMM epilogue (bitwise the same)
         co.wino_input(src, C, C, b, D, H, W, bs=bs, out=Vh, nsum=nsum, sum_stride=sum_stride)
-        co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, H // 2, W // 2, C, half=hf)
-        co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT, half=hf)
+        co.wino_gemm(Vh, C, None, 0, p["fc0_U"], Mc, b, D, H // 2, W // 2, C)
+        co.wino_output(Mc, p["fc0_b"], p["bn1"][0], p["bn1"][1], 0.01, None, None, None, t0, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
         co.wino_input(t0, C, C, b, D, H, W, out=Vh)
-        co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, H // 2, W // 2, C, half=hf)
-        co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT, half=hf)
+        co.wino_gemm(Vh, C, None, 0, p["fc3_U"], Mc, b, D, H // 2, W // 2, C)
+        co.wino_output(Mc, p["fc3_b"], p["bn4"][0], p["bn4"][1], 0.01, None, None, None, h, None, None, b, D, H, W, C, C, co.EPI_AFFINE_ACT)
 
     def _fuse_wino(self, xr, h0=None):
         """fuse_hip with every 3x3x3 convolution as Winograd F(2x2, 3x3) x 3 depth taps (csrc/winograd.hip): 2.25x fewer MFMA FLOPs.
@@ -926,15 +926,14 @@ class ConvGRU_3D(co.PackedModule):
         else:
             h.copy_(h0.permute(0, 2, 3, 4, 1).reshape(M, C))
         z, hr, h2, out = new(), new(), t0, new()
-        hg, hc = co.wino_half_applies(R, 2 * C, 2 * C), co.wino_half_applies(R, C, 2 * C)
         for ti in range(t):
             co.wino_input(h, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t, half=hg)
-            co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, half=hg)
+            co.wino_gemm(Vx, C, Vh, C, p["gate_U"], Mm, b, D, Ht, Wt, 2 * C, view=ti, views=t)
+            co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES)
             co.wino_input(hr, C, C, b, D, H, W, out=Vh)
-            co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t, half=hc)
+            co.wino_gemm(Vx, C, Vh, C, p["out_U"], Mc, b, D, Ht, Wt, C, view=ti, views=t)
             last = ti == t - 1
-            co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C, co.EPI_GRU_OUT, half=hc)
+            co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C, co.EPI_GRU_OUT)
             h, h2 = h2, h
         return out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3)
 
@@ -953,14 +952,14 @@ class ConvGRU_3D(co.PackedModule):
         new = lambda c=C: torch.empty(M, c, dtype=torch.float32, device=dev)
         geo = (b, D, H, W)
         Vx = co.wino_input(xr, C, C, b * t, D, H, W)
-        # 8-plane form (row stage of the inverse transform in the GEMM epilogue) when every launch of the chain takes the 64 x 128 tile: the shared
-        # input-half products and the per-step hidden-half products are then row-combined separately and added in the column-stage kernel
-        hf = all(co.wino_half_applies(r_, n_, C) for r_, n_ in ((R, 2 * C), (R, C), (b * t * R1, 2 * C), (b * t * R1, C)))
-        P = 8 if hf else 16
+        # 8-plane form (row stage of the inverse transform in the GEMM epilogue, convops.wino_half_applies) for the launches on the 64 x 128 tile: the
+        # shared input-half products and the per-step hidden-half products are then row-combined separately and added in the column-stage kernel
+        hx = co.wino_half_applies(R, C, C)                            # decided by the per-step launches (R rows); the all-view launches follow it
+        P = 8 if hx else 16
         MXg = torch.empty(P, b * t * R1, 2 * C, dtype=torch.float32, device=dev)
         MXc = torch.empty(P, b * t * R1, C, dtype=torch.float32, device=dev)
-        co.wino_gemm(Vx, C, None, 0, p["gate_Ux"], MXg, b * t, D, Ht, Wt, 2 * C, half=hf)
-        co.wino_gemm(Vx, C, None, 0, p["out_Ux"], MXc, b * t, D, Ht, Wt, C, half=hf)
+        co.wino_gemm(Vx, C, None, 0, p["gate_Ux"], MXg, b * t, D, Ht, Wt, 2 * C, half=hx)
+        co.wino_gemm(Vx, C, None, 0, p["out_Ux"], MXc, b * t, D, Ht, Wt, C, half=hx)
         Vh = torch.empty(16, R, C, dtype=torch.float32, device=dev)
         Mm = torch.empty(P, R, 2 * C, dtype=torch.float32, device=dev)
         Mc = Mm.view(-1)[:P * R * C].view(P, R, C)
@@ -977,13 +976,13 @@ class ConvGRU_3D(co.PackedModule):
             z, hr, h2, out = new(), new(), t0, new()
             for k, ti in enumerate(grp):
                 co.wino_input(h, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vh, C, None, 0, p["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C, half=hf)
-                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t, half=hf)
+                co.wino_gemm(Vh, C, None, 0, p["gate_Uh"], Mm, b, D, Ht, Wt, 2 * C)
+                co.wino_output(Mm, p["gate_b"], None, None, 1.0, None, h, None, z, hr, None, *geo, 2 * C, C, co.EPI_GRU_GATES, Mm2=MXg, view=ti, views=t)
                 co.wino_input(hr, C, C, b, D, H, W, out=Vh)
-                co.wino_gemm(Vh, C, None, 0, p["out_Uh"], Mc, b, D, Ht, Wt, C, half=hf)
+                co.wino_gemm(Vh, C, None, 0, p["out_Uh"], Mc, b, D, Ht, Wt, C)
                 last = k == len(grp) - 1
                 co.wino_output(Mc, p["out_b"], p["norm"][0], p["norm"][1], 1.0, None, h, z, h2, out if last else None, None, *geo, C, C,
-                               co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t, half=hf)
+                               co.EPI_GRU_OUT, Mm2=MXc, view=ti, views=t)
                 h, h2 = h2, h
             outs.append(out.reshape(b, D, H, W, C).permute(0, 4, 1, 2, 3))
         return outs

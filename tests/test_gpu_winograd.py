@@ -326,7 +326,7 @@ def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_f
     V1 = co.wino_input(x1, C1, C1, n, D, H, W)
     V2 = None if x2 is None else co.wino_input(x2, C2, C2, n, D, H, W)
     Mm, Mm8 = torch.empty(16, R, Cout, device=dev), torch.full((8, R, Cout), float("nan"), device=dev)
-    co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout)
+    co.wino_gemm(V1, C1, V2, C2, U, Mm, n, D, H // 2, W // 2, Cout, half=False)
     co.wino_gemm(V1, C1, V2, C2, U, Mm8, n, D, H // 2, W // 2, Cout, half=True)
     s0 = (Mm[0:4] + Mm[4:8]) + Mm[8:12]                              # rows of A^T M over the point index i (p = 4 i + j)
     s1 = (Mm[4:8] - Mm[8:12]) - Mm[12:16]
@@ -335,7 +335,8 @@ def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_f
     res = torch.randn(M, Cout, device=dev, generator=g)
     for epi, kw in ((co.EPI_BIAS, {}), (co.EPI_AFFINE_ACT, dict(scale=sc, shift=sh, slope=0.01, residual=res))):
         a, b = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
-        co.wino_output(Mm, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, a, None, None, n, D, H, W, Cout, Cout, epi)
+        co.wino_output(Mm, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, a, None, None, n, D, H, W, Cout, Cout, epi,
+                       half=False)
         co.wino_output(Mm8, bias, kw.get("scale"), kw.get("shift"), kw.get("slope", 1.0), kw.get("residual"), None, None, b, None, None, n, D, H, W, Cout, Cout, epi,
                        half=True)
         assert torch.equal(a, b)
@@ -344,7 +345,7 @@ def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_f
     Mx = torch.randn(16, R, Cout, device=dev, generator=g)
     Mx8 = torch.cat([(Mx[0:4] + Mx[4:8]) + Mx[8:12], (Mx[4:8] - Mx[8:12]) - Mx[12:16]])
     a, b = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
-    co.wino_output(Mm, bias, None, None, 1.0, None, None, None, a, None, None, n, D, H, W, Cout, Cout, co.EPI_BIAS, Mm2=Mx)
+    co.wino_output(Mm, bias, None, None, 1.0, None, None, None, a, None, None, n, D, H, W, Cout, Cout, co.EPI_BIAS, Mm2=Mx, half=False)
     co.wino_output(Mm8, bias, None, None, 1.0, None, None, None, b, None, None, n, D, H, W, Cout, Cout, co.EPI_BIAS, Mm2=Mx8, half=True)
     assert (a - b).abs().max().item() <= 4e-6 * a.abs().max().item()
     if Cout % 2 == 0:                                                 # the GRU tails: gates (z | r -> h r) on Cout = 2 Ch columns, state update on Cout columns

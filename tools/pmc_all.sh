@@ -42,9 +42,9 @@ names = {"rotate_fwd_kernel": "rotate_fwd_kernel", "render_fwd_kernel": "render_
          "conv_igemm_kernel<64, 64": "conv_igemm_kernel<64, 64, 4> (ConvGRU state, M=32768 N=128 K=6912)"}
 R_ = 32 * 16 * 16
 wino = {"wino_input_kernel": ("wino_input_kernel (h -> V_h, 32^3 x 128 channels)", 4.0 * (32 ** 3 * 128 + 16 * R_ * 128)),
-        "conv_igemm_kernel<": ("conv_igemm_kernel winograd gates point GEMMs (16 x [8192 x 768] x [768 x 256], one launch)",
-                               4.0 * (16 * R_ * 256 + 16 * 3 * 256 * 256 + 16 * R_ * 256)),
-        "wino_output_kernel": ("wino_output_kernel<GRU gates> (Mm -> z, h*r)", 4.0 * (16 * R_ * 256 + 3 * 32 ** 3 * 128))}
+        "conv_igemm_kernel<": ("conv_igemm_kernel winograd gates point GEMMs (16 x [8192 x 768] x [768 x 256], one launch; row stage of the inverse "
+                               "transform in the epilogue: 8 planes written)", 4.0 * (16 * R_ * 256 + 16 * 3 * 256 * 256 + 8 * R_ * 256)),
+        "wino_output_kernel": ("wino_output_kernel<GRU gates, HALF> (Mm8 -> z, h*r)", 4.0 * (8 * R_ * 256 + 3 * 32 ** 3 * 128))}
 Vb, Hb, Sb, Cb, Db = 10, 128, 64, 16, 64
 rbwd = {"render_bwd_rays_kernel<4, false>": ("render_bwd_rays_kernel<4, false> (10 views x 128^2 rays x 64 samples of one 64^3 volume: march + per-sample scalars)",
                                               4.0 * (17 * Db ** 3 + Vb * Hb * Hb * (Cb + 1) + 2 * Vb * Hb * Hb * Sb)),

@@ -78,6 +78,7 @@ v = fmod._v
 shape_of = {
     "forge_conv_igemm": lambda a: (v(a[19]) * v(a[20]) * v(a[21]) * v(a[22]), v(a[27]), v(a[1]) + v(a[5]), v(a[30]), "is%d os%d" % (v(a[23]), v(a[31]))),
     "forge_wino_gemm": lambda a: (v(a[12]) * v(a[13]) * v(a[14]) * v(a[15]), v(a[16]), v(a[1]) + v(a[6]), v(a[17]), "16 points"),
+    "forge_wino_gemm_half": lambda a: (v(a[12]) * v(a[13]) * v(a[14]) * v(a[15]), v(a[16]), v(a[1]) + v(a[6]), v(a[17]), "16 points, 8 planes out"),
     "forge_conv_wgrad": lambda a: (v(a[11]) * v(a[12]) * v(a[13]) * v(a[14]), v(a[19]), v(a[3]) + v(a[7]), v(a[21]), "is%d" % v(a[15])),
     "forge_wino_wgrad": lambda a: (v(a[10]) * v(a[11]) * v(a[12]) * v(a[13]), v(a[14]), v(a[2]) + v(a[6]), v(a[15]), "16 points"),
     "forge_attention_fwd": lambda a: (v(a[5]) * v(a[6]), v(a[7]), v(a[8]), 1, "keys x d"),

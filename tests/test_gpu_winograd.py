@@ -364,3 +364,26 @@ def test_half_inverse_transform_in_the_gemm_epilogue_is_bitwise_the_two_launch_f
         co.wino_output(Mm8 if half else Mm, bias, sc, sh, 1.0, None, hfull, zfull, hn, hb, cand, n, D, H, W, Cout, Cout, co.EPI_GRU_OUT, half=half)
         outs.append((hn, hb, cand))
     assert all(torch.equal(u, v) for u, v in zip(*outs))
+
+
+def test_half_form_one_depth_tap_2d_launches_bitwise():
+    """The 2-D form (kd = 1: the ResNet layer3 / layer4 3x3 convolutions at many images, planes of the (n, D) grid do not mix) through the four-point
+    GEMM: bitwise the 16-plane pair, ragged tile rows included."""
+    from forge_amd import convops as co
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(9)
+    n, H, W, C, Cout = 37, 16, 16, 256, 256                            # R = 37 x 64 = 2368 tile rows: not a multiple of the 64-row tile
+    R, M = n * (H // 2) * (W // 2), n * H * W
+    assert co.wino_half_applies(R, Cout, C)
+    V = torch.randn(16, R, C, device=dev, generator=g)
+    U = torch.randn(16, 1, Cout, C, device=dev, generator=g) * 0.05
+    sc, sh = torch.rand(Cout, device=dev, generator=g) + 0.5, torch.randn(Cout, device=dev, generator=g)
+    Mm, Mm8 = torch.empty(16, R, Cout, device=dev), torch.empty(8, R, Cout, device=dev)
+    co.wino_gemm(V, C, None, 0, U, Mm, n, 1, H // 2, W // 2, Cout, half=False)
+    co.wino_gemm(V, C, None, 0, U, Mm8, n, 1, H // 2, W // 2, Cout, half=True)
+    ref = torch.einsum("prc,poc->pro", V.double(), U[:, 0].double())
+    assert (Mm.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+    a, b = torch.empty(M, Cout, device=dev), torch.empty(M, Cout, device=dev)
+    co.wino_output(Mm, None, sc, sh, 0.0, None, None, None, a, None, None, n, 1, H, W, Cout, Cout, co.EPI_AFFINE_ACT, half=False)
+    co.wino_output(Mm8, None, sc, sh, 0.0, None, None, None, b, None, None, n, 1, H, W, Cout, Cout, co.EPI_AFFINE_ACT, half=True)
+    assert torch.equal(a, b)
